@@ -1,0 +1,126 @@
+"""ctypes binding of libavid_hip.so (the C-ABI declared in include/avid_hip.h).
+
+The HIP library is THE compute path: there is no CPU / eager fallback.  If the shared object is
+missing the import of this module raises, loudly (``AVID_HIP_AUTOBUILD=1`` lets it try ``make``
+once first, which is what ``__graft_entry__.build()`` does explicitly).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libavid_hip.so")
+
+AVID_OK = 0
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``avid_conv_desc`` (include/avid_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "B", "Ti", "Hi", "Wi", "Cin", "To", "Ho", "Wo", "Cout", "kt", "kh", "kw",
+        "st", "sh", "sw", "pt", "ph", "pw", "x_channel_first")]
+
+
+def build_library(verbose=False):
+    """Compile csrc/*.hip for gfx950 into avid_hip/libavid_hip.so (hipcc cross-compiles without a GPU)."""
+    proc = subprocess.run(["make", "-C", _PKG, "-j8"], capture_output=True, text=True)
+    if verbose or proc.returncode != 0:
+        print(proc.stdout[-4000:])
+        print(proc.stderr[-4000:])
+    if proc.returncode != 0:
+        raise RuntimeError("building libavid_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        if os.environ.get("AVID_HIP_AUTOBUILD", "0") == "1":
+            build_library()
+        else:
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback). "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C avid-cma_amd`.")
+    return C.CDLL(LIB_PATH)
+
+
+_lib = _load()
+
+_vp, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+_dp = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list every symbol of include/avid_hip.h (checked by tests)
+SIGNATURES = {
+    "avid_last_error": (C.c_char_p, []),
+    "avid_version": (_i, []),
+    "avid_device_info": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
+    "avid_conv_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "avid_conv_dgrad_workspace_bytes": (_sz, [_dp]),
+    "avid_conv_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avid_conv_wgrad_workspace_bytes": (_sz, [_dp]),
+    "avid_conv_wgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avid_bn_workspace_bytes": (_sz, [_i64, _i]),
+    "avid_bn_fwd_train": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avid_bn_fwd_eval": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
+    "avid_bn_bwd": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avid_maxpool_hw3s2_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "avid_maxpool_hw3s2_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "avid_global_maxpool_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "avid_global_maxpool_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "avid_relu_bwd": (_i, [_i64, _vp, _vp, _vp, _vp]),
+    "avid_colsum": (_i, [_i64, _i, _vp, _vp, _vp]),
+    "avid_l2norm_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "avid_l2norm_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "avid_alias_draw": (_i, [_i64, _i64, _vp, _vp, _i, _u64, _u64, _vp, _i64, _vp, _vp]),
+    "avid_bank_scores_fwd": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "avid_bank_scores_bwd": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
+    "avid_mean_exp": (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    "avid_nce_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _i, _vp, _vp]),
+    "avid_nce_bwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "avid_bank_update": (_i, [_i, _i, _i64, _vp, _vp, _vp, _f, _vp]),
+    "avid_cma_negatives": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "avid_cma_topk_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "avid_cma_topk": (_i, [_i64, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "avid_adam_flat": (_i, [_i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i64, _f, _vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(_lib, _name)          # AttributeError here == a declared symbol is not exported
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class AvidHipError(RuntimeError):
+    pass
+
+
+def last_error() -> str:
+    msg = _lib.avid_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str):
+    """Error convention of the C-ABI: negative return -> Python exception (never a silent fallback)."""
+    if rc != AVID_OK:
+        raise AvidHipError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+def call(name: str, *args):
+    check(getattr(_lib, name)(*args), name)
+
+
+def raw(name: str):
+    return getattr(_lib, name)
+
+
+def version() -> int:
+    return _lib.avid_version()
+
+
+def device_info(device: int = 0):
+    cu, lds = C.c_int(0), C.c_int(0)
+    buf = C.create_string_buffer(64)
+    check(_lib.avid_device_info(device, C.byref(cu), C.byref(lds), buf, 64), "avid_device_info")
+    return {"cu_count": cu.value, "lds_bytes": lds.value, "arch": buf.value.decode()}

@@ -1,0 +1,399 @@
+"""torch.autograd.Function wrappers around the C-ABI (include/avid_hip.h).
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and the autograd graph.
+Every op below launches hand-written gfx950 kernels through ctypes; none has a torch/CPU fallback —
+a CPU tensor raises ``AvidHipError``.
+
+Layout contract: activations are contiguous channels-last ``[B, T, H, W, C]``;
+conv / linear weights keep the reference's logical shape ``[Cout, Cin, kt, kh, kw]`` but live in
+memory as ``[Cout][kt][kh][kw][Cin]`` (torch ``channels_last_3d``); see ``make_weight``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import lib
+from .lib import AvidHipError, ConvDesc
+
+_WS = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise AvidHipError("avid_hip ops need HIP device tensors — there is no CPU fallback")
+
+
+def workspace(device, nbytes):
+    """Stream-ordered scratch, grown on demand, one per (device, stream)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------------------------------------
+# weights
+# ------------------------------------------------------------------------------------------------
+def make_weight(cout, cin, *k):
+    """Uninitialised tensor of logical shape [cout, cin, *k] whose memory is [cout, *k, cin]."""
+    return torch.empty(cout, *k, cin).movedim(-1, 1)
+
+
+def weight_layout_ok(w):
+    return w.dim() == 2 and w.is_contiguous() or (w.dim() > 2 and w.movedim(1, -1).is_contiguous())
+
+
+def _kdims(w):
+    k = tuple(w.shape[2:])
+    return (1,) * (3 - len(k)) + k
+
+
+def _desc(xs, cin, cout, k, stride, pad, channel_first):
+    B, Ti, Hi, Wi = xs
+    d = ConvDesc()
+    d.B, d.Ti, d.Hi, d.Wi, d.Cin = B, Ti, Hi, Wi, cin
+    d.kt, d.kh, d.kw = k
+    d.st, d.sh, d.sw = stride
+    d.pt, d.ph, d.pw = pad
+    d.To = (Ti + 2 * pad[0] - k[0]) // stride[0] + 1
+    d.Ho = (Hi + 2 * pad[1] - k[1]) // stride[1] + 1
+    d.Wo = (Wi + 2 * pad[2] - k[2]) // stride[2] + 1
+    d.Cout = cout
+    d.x_channel_first = 1 if channel_first else 0
+    return d
+
+
+class _ConvCL(Function):
+    """y = conv(x, w) [+ addend] [+ bias] [relu]  — avid_conv_fwd / avid_conv_dgrad / avid_conv_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, addend, bias, stride, pad, relu, channel_first):
+        _need_cuda(x, w, addend, bias)
+        if not x.is_contiguous():
+            raise AvidHipError("conv: x must be contiguous (channels-last [B,T,H,W,C])")
+        if not weight_layout_ok(w):
+            raise AvidHipError("conv: weight memory is not [Cout][k...][Cin] (channels-last); "
+                               "was the parameter re-created with .contiguous()?")
+        if x.dtype != torch.float32 or w.dtype != torch.float32:
+            raise AvidHipError("conv: fp32 only")
+        k = _kdims(w)
+        cout, cin = w.shape[0], w.shape[1]
+        if channel_first:
+            B, c, Ti, Hi, Wi = x.shape
+        else:
+            B, Ti, Hi, Wi, c = x.shape
+        if c != cin:
+            raise AvidHipError(f"conv: input has {c} channels, weight expects {cin}")
+        d = _desc((B, Ti, Hi, Wi), cin, cout, k, stride, pad, channel_first)
+        y = torch.empty((B, d.To, d.Ho, d.Wo, cout), dtype=torch.float32, device=x.device)
+        if addend is not None and (addend.shape != y.shape or not addend.is_contiguous()):
+            raise AvidHipError("conv: addend must be a contiguous tensor of the output shape")
+        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(addend), _p(bias), int(relu), _p(y), _stream())
+        ctx.d, ctx.relu, ctx.channel_first = d, relu, channel_first
+        ctx.has_addend, ctx.has_bias = addend is not None, bias is not None
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        d = ctx.d
+        dy = dy.contiguous()
+        st = _stream()
+        if ctx.relu:
+            g = torch.empty_like(dy)
+            lib.call("avid_relu_bwd", dy.numel(), _p(y), _p(dy), _p(g), st)
+            dy = g
+        dx = dw = dadd = dbias = None
+        if ctx.needs_input_grad[0]:
+            if ctx.channel_first:
+                raise AvidHipError("conv: input gradient of a channel-first stem is not implemented (never needed)")
+            nb = lib.raw("avid_conv_dgrad_workspace_bytes")(C.byref(d))
+            ws = workspace(x.device, nb)
+            dx = torch.empty_like(x)
+            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), None, _p(dx), _p(ws), ws.numel(), st)
+        if ctx.needs_input_grad[1]:
+            nb = lib.raw("avid_conv_wgrad_workspace_bytes")(C.byref(d))
+            ws = workspace(x.device, nb)
+            dw = torch.empty_like(w)          # preserve_format keeps the [Cout][k][Cin] memory
+            if dw.stride() != w.stride() and not weight_layout_ok(dw):
+                raise AvidHipError("conv: empty_like did not preserve the weight layout")
+            lib.call("avid_conv_wgrad", C.byref(d), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), st)
+        if ctx.has_addend and ctx.needs_input_grad[2]:
+            dadd = dy
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            dbias = torch.empty(d.Cout, dtype=torch.float32, device=dy.device)
+            lib.call("avid_colsum", dy.numel() // d.Cout, d.Cout, _p(dy), _p(dbias), st)
+        return dx, dw, dadd, dbias, None, None, None, None
+
+
+def conv_cl(x, w, stride=(1, 1, 1), pad=(0, 0, 0), addend=None, bias=None, relu=False, channel_first=False):
+    return _ConvCL.apply(x, w, addend, bias, tuple(stride), tuple(pad), bool(relu), bool(channel_first))
+
+
+def linear(x, w, bias=None, relu=False):
+    """nn.Linear (+ReLU) as a 1x1x1 conv over [B,1,1,1,C] — models/av_wrapper.py:23-29."""
+    B, Cin = x.shape
+    y = conv_cl(x.reshape(B, 1, 1, 1, Cin), w, (1, 1, 1), (0, 0, 0), None, bias, relu, False)
+    return y.reshape(B, w.shape[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm (+ReLU)
+# ------------------------------------------------------------------------------------------------
+class _BatchNormCL(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, stats, training, momentum, eps, relu):
+        _need_cuda(x, gamma, beta)
+        if not x.is_contiguous():
+            raise AvidHipError("bn: x must be contiguous channels-last")
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        rm, rv = stats
+        y = torch.empty_like(x)
+        st = _stream()
+        if training:
+            mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+            invstd = torch.empty(Cc, dtype=torch.float32, device=x.device)
+            nb = lib.raw("avid_bn_workspace_bytes")(M, Cc)
+            ws = workspace(x.device, nb)
+            lib.call("avid_bn_fwd_train", M, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv), float(momentum),
+                     float(eps), int(relu), _p(y), _p(mean), _p(invstd), _p(ws), ws.numel(), st)
+            ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        else:
+            lib.call("avid_bn_fwd_eval", M, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv), float(eps), int(relu),
+                     _p(y), st)
+            ctx.save_for_backward()
+        ctx.training, ctx.relu, ctx.M, ctx.C = training, relu, M, Cc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise AvidHipError("bn: backward through eval-mode BatchNorm is not implemented")
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(ctx.C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(ctx.C, dtype=torch.float32, device=x.device)
+        nb = lib.raw("avid_bn_workspace_bytes")(ctx.M, ctx.C)
+        ws = workspace(x.device, nb)
+        lib.call("avid_bn_bwd", ctx.M, ctx.C, _p(x), _p(y), _p(dy), _p(gamma), _p(mean), _p(invstd), int(ctx.relu),
+                 _p(dx), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream())
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batch_norm_cl(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False):
+    return _BatchNormCL.apply(x, gamma, beta, (running_mean, running_var), bool(training), momentum, eps, bool(relu))
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling
+# ------------------------------------------------------------------------------------------------
+class _MaxPoolHW3S2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        B, T, H, W, Cc = x.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = torch.empty((B, T, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+        am = torch.empty((B, T, Ho, Wo, Cc), dtype=torch.uint8, device=x.device)
+        lib.call("avid_maxpool_hw3s2_fwd", B, T, H, W, Cc, _p(x.contiguous()), _p(y), _p(am), _stream())
+        ctx.save_for_backward(am)
+        ctx.shape = (B, T, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (am,) = ctx.saved_tensors
+        B, T, H, W, Cc = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        lib.call("avid_maxpool_hw3s2_bwd", B, T, H, W, Cc, _p(dy.contiguous()), _p(am), _p(dx), _stream())
+        return dx
+
+
+def maxpool_hw3s2(x):
+    return _MaxPoolHW3S2.apply(x)
+
+
+class _GlobalMaxPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        B, Cc = x.shape[0], x.shape[-1]
+        S = x.numel() // (B * Cc)
+        y = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+        am = torch.empty((B, Cc), dtype=torch.int32, device=x.device)
+        lib.call("avid_global_maxpool_fwd", B, S, Cc, _p(x), _p(y), _p(am), _stream())
+        ctx.save_for_backward(am)
+        ctx.shape = tuple(x.shape)
+        ctx.S = S
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (am,) = ctx.saved_tensors
+        B, Cc = ctx.shape[0], ctx.shape[-1]
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        lib.call("avid_global_maxpool_bwd", B, ctx.S, Cc, _p(dy.contiguous()), _p(am), _p(dx), _stream())
+        return dx
+
+
+def global_maxpool(x):
+    """AdaptiveMaxPool{2,3}d(1) over a channels-last tensor -> [B, C]."""
+    return _GlobalMaxPool.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# criterion ops
+# ------------------------------------------------------------------------------------------------
+class _L2Norm(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = x.contiguous()
+        bs, D = x.shape
+        y = torch.empty_like(x)
+        nrm = torch.empty(bs, dtype=torch.float32, device=x.device)
+        lib.call("avid_l2norm_fwd", bs, D, _p(x), _p(y), _p(nrm), _stream())
+        ctx.save_for_backward(y, nrm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, nrm = ctx.saved_tensors
+        bs, D = y.shape
+        dx = torch.empty_like(y)
+        lib.call("avid_l2norm_bwd", bs, D, _p(y), _p(nrm), _p(dy.contiguous()), _p(dx), _stream())
+        return dx
+
+
+def l2_normalize(x):
+    return _L2Norm.apply(x)
+
+
+class _BankScores(Function):
+    """scores[b][j] = <bank[idx[b][j]], emb[b]> / T ; the bank gets no gradient (avid.py:56)."""
+
+    @staticmethod
+    def forward(ctx, emb, bank, idx, inv_T):
+        _need_cuda(emb, bank, idx)
+        emb = emb.contiguous()
+        idx = idx.contiguous()
+        if idx.dtype != torch.int64 or not bank.is_contiguous():
+            raise AvidHipError("bank_scores: idx must be int64 and the bank contiguous")
+        bs, D = emb.shape
+        R = idx.shape[1]
+        s = torch.empty((bs, R), dtype=torch.float32, device=emb.device)
+        # The reference's autograd keeps the PRE-update rows (the bank is EMA-updated inside forward,
+        # criterions/avid.py:78, before backward runs): snapshot them while they stream through.
+        rows = torch.empty((bs, R, D), dtype=torch.float32, device=emb.device) if emb.requires_grad else None
+        lib.call("avid_bank_scores_fwd", bs, R, D, bank.shape[0], _p(idx), _p(bank), _p(emb), float(inv_T), _p(s),
+                 _p(rows), _stream())
+        ctx.save_for_backward(rows)
+        ctx.inv_T, ctx.dims = inv_T, (bs, R, D)
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        (rows,) = ctx.saved_tensors
+        bs, R, D = ctx.dims
+        demb = torch.empty((bs, D), dtype=torch.float32, device=ds.device)
+        lib.call("avid_bank_scores_bwd", bs, R, D, 0, _p(rows), None, None, _p(ds.contiguous()),
+                 float(ctx.inv_T), 0, _p(demb), _stream())
+        return demb, None, None, None
+
+
+def bank_scores(emb, bank, idx, inv_T):
+    return _BankScores.apply(emb, bank, idx, inv_T)
+
+
+def mean_exp(s):
+    """mean(exp(s)) of a (possibly column-sliced) 2-D score matrix -> 0-d device tensor."""
+    _need_cuda(s)
+    rows, cols = s.shape
+    if s.stride(1) != 1:
+        s = s.contiguous()
+    out = torch.empty((), dtype=torch.float32, device=s.device)
+    lib.call("avid_mean_exp", rows, cols, s.stride(0), _p(s), _p(out), _stream())
+    return out
+
+
+class _NCELoss(Function):
+    @staticmethod
+    def forward(ctx, spos, sneg, Z):
+        _need_cuda(spos, sneg, Z)
+        if spos.stride(1) != 1:
+            spos = spos.contiguous()
+        if sneg.stride(1) != 1:
+            sneg = sneg.contiguous()
+        bs, P = spos.shape
+        K = sneg.shape[1]
+        loss = torch.empty((), dtype=torch.float32, device=spos.device)
+        lib.call("avid_nce_fwd", bs, P, K, _p(spos), spos.stride(0), _p(sneg), sneg.stride(0), _p(Z), 1.0, 0,
+                 _p(loss), _stream())
+        ctx.save_for_backward(spos, sneg, Z)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        spos, sneg, Z = ctx.saved_tensors
+        bs, P = spos.shape
+        K = sneg.shape[1]
+        dpos = torch.empty((bs, P), dtype=torch.float32, device=spos.device)
+        dneg = torch.empty((bs, K), dtype=torch.float32, device=spos.device)
+        lib.call("avid_nce_bwd", bs, P, K, _p(spos), spos.stride(0), _p(sneg), sneg.stride(0), _p(Z),
+                 _p(dloss.contiguous()), 1.0, _p(dpos), _p(dneg), _stream())
+        return dpos, dneg, None
+
+
+def nce_loss(spos, sneg, Z):
+    return _NCELoss.apply(spos, sneg, Z)
+
+
+def alias_draw(n, K, prob, alias, uniform, seed, offset, y=None, per_row=1, device=None):
+    device = device if device is not None else (y.device if y is not None else prob.device)
+    if device.type != "cuda":
+        raise AvidHipError("alias_draw: HIP device required")
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    lib.call("avid_alias_draw", n, K, _p(prob), _p(alias), int(uniform), int(seed), int(offset), _p(y), int(per_row),
+             _p(out), _stream())
+    return out
+
+
+def bank_update(bank, y, emb, momentum):
+    _need_cuda(bank, y, emb)
+    lib.call("avid_bank_update", y.shape[0], bank.shape[1], bank.shape[0], _p(bank), _p(y.contiguous()),
+             _p(emb.contiguous()), float(momentum), _stream())
+
+
+def cma_negatives(positive_set, y, rand_idx):
+    _need_cuda(positive_set, y, rand_idx)
+    bs, K = rand_idx.shape
+    P = positive_set.shape[1]
+    pos = torch.empty((bs, P), dtype=torch.int64, device=y.device)
+    neg = torch.empty((bs, K), dtype=torch.int64, device=y.device)
+    lib.call("avid_cma_negatives", bs, K, P, _p(positive_set), _p(y.contiguous()), _p(rand_idx.contiguous()),
+             _p(pos), _p(neg), _stream())
+    return pos, neg
+
+
+def adam_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    _need_cuda(p, g, m, v)
+    lib.call("avid_adam_flat", p.numel(), _p(p), _p(g), _p(m), _p(v), float(lr), float(beta1), float(beta2),
+             float(eps), float(wd), int(step), float(grad_scale), _stream())

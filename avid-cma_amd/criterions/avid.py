@@ -1,0 +1,176 @@
+"""AVID memory-bank criterion on gfx950 kernels (reference: criterions/avid.py:20-236)."""
+import pprint
+
+import torch
+from torch import nn
+import torch.distributed as dist
+
+from avid_hip import ops
+from utils.distributed_utils import _gather_from_all
+from utils.alias_method import AliasMethod
+from criterions.nce import NCECriterion
+
+__all__ = ['AVID']
+
+
+def _device_of(device):
+    if isinstance(device, torch.device):
+        return device
+    return torch.device('cuda', int(device) if device is not None else torch.cuda.current_device())
+
+
+def gather_update_records(video_emb, audio_emb, y):
+    """The three all_gathers of avid.py:108-111 fused into ONE: a packed [bs, 2D+2] fp32 record
+    (the int64 id travels bit-cast as two floats), 1032 B/sample at D = 128."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return video_emb, audio_emb, y
+    bs, D = video_emb.shape
+    rec = torch.empty((bs, 2 * D + 2), dtype=torch.float32, device=video_emb.device)
+    rec[:, :D] = video_emb
+    rec[:, D:2 * D] = audio_emb
+    rec[:, 2 * D:] = y.contiguous().view(torch.float32).view(bs, 2)
+    allrec = _gather_from_all(rec)
+    y_all = allrec[:, 2 * D:].contiguous().view(torch.int64).view(-1)
+    return allrec[:, :D].contiguous(), allrec[:, D:2 * D].contiguous(), y_all
+
+
+class AVIDSimilarityMemoryBank(nn.Module):
+    def __init__(self, memory_size, embedding_dim, xModal=True, wModal=False, num_negatives=1024, momentum=0.5,
+                 device=0):
+        super(AVIDSimilarityMemoryBank, self).__init__()
+        self.num_negatives = num_negatives
+        self.temperature = 0.07
+        if not isinstance(momentum, (list, tuple)):
+            momentum = [momentum] * 2
+        self.momentum = momentum
+        self.device = device
+
+        self.multinomial = AliasMethod(torch.ones(memory_size - 1))
+        self.xModal = xModal
+        self.wModal = wModal
+
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if self.distributed else 0
+
+        self.init_memory(memory_size, embedding_dim)
+
+    # ------------------------------------------------------------------ forward (avid.py:47-80)
+    def forward(self, video_emb, audio_emb, y):
+        K = int(self.num_negatives)
+        inv_T = 1.0 / self.temperature
+        video_emb = ops.l2_normalize(video_emb)
+        audio_emb = ops.l2_normalize(audio_emb)
+
+        with torch.no_grad():
+            idx = self.sample_negatives(y, K)
+            rows = torch.cat([y.view(-1, 1), idx], 1)        # column 0 = the positive (self) row
+
+        scores = {}
+        if self.xModal:
+            s = ops.bank_scores(video_emb, self.view2_mem, rows, inv_T)
+            scores['v2a'] = [s[:, :1], s[:, 1:]]
+            s = ops.bank_scores(audio_emb, self.view1_mem, rows, inv_T)
+            scores['a2v'] = [s[:, :1], s[:, 1:]]
+        if self.wModal:
+            s = ops.bank_scores(video_emb, self.view1_mem, rows, inv_T)
+            scores['v2v'] = [s[:, :1], s[:, 1:]]
+            s = ops.bank_scores(audio_emb, self.view2_mem, rows, inv_T)
+            scores['a2a'] = [s[:, :1], s[:, 1:]]
+
+        # Update memory bank (scores above used the pre-update rows; their snapshot is kept for backward)
+        self.update_memory(video_emb.detach(), audio_emb.detach(), y)
+        return scores
+
+    def sample_negatives(self, y, K):
+        """avid.py:82-86 — uniform over [0,N) \\ {y}; draw + "avoid self" in one kernel."""
+        bs = y.shape[0]
+        if self.multinomial.prob.device != y.device:
+            self.multinomial.to(y.device)
+        return self.multinomial.draw(bs * K, y=y.contiguous(), per_row=K).view(bs, K)
+
+    def init_memory(self, num_items, embedding_dim):
+        dev = _device_of(self.device)
+        self.register_buffer('view1_mem', torch.nn.functional.normalize(torch.randn(num_items, embedding_dim), p=2, dim=1))
+        self.register_buffer('view2_mem', torch.nn.functional.normalize(torch.randn(num_items, embedding_dim), p=2, dim=1))
+        self.view1_mem = self.view1_mem.to(dev)
+        self.view2_mem = self.view2_mem.to(dev)
+        self.multinomial.to(dev)
+        if self.distributed:
+            dist.broadcast(self.view1_mem, 0)
+            dist.broadcast(self.view2_mem, 0)
+            dist.barrier()
+
+    def update_memory(self, video_emb, audio_emb, y):
+        """avid.py:103-129: EMA + renormalise the rows of every sample of the GLOBAL batch, both banks.
+        Duplicate ids: last occurrence (highest global position) wins — the reference is unordered."""
+        video_mom = float(self.momentum[0])
+        audio_mom = float(self.momentum[1])
+        v_all, a_all, y_all = gather_update_records(video_emb, audio_emb, y)
+        with torch.no_grad():
+            ops.bank_update(self.view1_mem, y_all, v_all, video_mom)
+            ops.bank_update(self.view2_mem, y_all, a_all, audio_mom)
+
+    def __repr__(self):
+        repr_dict = {
+            'name': self._get_name(),
+            'num_negatives': int(self.num_negatives),
+            'momentum': [float(self.momentum[0]), float(self.momentum[1])],
+            'view1_buffer_size': self.view1_mem.shape,
+            'view2_buffer_size': self.view2_mem.shape,
+        }
+        return pprint.pformat(repr_dict, indent=2)
+
+
+class AVID(nn.Module):
+    """AVID criterion — same constructor, ``forward(emb1, emb2, target) -> (loss, tb_log)``,
+    ``set_epoch`` and state_dict keys as the reference (avid.py:145-236)."""
+
+    def __init__(self, num_data, embedding_dim, num_negatives=4096, momentum=0.9, xModal_coeff=1., wModal_coeff=0.,
+                 checkpoint=None, device=0):
+        super(AVID, self).__init__()
+        self.nce_average = AVIDSimilarityMemoryBank(
+            memory_size=num_data,
+            embedding_dim=embedding_dim,
+            num_negatives=num_negatives,
+            momentum=momentum,
+            xModal=xModal_coeff > 0.,
+            wModal=wModal_coeff > 0.,
+            device=device
+        )
+        sum_coeff = (xModal_coeff + wModal_coeff)
+        self.xModal_coeff = xModal_coeff / sum_coeff
+        self.wModal_coeff = wModal_coeff / sum_coeff
+        self.criterion = NCECriterion(num_data).to(_device_of(device))
+
+        # Restore memory bank and partition function if necessary (avid.py:187-200)
+        if checkpoint is not None:
+            ckp = torch.load(checkpoint, map_location='cpu')['train_criterion']
+            state_dict = self.state_dict()
+            state_dict['nce_average.view1_mem'] = ckp['nce_average.view1_mem']
+            state_dict['nce_average.view2_mem'] = ckp['nce_average.view2_mem']
+            Z = torch.stack([ckp[k].reshape(()) for k in ckp if 'avg_exp_score' in k]).mean()
+            for k in state_dict:
+                if 'avg_exp_score' in k:
+                    state_dict[k] = Z
+            self.load_state_dict(state_dict)
+
+    def forward(self, emb1, emb2, target):
+        tb_log = {}
+        scores = self.nce_average(emb1, emb2, target)
+
+        xModal_loss, wModal_loss = 0., 0
+        for k in scores:                       # one shared NCECriterion: Z comes from 'v2a' on the first batch
+            loss = self.criterion(*scores[k])
+            if k in {'v2a', 'a2v'}:
+                xModal_loss += loss / 2.
+            elif k in {'v2v', 'a2a'}:
+                wModal_loss += loss / 2.
+            tb_log[f'Loss/{k}'] = loss
+
+        tb_log['Loss/xModal'] = xModal_loss
+        tb_log['Loss/wModal'] = wModal_loss
+        total_loss = xModal_loss * self.xModal_coeff + wModal_loss * self.wModal_coeff
+        return total_loss, tb_log
+
+    def set_epoch(self, epoch):
+        pass

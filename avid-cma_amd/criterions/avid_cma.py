@@ -1,0 +1,206 @@
+"""AVID+CMA criterion on gfx950 kernels (reference: criterions/avid_cma.py:24-364)."""
+import pprint
+
+import torch
+from torch import nn
+import torch.distributed as dist
+
+from avid_hip import ops
+from utils.alias_method import AliasMethod
+from criterions.nce import NCECriterion
+from criterions.avid import AVIDSimilarityMemoryBank, _device_of
+
+__all__ = ['AVID_CMA']
+
+_KINDS = {'consensus': 0, 'union': 1, 'video': 2, 'audio': 3}
+
+
+class CMASampler:
+    """Cross-modal-agreement search (avid_cma.py:24-123).
+
+    The reference fans 16-query jobs out to one child process per GPU through mp.Queues while the
+    other ranks wait in a barrier.  Here every rank searches its own contiguous shard of query rows
+    in-process (each rank already holds both banks) and the shards are all-gathered.
+    """
+
+    def __init__(self, video_mem, audio_mem, sampling_args):
+        self.video_mem = video_mem
+        self.audio_mem = audio_mem
+        self.sampling_args = sampling_args
+        if sampling_args['type'] not in _KINDS:
+            raise ValueError
+
+    def sample_range(self, q0, q1, batch=1024):
+        from avid_hip import topk
+        return topk.cma_topk(self.video_mem, self.audio_mem, q0, q1, self.sampling_args['pos_k'],
+                             _KINDS[self.sampling_args['type']], batch)
+
+    def sample(self):
+        N = self.video_mem.shape[0]
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        per = (N + world - 1) // world
+        q0, q1 = min(rank * per, N), min((rank + 1) * per, N)
+        local = self.sample_range(q0, q1)
+        if world == 1:
+            return local
+        padded = torch.zeros((per, local.shape[1]), dtype=local.dtype, device=local.device)
+        padded[:q1 - q0] = local
+        out = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(out, padded)
+        return torch.cat(out, 0)[:N]
+
+
+class AVIDSimilarityPositiveExpansion(AVIDSimilarityMemoryBank):
+    def __init__(self, memory_size, embedding_dim, xModalInst=True, wModalInst=False, xModalPos=False,
+                 wModalPos=True, num_negatives=1024, num_negatives_within=None, sampling_args=None, momentum=0.5,
+                 device=0):
+        super().__init__(memory_size=memory_size, embedding_dim=embedding_dim, xModal=xModalInst, wModal=wModalInst,
+                         num_negatives=num_negatives, momentum=momentum, device=device)
+        self.num_negatives_within = num_negatives_within
+        self.multinomial = AliasMethod(torch.ones(memory_size - sampling_args['pos_k']))
+        self.multinomial.to(_device_of(device))
+        self.sampling_args = sampling_args
+
+        self.xModalInst = xModalInst
+        self.wModalInst = wModalInst
+        self.xModalPos = xModalPos
+        self.wModalPos = wModalPos
+
+    def forward(self, video_emb, audio_emb, y):
+        """avid_cma.py:150-194."""
+        inv_T = 1.0 / self.temperature
+        bs = y.shape[0]
+        video_emb = ops.l2_normalize(video_emb)
+        audio_emb = ops.l2_normalize(audio_emb)
+
+        with torch.no_grad():
+            pos_idx, neg_idx = self.memory_sampling(y)
+            P = pos_idx.shape[1]
+            rows = torch.cat([y.view(-1, 1), pos_idx, neg_idx], 1)      # [self | P positives | K negatives]
+
+        s_v2a = s_a2v = None
+        if self.xModalInst or self.wModalInst or self.xModalPos:
+            s_v2a = ops.bank_scores(video_emb, self.view2_mem, rows, inv_T)   # video emb vs audio bank
+            s_a2v = ops.bank_scores(audio_emb, self.view1_mem, rows, inv_T)   # audio emb vs video bank
+
+        scores = {}
+        neg = slice(1 + P, None)
+        if self.xModalInst:
+            scores['inst-v2a'] = [s_v2a[:, :1], s_v2a[:, neg]]
+            scores['inst-a2v'] = [s_a2v[:, :1], s_a2v[:, neg]]
+        if self.wModalInst:   # reference quirk kept: overwrites the same keys with the same cross-modal scores (:175-177)
+            scores['inst-v2a'] = [s_v2a[:, :1], s_v2a[:, neg]]
+            scores['inst-a2v'] = [s_a2v[:, :1], s_a2v[:, neg]]
+        if self.xModalPos:
+            scores['pos-v2a'] = [s_v2a[:, 1:1 + P], s_v2a[:, neg]]
+            scores['pos-a2v'] = [s_a2v[:, 1:1 + P], s_a2v[:, neg]]
+        if self.wModalPos:
+            Kw = neg_idx.shape[1] if self.num_negatives_within is None else int(self.num_negatives_within)
+            wrows = rows[:, 1:1 + P + Kw].contiguous()                  # [P positives | first Kw negatives]
+            s_v2v = ops.bank_scores(video_emb, self.view1_mem, wrows, inv_T)
+            s_a2a = ops.bank_scores(audio_emb, self.view2_mem, wrows, inv_T)
+            scores['pos-v2v'] = [s_v2v[:, :P], s_v2v[:, P:]]
+            scores['pos-a2a'] = [s_a2a[:, :P], s_a2a[:, P:]]
+
+        self.update_memory(video_emb.detach(), audio_emb.detach(), y)
+        return scores
+
+    def memory_sampling(self, y):
+        """avid_cma.py:196-209: positives = positive_set[y]; negatives skip the (sorted) positives."""
+        bs = y.shape[0]
+        if self.multinomial.prob.device != y.device:
+            self.multinomial.to(y.device)
+        rand_idx = self.multinomial.draw(bs * self.num_negatives).view(bs, -1)
+        return ops.cma_negatives(self.positive_set, y, rand_idx)
+
+    def find_correspondences(self):
+        """avid_cma.py:211-229 — every rank searches its shard; result all-gathered (no rank-0 bottleneck)."""
+        if self.sampling_args['pos_k'] <= 0:
+            return
+        positive_set = CMASampler(self.view1_mem, self.view2_mem, self.sampling_args).sample()
+        self.register_buffer('positive_set', positive_set.int().to(self.view1_mem.device))
+        if self.distributed:
+            dist.barrier()
+
+    def __repr__(self):
+        repr_dict = {
+            'name': self._get_name(),
+            'num_negatives': int(self.num_negatives),
+            'momentum': [float(self.momentum[0]), float(self.momentum[1])],
+            'view1_buffer_size': self.view1_mem.shape,
+            'view2_buffer_size': self.view2_mem.shape,
+        }
+        return pprint.pformat(repr_dict, indent=2)
+
+
+class AVID_CMA(nn.Module):
+    """Same constructor / forward / set_epoch / state_dict keys as the reference (avid_cma.py:245-364)."""
+
+    def __init__(self, num_data, embedding_dim, num_negatives=1024, num_negatives_within=None, momentum=0.5,
+                 xModalInstCoeff=1., wModalInstCoeff=0., xModalPosCoeff=0., wModalPosCoeff=1., sampling_args=None,
+                 checkpoint=None, resample_freq=-1, device=0):
+        super(AVID_CMA, self).__init__()
+        self.nce_average = AVIDSimilarityPositiveExpansion(
+            memory_size=num_data,
+            embedding_dim=embedding_dim,
+            num_negatives=num_negatives,
+            num_negatives_within=num_negatives_within,
+            momentum=momentum,
+            xModalInst=xModalInstCoeff > 0.,
+            xModalPos=xModalPosCoeff > 0.,
+            wModalInst=wModalInstCoeff > 0.,
+            wModalPos=wModalPosCoeff > 0.,
+            sampling_args=sampling_args,
+            device=device
+        )
+        sum_coeff = xModalInstCoeff + wModalInstCoeff + xModalPosCoeff + wModalPosCoeff
+        self.xModalInstCoeff = xModalInstCoeff / sum_coeff
+        self.wModalInstCoeff = wModalInstCoeff / sum_coeff
+        self.xModalPosCoeff = xModalPosCoeff / sum_coeff
+        self.wModalPosCoeff = wModalPosCoeff / sum_coeff
+
+        self.criterion = NCECriterion(num_data).to(_device_of(device))
+
+        # Restore memory bank and partition function from an AVID checkpoint (avid_cma.py:308-319)
+        if checkpoint is not None:
+            ckp = torch.load(checkpoint, map_location='cpu')['train_criterion']
+            state_dict = self.state_dict()
+            state_dict['nce_average.view1_mem'] = ckp['nce_average.view1_mem']
+            state_dict['nce_average.view2_mem'] = ckp['nce_average.view2_mem']
+            Z = torch.stack([ckp[k].reshape(()) for k in ckp if 'avg_exp_score' in k]).mean()
+            for k in state_dict:
+                if 'avg_exp_score' in k:
+                    state_dict[k] = Z
+            self.load_state_dict(state_dict)
+
+        self.resample_freq = resample_freq
+        self.nce_average.find_correspondences()
+
+    def forward(self, emb1, emb2, target):
+        tb_log = {}
+        scores = self.nce_average(emb1, emb2, target)
+
+        xModalInst_loss, wModalInst_loss, xModalPos_loss, wModalPos_loss = 0., 0., 0., 0.
+        for k in scores:
+            loss = self.criterion(*scores[k])
+            if k in {'inst-v2a', 'inst-a2v'}:
+                xModalInst_loss += loss / 2.
+            elif k in {'inst-v2v', 'inst-a2a'}:
+                wModalInst_loss += loss / 2.
+            elif k in {'pos-v2a', 'pos-a2v'}:
+                xModalPos_loss += loss / 2.
+            elif k in {'pos-v2v', 'pos-a2a'}:
+                wModalPos_loss += loss / 2.
+            with torch.no_grad():
+                tb_log[f'Loss/{k}'] = loss
+
+        total_loss = xModalInst_loss * self.xModalInstCoeff
+        total_loss += wModalInst_loss * self.wModalInstCoeff
+        total_loss += xModalPos_loss * self.xModalPosCoeff
+        total_loss += wModalPos_loss * self.wModalPosCoeff
+        return total_loss, tb_log
+
+    def set_epoch(self, epoch):
+        if self.resample_freq > 0 and epoch > 0 and epoch % self.resample_freq == 0:
+            self.nce_average.find_correspondences()

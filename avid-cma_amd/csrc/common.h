@@ -1,0 +1,60 @@
+// Shared host/device helpers for libavid_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/avid_hip.h"
+
+namespace avid {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return AVID_E_HIP;
+  }
+  return AVID_OK;
+}
+
+#define AVID_REQUIRE(cond, code, ...) \
+  do {                                \
+    if (!(cond)) {                    \
+      avid::set_error(__VA_ARGS__);   \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// 64-lane wave reductions (DPP/ds_swizzle chosen by the compiler from __shfl_xor).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: XCD k (= hardware id % 8) receives one
+// contiguous chunk of the logical tile space so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned nx = 8;
+  if (nwg < nx) return bid;
+  unsigned q = nwg / nx, r = nwg % nx;
+  unsigned xcd = bid % nx, pos = bid / nx;
+  unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + pos;
+}
+
+}  // namespace avid

@@ -1,0 +1,409 @@
+// Memory-bank NCE criterion kernels: wavefront-per-row gathers + DPP reductions, sized for banks of
+// N x 128 fp32 rows (512 B = one fully coalesced wave64 float2 read) resident in HBM.
+//
+// Reference ops replaced: criterions/avid.py:47-129 (normalize, gather, bmm scores, EMA update),
+// criterions/nce.py:21-58, utils/alias_method.py:56-71, criterions/avid_cma.py:196-209.
+#include <math.h>
+
+#include "common.h"
+
+namespace avid {
+
+// ---------------------------------------------------------------------------------------------
+// F.normalize(x, p=2, dim=1): one wave per row
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ norm_out, int bs, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= bs) return;
+  const float* p = x + (long long)row * D;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) ss += p[d] * p[d];
+  ss = wave_sum(ss);
+  const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+  for (int d = lane; d < D; d += 64) y[(long long)row * D + d] = p[d] / nrm;
+  if (lane == 0) norm_out[row] = nrm;
+}
+
+// dx = (dy - y * <y, dy>) / norm
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ norm,
+                                                         const float* __restrict__ dy, float* __restrict__ dx, int bs,
+                                                         int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= bs) return;
+  const long long o = (long long)row * D;
+  float dot = 0.f;
+  for (int d = lane; d < D; d += 64) dot += y[o + d] * dy[o + d];
+  dot = wave_sum(dot);
+  const float inv = 1.f / norm[row];
+  for (int d = lane; d < D; d += 64) dx[o + d] = (dy[o + d] - y[o + d] * dot) * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al.): counter = (i_lo, i_hi, off_lo, off_hi), key = (seed_lo, seed_hi)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t& r0, uint32_t& r1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  r0 = c0;
+  r1 = c1;
+}
+
+__global__ void alias_draw_kernel(long long n, long long K, const float* __restrict__ prob,
+                                  const long long* __restrict__ alias, int uniform, uint64_t seed, uint64_t offset,
+                                  const long long* __restrict__ y, long long per_row, long long* __restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint32_t r0, r1;
+    philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)offset, (uint32_t)(offset >> 32),
+                  (uint32_t)seed, (uint32_t)(seed >> 32), r0, r1);
+    const long long kk = (long long)(((uint64_t)r0 * (uint64_t)K) >> 32);
+    long long v = kk;
+    if (!uniform) {
+      const float u = (float)(r1 >> 8) * 5.9604644775390625e-8f;  // 2^-24
+      v = (u < prob[kk]) ? kk : alias[kk];
+    }
+    if (y) v += (v >= y[i / per_row]) ? 1 : 0;
+    out[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scores[b][j] = <bank[idx[b][j]], emb[b]> * inv_T.  grid = (row chunks, bs); 4 waves/block, each
+// wave keeps 4 independent 512-B row reads in flight.
+// ---------------------------------------------------------------------------------------------
+constexpr int SC_ROWS_PER_BLOCK = 64;
+
+template <int DPL>  // floats per lane: D = 64 * DPL
+__global__ __launch_bounds__(256) void bank_scores_fwd_kernel(const long long* __restrict__ idx,
+                                                              const float* __restrict__ bank,
+                                                              const float* __restrict__ emb, float inv_T,
+                                                              float* __restrict__ scores,
+                                                              float* __restrict__ rows_out, int R, long long N) {
+  constexpr int D = 64 * DPL;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  float e[DPL];
+#pragma unroll
+  for (int k = 0; k < DPL; ++k) e[k] = emb[(long long)b * D + k * 64 + lane];
+  const int j0 = blockIdx.x * SC_ROWS_PER_BLOCK;
+  const int j1 = min(j0 + SC_ROWS_PER_BLOCK, R);
+  const long long* ib = idx + (long long)b * R;
+  for (int j = j0 + wave * 4; j < j1; j += 16) {
+    float acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[u] = 0.f;
+      if (j + u < j1) {
+        long long row = ib[j + u];
+        row = row < 0 ? 0 : (row >= N ? N - 1 : row);  // never read outside the bank
+        const float* p = bank + row * D;
+        float* ro = rows_out ? rows_out + ((long long)b * R + j + u) * D : nullptr;
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) {
+          const float v = p[k * 64 + lane];
+          acc[u] += v * e[k];
+          if (ro) ro[k * 64 + lane] = v;  // snapshot of the pre-update row for backward
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float s = wave_sum(acc[u]);
+      if (lane == 0 && j + u < j1) scores[(long long)b * R + j + u] = s * inv_T;
+    }
+  }
+}
+
+// demb[b] (+)= inv_T * sum_j ds[b][j] * bank[idx[b][j]] : one 1024-thread block per sample
+template <int DPL>
+__global__ __launch_bounds__(1024) void bank_scores_bwd_kernel(const float* __restrict__ rows,
+                                                               const long long* __restrict__ idx,
+                                                               const float* __restrict__ bank,
+                                                               const float* __restrict__ ds, float inv_T,
+                                                               int accumulate, float* __restrict__ demb, int R,
+                                                               long long N) {
+  constexpr int D = 64 * DPL;
+  __shared__ float sh[16][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  const long long* ib = idx + (long long)b * R;
+  const float* db = ds + (long long)b * R;
+  float acc[DPL];
+#pragma unroll
+  for (int k = 0; k < DPL; ++k) acc[k] = 0.f;
+  for (int j = wave * 4; j < R; j += 64) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (j + u < R) {
+        const float* p;
+        if (rows) {
+          p = rows + ((long long)b * R + j + u) * D;
+        } else {
+          long long row = ib[j + u];
+          row = row < 0 ? 0 : (row >= N ? N - 1 : row);
+          p = bank + row * D;
+        }
+        const float g = db[j + u];
+#pragma unroll
+        for (int k = 0; k < DPL; ++k) acc[k] += g * p[k * 64 + lane];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DPL; ++k) sh[wave][k * 64 + lane] = acc[k];
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 1024) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += sh[w][d];
+    s *= inv_T;
+    float* o = demb + (long long)b * D + d;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCE (criterions/nce.py)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+  return t;  // valid on thread 0
+}
+
+__global__ __launch_bounds__(1024) void mean_exp_kernel(const float* __restrict__ s, int rows, int cols, int ld,
+                                                        float* __restrict__ out) {
+  __shared__ double sh[16];
+  double acc = 0;
+  const long long n = (long long)rows * cols;
+  for (long long i = threadIdx.x; i < n; i += 1024) acc += (double)expf(s[(i / cols) * ld + (i % cols)]);
+  const double t = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) out[0] = (float)(t / (double)n);
+}
+
+__global__ __launch_bounds__(1024) void nce_fwd_kernel(const float* __restrict__ spos, const float* __restrict__ sneg,
+                                                       const float* __restrict__ Zp, int bs, int P, int K, int ldp,
+                                                       int ldn, float scale, int accumulate,
+                                                       float* __restrict__ loss) {
+  __shared__ double sh[16];
+  const float KZ = (float)K * Zp[0];
+  double acc = 0;
+  const long long nn = (long long)bs * K, np = (long long)bs * P;
+  for (long long i = threadIdx.x; i < nn; i += 1024) {
+    const float e = expf(sneg[(i / K) * ldn + (i % K)]);
+    acc += (double)(-logf(KZ / (e + KZ)));
+  }
+  const double invP = 1.0 / (double)P;
+  for (long long i = threadIdx.x; i < np; i += 1024) {
+    const float e = expf(spos[(i / P) * ldp + (i % P)]);
+    acc += (double)(-logf(e / (e + KZ))) * invP;
+  }
+  const double t = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) {
+    const float v = (float)(t / (double)bs) * scale;
+    loss[0] = accumulate ? loss[0] + v : v;
+  }
+}
+
+__global__ void nce_bwd_kernel(const float* __restrict__ spos, const float* __restrict__ sneg,
+                               const float* __restrict__ Zp, const float* __restrict__ dloss, int bs, int P, int K,
+                               int ldp, int ldn, float scale, float* __restrict__ dpos, float* __restrict__ dneg) {
+  const float KZ = (float)K * Zp[0];
+  const float g = dloss[0] * scale / (float)bs;
+  const long long nn = (long long)bs * K, np = (long long)bs * P;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nn + np; i += stride) {
+    if (i < nn) {
+      const float e = expf(sneg[(i / K) * ldn + (i % K)]);
+      dneg[i] = g * (e / (e + KZ));
+    } else {
+      const long long k = i - nn;
+      const float e = expf(spos[(k / P) * ldp + (k % P)]);
+      dpos[k] = -(g / (float)P) * (KZ / (e + KZ));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bank[y[i]] = normalize(m * bank[y[i]] + (1-m) * emb[i]); last duplicate wins. One wave per sample.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bank_update_kernel(float* __restrict__ bank, const long long* __restrict__ y,
+                                                          const float* __restrict__ emb, float mom, int B, int D,
+                                                          long long N) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B) return;
+  const long long row = y[i];
+  if (row < 0 || row >= N) return;
+  int dup = 0;
+  for (int k = i + 1 + lane; k < B; k += 64) dup |= (y[k] == row);
+  if (__any(dup)) return;  // a later sample owns this row
+  float* p = bank + row * D;
+  float ss = 0.f;
+  float v[8];
+  int cnt = 0;
+  for (int d = lane; d < D && cnt < 8; d += 64, ++cnt) {
+    const float t = __fadd_rn(__fmul_rn(p[d], mom), __fmul_rn(emb[(long long)i * D + d], 1.f - mom));
+    v[cnt] = t;
+    ss += t * t;
+  }
+  ss = wave_sum(ss);
+  const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+  cnt = 0;
+  for (int d = lane; d < D && cnt < 8; d += 64, ++cnt) p[d] = v[cnt] / nrm;
+}
+
+// criterions/avid_cma.py:196-209
+__global__ void cma_negatives_kernel(const int32_t* __restrict__ pset, const long long* __restrict__ y,
+                                     const long long* __restrict__ rnd, long long* __restrict__ pos_out,
+                                     long long* __restrict__ neg_out, int bs, int K, int P) {
+  const long long n = (long long)bs * K;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int b = (int)(i / K), k = (int)(i % K);
+    const int32_t* ps = pset + y[b] * (long long)P;
+    const long long r = rnd[i];
+    int cnt = 0;
+    for (int j = 0; j < P; ++j) cnt += (r >= (long long)ps[j] - j) ? 1 : 0;
+    neg_out[i] = r + cnt;
+    if (k < P) pos_out[(long long)b * P + k] = ps[k];
+  }
+  // K < P is legal: finish the positive copy
+  if (K < P)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)bs * P; i += stride) {
+      const int b = (int)(i / P), k = (int)(i % P);
+      if (k >= K) pos_out[i] = pset[y[b] * (long long)P + k];
+    }
+}
+
+}  // namespace avid
+
+using namespace avid;
+
+extern "C" int avid_l2norm_fwd(int bs, int D, const float* x, float* y, float* norm_out, avid_stream_t stream) {
+  AVID_REQUIRE(bs > 0 && D > 0 && x && y && norm_out, AVID_E_BADARG, "l2norm_fwd: bad argument");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)ceil_div(bs, 4)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     norm_out, bs, D);
+  return check_launch("l2norm_fwd");
+}
+
+extern "C" int avid_l2norm_bwd(int bs, int D, const float* y, const float* norm, const float* dy, float* dx,
+                               avid_stream_t stream) {
+  AVID_REQUIRE(bs > 0 && D > 0 && y && norm && dy && dx, AVID_E_BADARG, "l2norm_bwd: bad argument");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)ceil_div(bs, 4)), dim3(256), 0, (hipStream_t)stream, y, norm,
+                     dy, dx, bs, D);
+  return check_launch("l2norm_bwd");
+}
+
+extern "C" int avid_alias_draw(int64_t n, int64_t K, const float* prob, const int64_t* alias, int uniform,
+                               uint64_t seed, uint64_t offset, const int64_t* y, int64_t per_row, int64_t* out,
+                               avid_stream_t stream) {
+  AVID_REQUIRE(n > 0 && K > 0 && K < (1ll << 32) && out, AVID_E_BADARG, "alias_draw: bad argument");
+  AVID_REQUIRE(uniform || (prob && alias), AVID_E_BADARG, "alias_draw: tables missing");
+  AVID_REQUIRE(!y || per_row > 0, AVID_E_BADARG, "alias_draw: per_row must be > 0 with y");
+  long long g = ceil_div(n, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(alias_draw_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (long long)n,
+                     (long long)K, prob, (const long long*)alias, uniform, seed, offset, (const long long*)y,
+                     (long long)(per_row > 0 ? per_row : 1), (long long*)out);
+  return check_launch("alias_draw");
+}
+
+extern "C" int avid_bank_scores_fwd(int bs, int R, int D, int64_t N, const int64_t* idx, const float* bank,
+                                    const float* emb, float inv_T, float* scores, float* rows_out,
+                                    avid_stream_t stream) {
+  AVID_REQUIRE(bs > 0 && R > 0 && N > 0 && idx && bank && emb && scores, AVID_E_BADARG, "bank_scores_fwd: bad argument");
+  AVID_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, AVID_E_UNSUPPORTED, "bank_scores_fwd: D=%d unsupported", D);
+  dim3 grid((unsigned)ceil_div(R, SC_ROWS_PER_BLOCK), (unsigned)bs);
+  hipStream_t s = (hipStream_t)stream;
+  const long long* ix = (const long long*)idx;
+  switch (D / 64) {
+    case 1: hipLaunchKernelGGL(bank_scores_fwd_kernel<1>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N); break;
+    case 2: hipLaunchKernelGGL(bank_scores_fwd_kernel<2>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N); break;
+    case 4: hipLaunchKernelGGL(bank_scores_fwd_kernel<4>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N); break;
+    default: hipLaunchKernelGGL(bank_scores_fwd_kernel<8>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N); break;
+  }
+  return check_launch("bank_scores_fwd");
+}
+
+extern "C" int avid_bank_scores_bwd(int bs, int R, int D, int64_t N, const float* rows, const int64_t* idx,
+                                    const float* bank, const float* dscores, float inv_T, int accumulate,
+                                    float* demb, avid_stream_t stream) {
+  AVID_REQUIRE(bs > 0 && R > 0 && dscores && demb && (rows || (N > 0 && idx && bank)), AVID_E_BADARG,
+               "bank_scores_bwd: bad argument");
+  AVID_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, AVID_E_UNSUPPORTED, "bank_scores_bwd: D=%d unsupported", D);
+  hipStream_t s = (hipStream_t)stream;
+  const long long* ix = (const long long*)idx;
+  switch (D / 64) {
+    case 1: hipLaunchKernelGGL(bank_scores_bwd_kernel<1>, dim3(bs), dim3(1024), 0, s, rows, ix, bank, dscores, inv_T, accumulate, demb, R, (long long)N); break;
+    case 2: hipLaunchKernelGGL(bank_scores_bwd_kernel<2>, dim3(bs), dim3(1024), 0, s, rows, ix, bank, dscores, inv_T, accumulate, demb, R, (long long)N); break;
+    case 4: hipLaunchKernelGGL(bank_scores_bwd_kernel<4>, dim3(bs), dim3(1024), 0, s, rows, ix, bank, dscores, inv_T, accumulate, demb, R, (long long)N); break;
+    default: hipLaunchKernelGGL(bank_scores_bwd_kernel<8>, dim3(bs), dim3(1024), 0, s, rows, ix, bank, dscores, inv_T, accumulate, demb, R, (long long)N); break;
+  }
+  return check_launch("bank_scores_bwd");
+}
+
+extern "C" int avid_mean_exp(int rows, int cols, int ld, const float* s, float* out, avid_stream_t stream) {
+  AVID_REQUIRE(rows > 0 && cols > 0 && ld >= cols && s && out, AVID_E_BADARG, "mean_exp: bad argument");
+  hipLaunchKernelGGL(mean_exp_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, s, rows, cols, ld, out);
+  return check_launch("mean_exp");
+}
+
+extern "C" int avid_nce_fwd(int bs, int P, int K, const float* spos, int ld_pos, const float* sneg, int ld_neg,
+                            const float* Z, float scale, int accumulate, float* loss, avid_stream_t stream) {
+  AVID_REQUIRE(bs > 0 && P > 0 && K > 0 && spos && sneg && Z && loss && ld_pos >= P && ld_neg >= K, AVID_E_BADARG,
+               "nce_fwd: bad argument");
+  hipLaunchKernelGGL(nce_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, spos, sneg, Z, bs, P, K, ld_pos,
+                     ld_neg, scale, accumulate, loss);
+  return check_launch("nce_fwd");
+}
+
+extern "C" int avid_nce_bwd(int bs, int P, int K, const float* spos, int ld_pos, const float* sneg, int ld_neg,
+                            const float* Z, const float* dloss, float scale, float* dpos, float* dneg,
+                            avid_stream_t stream) {
+  AVID_REQUIRE(bs > 0 && P > 0 && K > 0 && spos && sneg && Z && dloss && dpos && dneg && ld_pos >= P && ld_neg >= K,
+               AVID_E_BADARG, "nce_bwd: bad argument");
+  const long long n = (long long)bs * (K + P);
+  long long g = ceil_div(n, 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(nce_bwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, spos, sneg, Z, dloss, bs, P,
+                     K, ld_pos, ld_neg, scale, dpos, dneg);
+  return check_launch("nce_bwd");
+}
+
+extern "C" int avid_bank_update(int B, int D, int64_t N, float* bank, const int64_t* y, const float* emb,
+                                float momentum, avid_stream_t stream) {
+  AVID_REQUIRE(B > 0 && D > 0 && D <= 512 && N > 0 && bank && y && emb, AVID_E_BADARG, "bank_update: bad argument");
+  hipLaunchKernelGGL(bank_update_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, bank,
+                     (const long long*)y, emb, momentum, B, D, (long long)N);
+  return check_launch("bank_update");
+}
+
+extern "C" int avid_cma_negatives(int bs, int K, int P, const int32_t* positive_set, const int64_t* y,
+                                  const int64_t* rand_idx, int64_t* pos_out, int64_t* neg_out, avid_stream_t stream) {
+  AVID_REQUIRE(bs > 0 && K > 0 && P > 0 && positive_set && y && rand_idx && pos_out && neg_out, AVID_E_BADARG,
+               "cma_negatives: bad argument");
+  const long long n = (long long)bs * (K > P ? K : P);
+  long long g = ceil_div(n, 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(cma_negatives_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, positive_set,
+                     (const long long*)y, (const long long*)rand_idx, (long long*)pos_out, (long long*)neg_out, bs, K,
+                     P);
+  return check_launch("cma_negatives");
+}

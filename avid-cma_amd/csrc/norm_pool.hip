@@ -1,0 +1,511 @@
+// HBM-bound epilogue kernels over channels-last [M, C] activations: train/eval BatchNorm (+ReLU)
+// forward/backward, the stem max-pool, global (adaptive) max-pool, ReLU backward, column sums.
+// All accesses are 16-B vectors with consecutive lanes on consecutive channels (fully coalesced).
+//
+// Reference ops replaced: nn.BatchNorm3d/2d + nn.ReLU (models/network_blocks.py:19-27,36-59,
+// models/video.py:21-22, models/audio.py:23-24), nn.MaxPool3d (models/video.py:23),
+// nn.AdaptiveMaxPool3d/2d (models/video.py:41, models/audio.py:31).
+#include <math.h>
+
+#include "common.h"
+
+namespace avid {
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm statistics: grid of row-blocks, each thread owns one float4 channel group.
+// partial[blk][0][C] = sum x, partial[blk][1][C] = sum x^2   (fp32 partials, fp64 final combine)
+// ---------------------------------------------------------------------------------------------
+struct BnPlan {
+  int G;               // float4 groups per row = C/4
+  int rows_per_pass;   // 256 / G
+  int rows_per_block;
+  int nblk;
+};
+
+static BnPlan bn_plan(int64_t M, int C) {
+  BnPlan p;
+  p.G = C / 4;
+  p.rows_per_pass = 256 / p.G;
+  int64_t rpb = ceil_div(M, 1024);
+  if (rpb < 64) rpb = 64;
+  rpb = ceil_div(rpb, p.rows_per_pass) * p.rows_per_pass;
+  p.rows_per_block = (int)rpb;
+  p.nblk = (int)ceil_div(M, rpb);
+  return p;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                               long long M, int C, int G, int rows_per_pass,
+                                                               int rows_per_block) {
+  __shared__ floatx4 sh[2][256];
+  const int tid = threadIdx.x;
+  const int g = tid % G, r = tid / G;
+  floatx4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+  const long long row0 = (long long)blockIdx.x * rows_per_block;
+  if (r < rows_per_pass) {
+    for (int k = r; k < rows_per_block; k += rows_per_pass) {
+      const long long row = row0 + k;
+      if (row < M) {
+        const floatx4 v = *reinterpret_cast<const floatx4*>(x + row * C + g * 4);
+        s += v;
+        ss += v * v;
+      }
+    }
+  }
+  sh[0][tid] = s;
+  sh[1][tid] = ss;
+  __syncthreads();
+  if (r == 0) {
+    for (int k = 1; k < rows_per_pass; ++k) {
+      s += sh[0][k * G + g];
+      ss += sh[1][k * G + g];
+    }
+    float* o = part + (long long)blockIdx.x * 2 * C;
+    *reinterpret_cast<floatx4*>(o + g * 4) = s;
+    *reinterpret_cast<floatx4*>(o + C + g * 4) = ss;
+  }
+}
+
+// one thread per channel: combine partials in fp64, emit mean / invstd / scale / shift, update running stats
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, long long M, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                   float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, ss = 0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)part[(long long)b * 2 * C + c];
+    ss += (double)part[(long long)b * 2 * C + C + c];
+  }
+  const double mean = s / (double)M;
+  double var = ss / (double)M - mean * mean;
+  if (var < 0) var = 0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (running_mean) {
+    const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                     float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       long long n4, int G, int relu) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int g = (int)(i % G);
+    const floatx4 v = reinterpret_cast<const floatx4*>(x)[i];
+    const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g];
+    const floatx4 sh = reinterpret_cast<const floatx4*>(shift)[g];
+    floatx4 o = v * sc + sh;
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    reinterpret_cast<floatx4*>(y)[i] = o;
+  }
+}
+
+// eval path computes its coefficients in-kernel (no workspace): y = gamma*(x-rm)/sqrt(rv+eps)+beta
+__global__ __launch_bounds__(256) void bn_apply_eval_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ rm, const float* __restrict__ rv,
+                                                            float eps, long long n4, int G, int relu) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int g = (int)(i % G);
+    const floatx4 v = reinterpret_cast<const floatx4*>(x)[i];
+    const floatx4 ga = reinterpret_cast<const floatx4*>(gamma)[g];
+    const floatx4 be = reinterpret_cast<const floatx4*>(beta)[g];
+    const floatx4 m = reinterpret_cast<const floatx4*>(rm)[g];
+    const floatx4 vv = reinterpret_cast<const floatx4*>(rv)[g];
+    floatx4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float invstd = 1.f / sqrtf(vv[j] + eps);
+      o[j] = (v[j] - m[j]) * invstd * ga[j] + be[j];
+      if (relu) o[j] = fmaxf(o[j], 0.f);
+    }
+    reinterpret_cast<floatx4*>(y)[i] = o;
+  }
+}
+
+// backward partials: part[blk][0][C] = sum dy_m, part[blk][1][C] = sum dy_m * xhat
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float* __restrict__ part,
+                                                             long long M, int C, int G, int rows_per_pass,
+                                                             int rows_per_block, int relu) {
+  __shared__ floatx4 sh[2][256];
+  const int tid = threadIdx.x;
+  const int g = tid % G, r = tid / G;
+  floatx4 s = {0, 0, 0, 0}, sx = {0, 0, 0, 0};
+  const long long row0 = (long long)blockIdx.x * rows_per_block;
+  if (r < rows_per_pass) {
+    const floatx4 mu = reinterpret_cast<const floatx4*>(mean)[g];
+    const floatx4 is = reinterpret_cast<const floatx4*>(invstd)[g];
+    for (int k = r; k < rows_per_block; k += rows_per_pass) {
+      const long long row = row0 + k;
+      if (row < M) {
+        const long long o = row * C + g * 4;
+        floatx4 d = *reinterpret_cast<const floatx4*>(dy + o);
+        const floatx4 xv = *reinterpret_cast<const floatx4*>(x + o);
+        if (relu) {
+          const floatx4 yv = *reinterpret_cast<const floatx4*>(y + o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[j] = yv[j] > 0.f ? d[j] : 0.f;
+        }
+        s += d;
+        sx += d * ((xv - mu) * is);
+      }
+    }
+  }
+  sh[0][tid] = s;
+  sh[1][tid] = sx;
+  __syncthreads();
+  if (r == 0) {
+    for (int k = 1; k < rows_per_pass; ++k) {
+      s += sh[0][k * G + g];
+      sx += sh[1][k * G + g];
+    }
+    float* o = part + (long long)blockIdx.x * 2 * C;
+    *reinterpret_cast<floatx4*>(o + g * 4) = s;
+    *reinterpret_cast<floatx4*>(o + C + g * 4) = sx;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, long long M, int C,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ k1,
+                                       float* __restrict__ k2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, sx = 0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)part[(long long)b * 2 * C + c];
+    sx += (double)part[(long long)b * 2 * C + C + c];
+  }
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)sx;
+  k1[c] = (float)(s / (double)M);
+  k2[c] = (float)(sx / (double)M);
+}
+
+// dx = gamma*invstd * (dy_m - mean(dy_m) - xhat * mean(dy_m*xhat))
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ k1,
+                                                           const float* __restrict__ k2, float* __restrict__ dx,
+                                                           long long n4, int G, int relu) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int g = (int)(i % G);
+    floatx4 d = reinterpret_cast<const floatx4*>(dy)[i];
+    const floatx4 xv = reinterpret_cast<const floatx4*>(x)[i];
+    if (relu) {
+      const floatx4 yv = reinterpret_cast<const floatx4*>(y)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = yv[j] > 0.f ? d[j] : 0.f;
+    }
+    const floatx4 mu = reinterpret_cast<const floatx4*>(mean)[g];
+    const floatx4 is = reinterpret_cast<const floatx4*>(invstd)[g];
+    const floatx4 ga = reinterpret_cast<const floatx4*>(gamma)[g];
+    const floatx4 a = reinterpret_cast<const floatx4*>(k1)[g];
+    const floatx4 b = reinterpret_cast<const floatx4*>(k2)[g];
+    const floatx4 xh = (xv - mu) * is;
+    reinterpret_cast<floatx4*>(dx)[i] = ga * is * (d - a - xh * b);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool (1,3,3) stride (1,2,2) pad (0,1,1), channels-last.  argmax = window slot (dh*3+dw) of the
+// FIRST maximum in scan order (ATen CPU: `val > max || isnan(val)`).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ am, int BT, int H, int W, int Ho,
+                                                          int Wo, int G) {
+  const long long n = (long long)BT * Ho * Wo * G;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int g = (int)(i % G);
+    long long r = i / G;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const long long bt = r / Ho;
+    floatx4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int slot[4] = {0, 0, 0, 0};
+    bool first = true;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = ho * 2 - 1 + dh;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = wo * 2 - 1 + dw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const floatx4 v = *reinterpret_cast<const floatx4*>(x + (((bt * H + h) * W + w) * (long long)G + g) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (first || v[j] > best[j] || v[j] != v[j]) {
+            best[j] = v[j];
+            slot[j] = dh * 3 + dw;
+          }
+        }
+        first = false;
+      }
+    }
+    reinterpret_cast<floatx4*>(y)[i] = best;
+    reinterpret_cast<uchar4*>(am)[i] = make_uchar4((unsigned char)slot[0], (unsigned char)slot[1],
+                                                   (unsigned char)slot[2], (unsigned char)slot[3]);
+  }
+}
+
+// gather-style backward: every input pixel sums dy over the (<= 4) windows whose argmax is this pixel.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ am,
+                                                          float* __restrict__ dx, int BT, int H, int W, int Ho, int Wo,
+                                                          int G) {
+  const long long n = (long long)BT * H * W * G;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int g = (int)(i % G);
+    long long r = i / G;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const long long bt = r / H;
+    floatx4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int nh = h + 1 - dh;
+      if (nh < 0 || (nh & 1)) continue;
+      const int ho = nh >> 1;
+      if (ho >= Ho) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int nw = w + 1 - dw;
+        if (nw < 0 || (nw & 1)) continue;
+        const int wo = nw >> 1;
+        if (wo >= Wo) continue;
+        const long long o = ((bt * Ho + ho) * Wo + wo) * (long long)G + g;
+        const uchar4 a = reinterpret_cast<const uchar4*>(am)[o];
+        const floatx4 d = reinterpret_cast<const floatx4*>(dy)[o];
+        const int slot = dh * 3 + dw;
+        acc.x += a.x == slot ? d.x : 0.f;
+        acc.y += a.y == slot ? d.y : 0.f;
+        acc.z += a.z == slot ? d.z : 0.f;
+        acc.w += a.w == slot ? d.w : 0.f;
+      }
+    }
+    reinterpret_cast<floatx4*>(dx)[i] = acc;
+  }
+}
+
+// global max over S positions: x [B,S,C] -> y [B,C]; first maximum wins
+__global__ void global_maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ am,
+                                          int B, int S, int C) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * C) return;
+  const int c = (int)(i % C);
+  const long long b = i / C;
+  const float* p = x + b * S * C + c;
+  float best = p[0];
+  int arg = 0;
+  for (int s = 1; s < S; ++s) {
+    const float v = p[(long long)s * C];
+    if (v > best || v != v) {
+      best = v;
+      arg = s;
+    }
+  }
+  y[i] = best;
+  am[i] = arg;
+}
+
+__global__ void global_maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ am,
+                                          float* __restrict__ dx, int B, int S, int C) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * S * C) return;
+  const int c = (int)(i % C);
+  const long long r = i / C;
+  const int s = (int)(r % S);
+  const long long b = r / S;
+  dx[i] = am[b * C + c] == s ? dy[b * C + c] : 0.f;
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
+                                long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+// out[c] = sum_m x[m][c] — one wave column-slab per block: 64 lanes = 64 consecutive channels
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long long M,
+                                                     int C) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < C)
+    for (long long m = wave; m < M; m += 4) s += x[m * C + c];
+  sh[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < C) out[c] = sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane];
+}
+
+static unsigned ew_grid(long long n) {
+  long long g = ceil_div(n, 256);
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace avid
+
+using namespace avid;
+
+extern "C" size_t avid_bn_workspace_bytes(int64_t M, int C) {
+  if (M <= 0 || C <= 0 || C % 4 || 256 % (C / 4)) return 0;
+  BnPlan p = bn_plan(M, C);
+  return sizeof(float) * ((size_t)p.nblk * 2 * C + 4 * (size_t)C);
+}
+
+static int bn_check(int64_t M, int C, const char* who) {
+  AVID_REQUIRE(M > 0 && C > 0, AVID_E_SHAPE, "%s: empty tensor", who);
+  AVID_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, AVID_E_UNSUPPORTED,
+               "%s: C=%d must be a power of two in [4, 1024]", who, C);
+  return AVID_OK;
+}
+
+extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                 float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                                 avid_stream_t stream) {
+  int rc = bn_check(M, C, "bn_fwd_train");
+  if (rc) return rc;
+  AVID_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, AVID_E_BADARG, "bn_fwd_train: null pointer");
+  AVID_REQUIRE(ws_bytes >= avid_bn_workspace_bytes(M, C), AVID_E_BADARG, "bn_fwd_train: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  BnPlan p = bn_plan(M, C);
+  float* part = static_cast<float*>(ws);
+  float* scale = part + (size_t)p.nblk * 2 * C;
+  float* shift = scale + C;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
+                     p.rows_per_pass, p.rows_per_block);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64), 0, s, part, p.nblk, (long long)M,
+                     C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+  const long long n4 = (long long)M * p.G;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, x, y, scale, shift, n4, p.G, relu);
+  return check_launch("bn_fwd_train");
+}
+
+extern "C" int avid_bn_fwd_eval(int64_t M, int C, const float* x, const float* gamma, const float* beta,
+                                const float* running_mean, const float* running_var, float eps, int relu, float* y,
+                                avid_stream_t stream) {
+  int rc = bn_check(M, C, "bn_fwd_eval");
+  if (rc) return rc;
+  AVID_REQUIRE(x && gamma && beta && running_mean && running_var && y, AVID_E_BADARG, "bn_fwd_eval: null pointer");
+  const long long n4 = (long long)M * (C / 4);
+  hipLaunchKernelGGL(bn_apply_eval_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta,
+                     running_mean, running_var, eps, n4, C / 4, relu);
+  return check_launch("bn_fwd_eval");
+}
+
+extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* y, const float* dy, const float* gamma,
+                           const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
+                           float* dbeta, void* ws, size_t ws_bytes, avid_stream_t stream) {
+  int rc = bn_check(M, C, "bn_bwd");
+  if (rc) return rc;
+  AVID_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, AVID_E_BADARG,
+               "bn_bwd: null pointer");
+  AVID_REQUIRE(!relu || y, AVID_E_BADARG, "bn_bwd: relu needs the saved output y");
+  AVID_REQUIRE(ws_bytes >= avid_bn_workspace_bytes(M, C), AVID_E_BADARG, "bn_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  BnPlan p = bn_plan(M, C);
+  float* part = static_cast<float*>(ws);
+  float* k1 = part + (size_t)p.nblk * 2 * C;
+  float* k2 = k1 + C;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, y, dy, save_mean, save_invstd, part,
+                     (long long)M, C, p.G, p.rows_per_pass, p.rows_per_block, relu);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64), 0, s, part, p.nblk,
+                     (long long)M, C, dgamma, dbeta, k1, k2);
+  const long long n4 = (long long)M * p.G;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, x, y, dy, gamma, save_mean, save_invstd,
+                     k1, k2, dx, n4, p.G, relu);
+  return check_launch("bn_bwd");
+}
+
+extern "C" int avid_maxpool_hw3s2_fwd(int B, int T, int H, int W, int C, const float* x, float* y, uint8_t* argmax,
+                                      avid_stream_t stream) {
+  AVID_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, AVID_E_SHAPE, "maxpool_fwd: bad shape");
+  AVID_REQUIRE(x && y && argmax, AVID_E_BADARG, "maxpool_fwd: null pointer");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long n = (long long)B * T * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, B * T, H,
+                     W, Ho, Wo, C / 4);
+  return check_launch("maxpool_fwd");
+}
+
+extern "C" int avid_maxpool_hw3s2_bwd(int B, int T, int H, int W, int C, const float* dy, const uint8_t* argmax,
+                                      float* dx, avid_stream_t stream) {
+  AVID_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, AVID_E_SHAPE, "maxpool_bwd: bad shape");
+  AVID_REQUIRE(dy && dx && argmax, AVID_E_BADARG, "maxpool_bwd: null pointer");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long n = (long long)B * T * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, B * T, H,
+                     W, Ho, Wo, C / 4);
+  return check_launch("maxpool_bwd");
+}
+
+extern "C" int avid_global_maxpool_fwd(int B, int S, int C, const float* x, float* y, int32_t* argmax,
+                                       avid_stream_t stream) {
+  AVID_REQUIRE(B > 0 && S > 0 && C > 0, AVID_E_SHAPE, "global_maxpool_fwd: bad shape");
+  AVID_REQUIRE(x && y && argmax, AVID_E_BADARG, "global_maxpool_fwd: null pointer");
+  const long long n = (long long)B * C;
+  hipLaunchKernelGGL(global_maxpool_fwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     y, argmax, B, S, C);
+  return check_launch("global_maxpool_fwd");
+}
+
+extern "C" int avid_global_maxpool_bwd(int B, int S, int C, const float* dy, const int32_t* argmax, float* dx,
+                                       avid_stream_t stream) {
+  AVID_REQUIRE(B > 0 && S > 0 && C > 0, AVID_E_SHAPE, "global_maxpool_bwd: bad shape");
+  AVID_REQUIRE(dy && dx && argmax, AVID_E_BADARG, "global_maxpool_bwd: null pointer");
+  const long long n = (long long)B * S * C;
+  hipLaunchKernelGGL(global_maxpool_bwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     dy, argmax, dx, B, S, C);
+  return check_launch("global_maxpool_bwd");
+}
+
+extern "C" int avid_relu_bwd(int64_t n, const float* y, const float* dy, float* dx, avid_stream_t stream) {
+  AVID_REQUIRE(n > 0 && y && dy && dx, AVID_E_BADARG, "relu_bwd: bad argument");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, (long long)n);
+  return check_launch("relu_bwd");
+}
+
+extern "C" int avid_colsum(int64_t M, int C, const float* x, float* out, avid_stream_t stream) {
+  AVID_REQUIRE(M > 0 && C > 0 && x && out, AVID_E_BADARG, "colsum: bad argument");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream, x, out,
+                     (long long)M, C);
+  return check_launch("colsum");
+}

@@ -1,0 +1,96 @@
+"""Two-tower wrapper + projection heads (reference: models/av_wrapper.py:17-76)."""
+import math
+
+import torch
+import torch.nn as nn
+
+from avid_hip import ops
+
+__all__ = ["av_wrapper"]
+
+
+class LinearCL(nn.Module):
+    """nn.Linear replacement (same ``weight [out,in]`` / ``bias`` and default init); optional fused ReLU."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_features)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, relu=False):
+        return ops.linear(x, self.weight, self.bias, relu)
+
+    def extra_repr(self):
+        return f"in_features={self.in_features}, out_features={self.out_features}, bias=True"
+
+
+class Head(nn.Module):
+    """Linear(+ReLU) x (n-1), Linear — av_wrapper.py:17-33.  ``projection`` keeps indices 0,2,4."""
+
+    def __init__(self, input_dim, proj_dims):
+        super().__init__()
+        if not isinstance(proj_dims, list):
+            proj_dims = [proj_dims]
+        projection = []
+        for i, d in enumerate(proj_dims):
+            projection += [LinearCL(input_dim, d)]
+            input_dim = d
+            if i < len(proj_dims) - 1:
+                projection += [nn.ReLU(inplace=True)]
+        self.projection = nn.Sequential(*projection)
+        self.out_dim = proj_dims[-1]
+
+    def forward(self, x):
+        mods = list(self.projection)
+        i = 0
+        while i < len(mods):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = mods[i](x, relu=fuse)
+            i += 2 if fuse else 1
+        return x
+
+
+class AV_Wrapper(nn.Module):
+    def __init__(self, video_model, audio_model, proj_dim=128):
+        super().__init__()
+        self.video_model = video_model
+        self.audio_model = audio_model
+        self.use_linear_proj = proj_dim is not None
+        if proj_dim is not None:
+            self.video_proj = Head(video_model.out_dim, proj_dim)
+            self.audio_proj = Head(audio_model.out_dim, proj_dim)
+            self.out_dim = self.video_proj.out_dim
+        else:
+            self.out_dim = video_model.out_dim
+
+    def forward(self, video, audio):
+        video_emb = self.video_model(video)
+        video_emb = video_emb.view(video_emb.shape[0], video_emb.shape[1])
+        if self.use_linear_proj:
+            video_emb = self.video_proj(video_emb)
+        audio_emb = self.audio_model(audio)
+        audio_emb = audio_emb.view(audio_emb.shape[0], audio_emb.shape[1])
+        if self.use_linear_proj:
+            audio_emb = self.audio_proj(audio_emb)
+        return video_emb, audio_emb
+
+
+def av_wrapper(video_backbone, video_backbone_args, audio_backbone, audio_backbone_args, proj_dim=128,
+               checkpoint=None):
+    """Factory with the reference signature (av_wrapper.py:64); backbones resolved by name."""
+    import models
+    assert video_backbone in models.__dict__, 'Unknown model architecture'
+    assert audio_backbone in models.__dict__, 'Unknown model architecture'
+    video_model = models.__dict__[video_backbone](**video_backbone_args)
+    audio_model = models.__dict__[audio_backbone](**audio_backbone_args)
+    model = AV_Wrapper(video_model, audio_model, proj_dim=proj_dim)
+    if checkpoint is not None:
+        ckp = torch.load(checkpoint, map_location='cpu')
+        # reference checkpoints carry the DataParallel 'module.' prefix (av_wrapper.py:72-74)
+        sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in ckp['model'].items()}
+        model.load_state_dict(sd)
+    return model

@@ -1,0 +1,129 @@
+"""Building blocks of the two encoders on the gfx950 kernels (reference: models/network_blocks.py).
+
+Modules keep the reference's attribute names, parameter shapes and state_dict keys; internally
+activations are channels-last ``[B,T,H,W,C]`` and every op is a hand-written HIP kernel
+(avid_hip.ops).  Conv+residual-add and BN+ReLU are fused.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from avid_hip import ops
+
+
+class ConvCL(nn.Module):
+    """nn.Conv3d / nn.Conv2d (bias=False) replacement.
+
+    ``weight`` has the reference's logical shape ``[Cout, Cin, *k]`` and torch's default init
+    (kaiming_uniform(a=sqrt(5)), as nn.Conv3d.reset_parameters) but channels-last memory.
+    """
+
+    def __init__(self, in_planes, out_planes, kernel_size, stride, padding, channel_first=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_planes, out_planes
+        self.kernel_size, self.ndim = tuple(kernel_size), len(kernel_size)
+        pad3 = lambda v: (1,) * 0 + ((v,) * 3 if isinstance(v, int) else tuple(v))  # noqa: E731
+        k3 = (1,) * (3 - self.ndim) + self.kernel_size
+        s = pad3(stride) if not isinstance(stride, int) else (stride,) * self.ndim
+        p = pad3(padding) if not isinstance(padding, int) else (padding,) * self.ndim
+        self.stride3 = (1,) * (3 - len(s)) + tuple(s)
+        self.padding3 = (0,) * (3 - len(p)) + tuple(p)
+        self.k3 = k3
+        self.channel_first = channel_first
+        self.weight = nn.Parameter(ops.make_weight(out_planes, in_planes, *self.kernel_size))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def forward(self, x, addend=None):
+        return ops.conv_cl(x, self.weight, self.stride3, self.padding3, addend=addend,
+                           channel_first=self.channel_first)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
+                f"stride={self.stride3[3 - self.ndim:]}, padding={self.padding3[3 - self.ndim:]}, bias=False")
+
+
+class BatchNormCL(nn.Module):
+    """nn.BatchNorm3d/2d replacement over channels-last activations, optional fused ReLU.
+
+    Same parameters / buffers / defaults (eps 1e-5, momentum 0.1, affine, track_running_stats).
+    """
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, relu=False):
+        if self.training:
+            self.num_batches_tracked.add_(1)
+        return ops.batch_norm_cl(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                 self.momentum, self.eps, relu)
+
+    def extra_repr(self):
+        return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"
+
+
+class Basic2DBlock(nn.Module):
+    """reference models/network_blocks.py:13-27 — ReLU(bn1(conv1)) -> ReLU(bn2(conv2)); no residual."""
+
+    def __init__(self, in_planes, out_planes, stride=(1, 1)):
+        super().__init__()
+        if isinstance(stride, int):
+            stride = (stride, stride)
+        self.conv1 = ConvCL(in_planes, out_planes, (3, 3), stride, (1, 1))
+        self.bn1 = BatchNormCL(out_planes)
+        self.conv2 = ConvCL(out_planes, out_planes, (3, 3), (1, 1), (1, 1))
+        self.bn2 = BatchNormCL(out_planes)
+        self.relu = nn.ReLU(inplace=True)      # kept for module-tree parity; fused into the BN kernels
+
+    def forward(self, x):
+        x = self.bn1(self.conv1(x), relu=True)
+        x = self.bn2(self.conv2(x), relu=True)
+        return x
+
+
+class BasicR2P1DBlock(nn.Module):
+    """reference models/network_blocks.py:30-60.
+
+    spt(1,3,3) -> BN -> ReLU -> tmp(3,1,1) -> BN -> ReLU -> spt -> BN -> ReLU -> tmp ; the residual
+    (1x1x1 strided ``res_conv`` or identity) is added inside tmp_conv2's epilogue; out = ReLU(out_bn(.)).
+    """
+
+    def __init__(self, in_planes, out_planes, stride=(1, 1, 1)):
+        super().__init__()
+        spt_stride = (1, stride[1], stride[2])
+        tmp_stride = (stride[0], 1, 1)
+        self.spt_conv1 = ConvCL(in_planes, out_planes, (1, 3, 3), spt_stride, (0, 1, 1))
+        self.spt_bn1 = BatchNormCL(out_planes)
+        self.tmp_conv1 = ConvCL(out_planes, out_planes, (3, 1, 1), tmp_stride, (1, 0, 0))
+        self.tmp_bn1 = BatchNormCL(out_planes)
+        self.spt_conv2 = ConvCL(out_planes, out_planes, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+        self.spt_bn2 = BatchNormCL(out_planes)
+        self.tmp_conv2 = ConvCL(out_planes, out_planes, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+        self.out_bn = BatchNormCL(out_planes)
+        self.relu = nn.ReLU(inplace=True)
+        if in_planes != out_planes or any(s != 1 for s in stride):
+            self.res = True
+            self.res_conv = ConvCL(in_planes, out_planes, (1, 1, 1), stride, (0, 0, 0))
+        else:
+            self.res = False
+
+    def forward(self, x):
+        h = self.spt_bn1(self.spt_conv1(x), relu=True)
+        h = self.tmp_bn1(self.tmp_conv1(h), relu=True)
+        h = self.spt_bn2(self.spt_conv2(h), relu=True)
+        x_res = self.res_conv(x) if self.res else x
+        s = self.tmp_conv2(h, addend=x_res)
+        return self.out_bn(s, relu=True)
+
+
+class MaxPoolHW3S2(nn.Module):
+    """nn.MaxPool3d((1,3,3),(1,2,2),(0,1,1)) over channels-last activations (models/video.py:23)."""
+
+    def forward(self, x):
+        return ops.maxpool_hw3s2(x)

@@ -1,0 +1,187 @@
+/*
+ * avid_hip.h — C-ABI of libavid_hip.so: the MI355X (gfx950) kernels behind the AVID / AVID-CMA
+ * training step.  Plain C types only; no torch / C++ types cross this boundary.
+ *
+ * The reference (facebookresearch/AVID-CMA) is pure Python and has no FFI of its own: every entry
+ * point below replaces the ATen/cuDNN op that a reference line dispatches to.  Each declaration
+ * cites that line (paths relative to the reference root).  The Python side that binds these symbols
+ * with ctypes lives in avid-cma_amd/avid_hip/lib.py; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - All device pointers are fp32 unless stated; indices are int64 (reference: default collate of
+ *     Python ints, datasets/video_db.py:263) except positive_set (int32, criterions/avid_cma.py:223).
+ *   - Activations are channels-last: [B, T, H, W, C] (2-D audio uses T = 1).  Conv weights are
+ *     [Cout][kt][kh][kw][Cin] — the memory of a torch tensor of logical shape [Cout,Cin,kt,kh,kw]
+ *     held in torch.channels_last_3d format, so state_dict keys *and shapes* equal the reference's.
+ *   - The stem convs read the reference's NCDHW / NCHW input directly (x_channel_first = 1).
+ *   - Every call is asynchronous on `stream` (a hipStream_t); nothing here synchronises the host.
+ *   - The library never allocates persistent device memory: scratch is passed in by the caller
+ *     (sizes from the *_workspace_bytes queries); torch owns every buffer.
+ *   - Return value: 0 = AVID_OK, negative = error; avid_last_error() gives the message
+ *     (thread-local).  Kernels never abort.
+ */
+#ifndef AVID_HIP_H
+#define AVID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVID_OK 0
+#define AVID_E_BADARG (-1)
+#define AVID_E_SHAPE (-2)
+#define AVID_E_HIP (-3)
+#define AVID_E_UNSUPPORTED (-4)
+
+typedef void* avid_stream_t; /* hipStream_t */
+
+const char* avid_last_error(void);
+int avid_version(void);
+/* CU count / LDS per CU / arch name of `device` ("gfx950" expected). */
+int avid_device_info(int device, int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution = implicit GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-fp32 numerics.
+ * Replaces nn.Conv3d / nn.Conv2d / nn.Linear forward+backward:
+ *   models/video.py:20, models/network_blocks.py:18,20,35,37,40,42,49, models/audio.py:22,
+ *   models/av_wrapper.py:25 (Linear == 1x1x1 conv over a [B,1,1,1,C] tensor).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct avid_conv_desc {
+  int32_t B, Ti, Hi, Wi, Cin; /* input  [B,Ti,Hi,Wi,Cin] */
+  int32_t To, Ho, Wo, Cout;   /* output [B,To,Ho,Wo,Cout] */
+  int32_t kt, kh, kw;         /* kernel extent */
+  int32_t st, sh, sw;         /* stride */
+  int32_t pt, ph, pw;         /* zero padding */
+  int32_t x_channel_first;    /* 1: x is [B,Cin,Ti,Hi,Wi] (stems only; Cin in {1,3}) */
+} avid_conv_desc;
+
+/* y = conv(x, w) [+ addend] [+ bias] [relu].  addend: [B,To,Ho,Wo,Cout] or NULL (residual add of
+ * models/network_blocks.py:59 fused into tmp_conv2/res_conv); bias: [Cout] or NULL. */
+int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* addend,
+                  const float* bias, int relu, float* y, avid_stream_t stream);
+
+/* dx = conv_transpose(dy, w) [+ addend].  ws: scratch for the transposed weights. */
+size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d);
+int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* addend,
+                    float* dx, void* ws, size_t ws_bytes, avid_stream_t stream);
+
+/* dw[Cout][kt][kh][kw][Cin] = sum_m dy[m][:]^T x_col[m][:]  (deterministic split-M + tree reduce). */
+size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d);
+int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,
+                    size_t ws_bytes, avid_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm (train / eval) over a channels-last [M, C] view, fused ReLU.
+ * Replaces nn.BatchNorm3d/2d + nn.ReLU: models/network_blocks.py:19,21,36,38,41,43,54-59,
+ * models/video.py:21-22, models/audio.py:23-24.
+ * ---------------------------------------------------------------------------------------------- */
+size_t avid_bn_workspace_bytes(int64_t M, int C);
+/* Train: batch mean / biased var -> save_mean, save_invstd [C]; running stats updated in place
+ * (momentum, unbiased var); y = [relu](gamma * (x - mean) * invstd + beta). */
+int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, int relu,
+                      float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                      avid_stream_t stream);
+/* Eval: uses running stats. */
+int avid_bn_fwd_eval(int64_t M, int C, const float* x, const float* gamma, const float* beta,
+                     const float* running_mean, const float* running_var, float eps, int relu,
+                     float* y, avid_stream_t stream);
+/* Backward of train-mode BN(+ReLU): y is the saved forward output (ReLU mask = y > 0). */
+int avid_bn_bwd(int64_t M, int C, const float* x, const float* y, const float* dy,
+                const float* gamma, const float* save_mean, const float* save_invstd, int relu,
+                float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                avid_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pooling.  MaxPool3d((1,3,3),(1,2,2),(0,1,1)) — models/video.py:23;  AdaptiveMaxPool{3,2}d(1) —
+ * models/video.py:41, models/audio.py:31.  Ties: first maximum in (t,h,w) scan order (ATen CPU).
+ * ---------------------------------------------------------------------------------------------- */
+int avid_maxpool_hw3s2_fwd(int B, int T, int H, int W, int C, const float* x, float* y,
+                           uint8_t* argmax, avid_stream_t stream);
+int avid_maxpool_hw3s2_bwd(int B, int T, int H, int W, int C, const float* dy,
+                           const uint8_t* argmax, float* dx, avid_stream_t stream);
+/* x [B, S, C] -> y [B, C], argmax [B, C] (int32 position in S). */
+int avid_global_maxpool_fwd(int B, int S, int C, const float* x, float* y, int32_t* argmax,
+                            avid_stream_t stream);
+int avid_global_maxpool_bwd(int B, int S, int C, const float* dy, const int32_t* argmax, float* dx,
+                            avid_stream_t stream);
+
+/* Small helpers for the projection heads (models/av_wrapper.py:23-29). */
+int avid_relu_bwd(int64_t n, const float* y, const float* dy, float* dx, avid_stream_t stream);
+int avid_colsum(int64_t M, int C, const float* x, float* out, avid_stream_t stream); /* bias grad */
+
+/* ------------------------------------------------------------------------------------------------
+ * Criterion path (criterions/avid.py, criterions/nce.py, utils/alias_method.py).
+ * ---------------------------------------------------------------------------------------------- */
+/* F.normalize(x, p=2, dim=1) — criterions/avid.py:52-53.  norm_out [bs] = max(||x||, 1e-12). */
+int avid_l2norm_fwd(int bs, int D, const float* x, float* y, float* norm_out, avid_stream_t stream);
+int avid_l2norm_bwd(int bs, int D, const float* y, const float* norm, const float* dy, float* dx,
+                    avid_stream_t stream);
+
+/* AliasMethod.draw + "avoid self" — utils/alias_method.py:56-71, criterions/avid.py:82-86.
+ * out[i] = alias_select(prob, alias, kk_i, u_i) with (kk_i, u_i) from Philox4x32-10
+ * (counter = (i, offset), key = seed); if y != NULL: out[i] += (out[i] >= y[i / per_row]).
+ * uniform != 0 short-circuits the table lookup for the all-ones table (prob == 1, alias == 0). */
+int avid_alias_draw(int64_t n, int64_t K, const float* prob, const int64_t* alias, int uniform,
+                    uint64_t seed, uint64_t offset, const int64_t* y, int64_t per_row,
+                    int64_t* out, avid_stream_t stream);
+
+/* scores[b][j] = <bank[idx[b][j]], emb[b]> * inv_T — the gather + bmm of criterions/avid.py:57-71.
+ * idx [bs][R] int64, bank [N][D], emb [bs][D], D in {64,128,256,512}.  rows_out (nullable,
+ * [bs][R][D]) receives a snapshot of the gathered rows: the reference's autograd keeps the
+ * PRE-update rows for backward (the bank is updated inside forward, avid.py:78). */
+int avid_bank_scores_fwd(int bs, int R, int D, int64_t N, const int64_t* idx, const float* bank,
+                         const float* emb, float inv_T, float* scores, float* rows_out,
+                         avid_stream_t stream);
+/* demb[b] (+)= inv_T * sum_j dscores[b][j] * row(b,j)  (autograd of torch.bmm, avid.py:66), where
+ * row(b,j) = rows[b][j] if rows != NULL (the snapshot) else bank[idx[b][j]]. */
+int avid_bank_scores_bwd(int bs, int R, int D, int64_t N, const float* rows, const int64_t* idx,
+                         const float* bank, const float* dscores, float inv_T, int accumulate,
+                         float* demb, avid_stream_t stream);
+
+/* NCE — criterions/nce.py:38-58.  Score matrices are row-major with leading dimension ld_* so the
+ * positive / negative column blocks of one [bs][P+K] score buffer can be passed without a copy.
+ * mean_exp: out[0] = mean(exp(s[rows][cols])) (first-call Z, nce.py:27).
+ * fwd: loss[0] (+)= scale * mean_b( -mean_p log Pmt - sum_k log Pon ); Z is read from device memory.
+ * bwd: dpos [bs][P], dneg [bs][K] (dense) = dloss[0] * scale * dL/ds. */
+int avid_mean_exp(int rows, int cols, int ld, const float* s, float* out, avid_stream_t stream);
+int avid_nce_fwd(int bs, int P, int K, const float* spos, int ld_pos, const float* sneg, int ld_neg,
+                 const float* Z, float scale, int accumulate, float* loss, avid_stream_t stream);
+int avid_nce_bwd(int bs, int P, int K, const float* spos, int ld_pos, const float* sneg, int ld_neg,
+                 const float* Z, const float* dloss, float scale, float* dpos, float* dneg,
+                 avid_stream_t stream);
+
+/* update_memory — criterions/avid.py:118-129: bank[y[i]] = normalize(m*bank[y[i]] + (1-m)*emb[i]).
+ * Duplicate ids: the LAST occurrence wins (the reference's index_copy_ order is unspecified). */
+int avid_bank_update(int B, int D, int64_t N, float* bank, const int64_t* y, const float* emb,
+                     float momentum, avid_stream_t stream);
+
+/* memory_sampling remap — criterions/avid_cma.py:196-209.  positive_set int32 [N][P] (rows sorted);
+ * pos_out [bs][P] = positive_set[y];  neg_out[b][k] = r + #{j : r >= pos_j - j}, r = rand_idx[b][k]. */
+int avid_cma_negatives(int bs, int K, int P, const int32_t* positive_set, const int64_t* y,
+                       const int64_t* rand_idx, int64_t* pos_out, int64_t* neg_out,
+                       avid_stream_t stream);
+
+/* CMA correspondence search — criterions/avid_cma.py:42-73: for queries q in [q0, q0+nq):
+ * sim = combine(V V[q]^T, A A[q]^T) (kind 0 consensus=min, 1 union=max, 2 video, 3 audio);
+ * top-(pos_k+1) by similarity, drop the best (self), sort ascending -> out [nq][pos_k] int32. */
+size_t avid_cma_topk_workspace_bytes(int64_t N, int nq, int pos_k);
+int avid_cma_topk(int64_t N, int D, const float* view1, const float* view2, int64_t q0, int nq,
+                  int pos_k, int kind, int32_t* out, void* ws, size_t ws_bytes,
+                  avid_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer: torch.optim.Adam semantics (L2 weight decay folded into the gradient; bias-corrected)
+ * over one flat fp32 buffer — utils/main_utils.py:250-261.
+ * ---------------------------------------------------------------------------------------------- */
+int avid_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                   avid_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVID_HIP_H */

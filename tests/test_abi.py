@@ -1,0 +1,59 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/avid_hip.h declares (no compute calls — there is no GPU here), the ctypes table covers the
+header, and the error convention works."""
+import ctypes
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "avid_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(avid_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from avid_hip import lib
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(dll, s), f"{s} declared in include/avid_hip.h but not exported"
+    assert sorted(lib.SIGNATURES) == syms, "ctypes table and header disagree"
+
+
+def test_conv_desc_matches_header():
+    from avid_hip.lib import ConvDesc
+    src = open(HEADER).read()
+    body = re.search(r"typedef struct avid_conv_desc \{(.*?)\} avid_conv_desc;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [f.strip() for decl in re.findall(r"int32_t ([^;]+);", body) for f in decl.split(",")]
+    assert fields == [n for n, _ in ConvDesc._fields_]
+    assert ctypes.sizeof(ConvDesc) == 4 * len(fields)
+
+
+def test_error_convention():
+    from avid_hip import lib
+    assert lib.version() >= 100
+    d = lib.ConvDesc()          # all zeros -> AVID_E_SHAPE, message set, no kernel launched
+    rc = lib.raw("avid_conv_fwd")(ctypes.byref(d), None, None, None, None, 0, None, None)
+    assert rc < 0 and "conv" in lib.last_error()
+    with pytest.raises(lib.AvidHipError):
+        lib.call("avid_l2norm_fwd", 0, 0, None, None, None, None)
+    assert lib.raw("avid_bn_workspace_bytes")(1 << 20, 64) > 0
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from avid_hip import ops, AvidHipError
+    x = torch.zeros(2, 1, 4, 4, 64)
+    w = ops.make_weight(64, 64, 1, 3, 3)
+    with pytest.raises(AvidHipError):
+        ops.conv_cl(x, w, (1, 1, 1), (0, 1, 1))
+    with pytest.raises(AvidHipError):
+        ops.l2_normalize(torch.zeros(2, 128))

@@ -1,0 +1,82 @@
+"""CPU-side checks of the host-side mirror of the reference interface (no GPU, no kernels)."""
+import numpy as np
+import torch
+
+from oracle import avid_oracle as O
+
+
+def test_registry_and_state_dict_keys(golden):
+    import models
+    import criterions
+    assert {"av_wrapper", "R2Plus1D", "Conv2D"} <= set(models.__dict__)
+    assert {"AVID", "AVID_CMA"} <= set(criterions.__dict__)
+    m = models.av_wrapper("R2Plus1D", {"depth": 18}, "Conv2D", {"depth": 10}, proj_dim=[512, 512, 128])
+    g = golden("av_wrapper")
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["state_keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["state_shapes"])
+    assert m.out_dim == 128 and m.use_linear_proj
+    assert sum(p.numel() for p in m.parameters()) == 21286784
+    assert len(list(m.parameters())) == 141
+    for d in (10, 34):
+        v = models.R2Plus1D(depth=d)
+        assert ["video_model." + k for k in v.state_dict()] == [n for n, _ in O.r2plus1d_spec("video_model", d)]
+
+
+def test_weight_layout_survives_plumbing():
+    import copy
+    import models
+    from avid_hip import ops
+    m = models.R2Plus1D(depth=10)
+    w = m.conv3x.spt_conv1.weight
+    assert tuple(w.shape) == (128, 64, 1, 3, 3) and ops.weight_layout_ok(w)
+    assert w.movedim(1, -1).is_contiguous()
+    m2 = copy.deepcopy(m)
+    m2.load_state_dict({k: v.contiguous() for k, v in m.state_dict().items()})   # plain-contiguous source tensors
+    for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p, q) and (p.dim() < 3 or ops.weight_layout_ok(q)), n
+    opt = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=1e-5)
+    for p in m2.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    assert all(ops.weight_layout_ok(p) for p in m2.parameters() if p.dim() > 2)
+    assert torch.empty_like(w).stride() == w.stride()
+
+
+def test_alias_tables_match_reference(golden):
+    from utils.alias_method import AliasMethod
+    g = golden("alias")
+    for name in ["ones999", "p4", "det50"]:
+        am = AliasMethod(torch.from_numpy(g[f"{name}_probs"].copy()))
+        np.testing.assert_array_equal(am.prob.numpy(), g[f"{name}_prob"])
+        np.testing.assert_array_equal(am.alias.numpy(), g[f"{name}_alias"])
+    assert AliasMethod(torch.ones(999)).uniform and not AliasMethod(torch.tensor([.5, .3, .1, .1])).uniform
+    big = AliasMethod(torch.ones(2_000_000 - 1))      # closed form: instant (the reference loops ~1 min)
+    assert big.uniform and big.alias.numel() == 1_999_999
+
+
+def test_utils_namespace_extends(tmp_path, monkeypatch):
+    """`utils` must merge with another `utils` directory later on sys.path (the reference's)."""
+    import importlib
+    import sys
+    other = tmp_path / "ref" / "utils"
+    other.mkdir(parents=True)
+    (other / "__init__.py").write_text("")
+    (other / "main_utils_probe.py").write_text("VALUE = 42\n")
+    monkeypatch.syspath_prepend(str(tmp_path / "ref"))
+    pkg = sys.path.pop(0)
+    sys.path.append(pkg)                      # ours first, the "reference" later
+    for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        monkeypatch.delitem(sys.modules, k)
+    utils = importlib.import_module("utils")
+    from utils.alias_method import AliasMethod  # noqa: F401  (ours)
+    probe = importlib.import_module("utils.main_utils_probe")
+    assert probe.VALUE == 42 and len(utils.__path__) >= 2
+
+
+def test_nce_checkpoint_shape_quirk():
+    from criterions.nce import NCECriterion
+    c = NCECriterion(10)
+    assert c.avg_exp_score.shape == ()
+    c.load_state_dict({"avg_exp_score": torch.tensor([3.5])})     # reference stores shape (1,) after step 1
+    assert c.avg_exp_score.shape == () and float(c.avg_exp_score) == 3.5
