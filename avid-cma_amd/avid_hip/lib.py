@@ -56,11 +56,14 @@ SIGNATURES = {
     "avid_last_error": (C.c_char_p, []),
     "avid_version": (_i, []),
     "avid_device_info": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
+    "avid_timing_enable": (_i, [_i]),
+    "avid_timing_report": (_i, [C.c_char_p, _sz]),
     "avid_conv_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "avid_conv_dgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_conv_wgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_wgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avid_conv_kernel_name": (_i, [_dp, _i, C.c_char_p, _i]),
     "avid_bn_workspace_bytes": (_sz, [_i64, _i]),
     "avid_bn_fwd_train": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_bn_fwd_eval": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
@@ -124,3 +127,18 @@ def device_info(device: int = 0):
     buf = C.create_string_buffer(64)
     check(_lib.avid_device_info(device, C.byref(cu), C.byref(lds), buf, 64), "avid_device_info")
     return {"cu_count": cu.value, "lds_bytes": lds.value, "arch": buf.value.decode()}
+
+
+def timing_enable(on: bool):
+    check(_lib.avid_timing_enable(1 if on else 0), "avid_timing_enable")
+
+
+def timing_report():
+    """{kernel name: {"launches", "ms", "flops", "bytes"}} for everything launched since timing_enable(True)."""
+    buf = C.create_string_buffer(1 << 16)
+    check(_lib.avid_timing_report(buf, len(buf)), "avid_timing_report")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, n, ms, fl, by = line.split(";")
+        out[name] = {"launches": int(n), "ms": float(ms), "flops": float(fl), "bytes": float(by)}
+    return out

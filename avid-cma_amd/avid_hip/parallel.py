@@ -1,0 +1,144 @@
+"""Data-parallel training step: one process per MI355X, RCCL (torch.distributed "nccl") over xGMI.
+
+What the reference does with ``DistributedDataParallel`` + ``torch.optim.Adam``
+(utils/main_utils.py:105-117, :250-261; main-avid.py:155-180) is done here with
+
+* ``FlatParams``   — every parameter (and its gradient) is a strided view into ONE flat fp32 buffer,
+                     laid out in reverse registration order so buckets complete front-to-back while
+                     backward runs (conv5x / heads first).  Views keep each tensor's memory format,
+                     so the channels-last conv weights stay channels-last.
+* ``GradBuckets``  — per-bucket async all-reduce (sum) launched from post-accumulate-grad hooks as soon
+                     as the bucket's last gradient is written, i.e. overlapped with the rest of
+                     backward; ``finish()`` makes the compute stream wait.  The 1/world average is
+                     folded into the optimizer kernel's ``grad_scale``.
+* ``TrainStep``    — fwd -> criterion -> bwd (+ overlapped all-reduce) -> one fused flat-Adam launch.
+
+The comm layer is backend-agnostic (gloo on CPU in tests/test_distributed_cpu.py); only the Adam
+kernel needs the GPU.  BatchNorm statistics stay per-rank — the reference has no SyncBN.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class FlatParams:
+    """Re-seat ``module``'s parameters and gradients as views of two flat buffers."""
+
+    def __init__(self, module: torch.nn.Module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.params = list(reversed(params))            # backward produces gradients roughly in this order
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.offsets, off = [], 0
+        for p in self.params:
+            if not (p.is_contiguous() or p.movedim(1, -1).is_contiguous()):
+                raise ValueError("FlatParams needs dense parameters")
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4             # keep every slice 16-byte aligned
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=dt, device=dev)
+        self.grad = torch.zeros(off, dtype=dt, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            view = self.flat[o:o + p.numel()].as_strided(p.shape, p.stride())
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[o:o + p.numel()].as_strided(p.shape, p.stride())
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):     # re-seat if something replaced .grad (set_to_none)
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].as_strided(p.shape, p.stride())
+
+
+class GradBuckets:
+    """Bucketed, backward-overlapped gradient all-reduce over a ``FlatParams`` gradient buffer."""
+
+    def __init__(self, flat: FlatParams, bucket_bytes: int = 16 << 20):
+        self.flat = flat
+        self.world = dist.get_world_size() if _dist_on() else 1
+        self.bounds, self.bucket_of = [], []
+        start, cur = 0, 0
+        for i, (p, o) in enumerate(zip(flat.params, flat.offsets)):
+            end = o + (p.numel() + 3) // 4 * 4
+            self.bucket_of.append(len(self.bounds))
+            if (end - start) * 4 >= bucket_bytes or i == len(flat.params) - 1:
+                self.bounds.append((start, end))
+                start = end
+        self.counts = [0] * len(self.bounds)
+        for b in self.bucket_of:
+            self.counts[b] += 1
+        self.pending = list(self.counts)
+        self.works = []
+        self.hooks = []
+        if self.world > 1:
+            for i, p in enumerate(flat.params):
+                self.hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i):
+        b = self.bucket_of[i]
+
+        def hook(param):
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                s, e = self.bounds[b]
+                self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
+        return hook
+
+    def finish(self):
+        """Launch whatever did not fire (unused parameters) and make the current stream wait for all buckets."""
+        if self.world > 1:
+            for b, left in enumerate(self.pending):
+                if left > 0:
+                    s, e = self.bounds[b]
+                    self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
+            for w in self.works:
+                w.wait()
+        self.works = []
+        self.pending = list(self.counts)
+
+
+class TrainStep:
+    """One AVID training step (main-avid.py:155-180) on this rank's GPU.
+
+    ``step(video, audio, index)`` returns the (device) loss tensor; nothing synchronises the host.
+    Adam hyper-parameters follow the shipped configs (lr 2e-4, betas (0.9, 0.999), L2 wd 1e-5).
+    """
+
+    def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5,
+                 bucket_bytes=16 << 20):
+        self.model, self.criterion = model, criterion
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        if _dist_on():                                   # DDP's construction-time parameter broadcast (C3)
+            for p in model.parameters():
+                dist.broadcast(p.data, 0)
+            for b in model.buffers():
+                dist.broadcast(b.data, 0)
+        self.flat = FlatParams(model)
+        self.buckets = GradBuckets(self.flat, bucket_bytes)
+        self.m = torch.zeros_like(self.flat.flat)
+        self.v = torch.zeros_like(self.flat.flat)
+        self.t = 0
+
+    def forward_backward(self, video, audio, index):
+        self.flat.zero_grad()
+        video_emb, audio_emb = self.model(video, audio)
+        loss, _ = self.criterion(video_emb, audio_emb, index)
+        loss.backward()
+        self.buckets.finish()
+        return loss
+
+    def optimizer_step(self):
+        from . import ops
+        self.t += 1
+        ops.adam_flat(self.flat.flat, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.wd, self.t, grad_scale=1.0 / self.buckets.world)
+
+    def step(self, video, audio, index):
+        loss = self.forward_backward(video, audio, index)
+        self.optimizer_step()
+        return loss.detach()

@@ -33,6 +33,15 @@ inline int check_launch(const char* what) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Optional per-kernel timing with HIP events recorded on the launch stream (avid_timing_enable /
+// avid_timing_report): bench.py uses it for the roofline numbers.  Zero cost when disabled.
+struct ScopedTimer {
+  hipStream_t s;
+  int slot;
+  ScopedTimer(hipStream_t stream, const char* name, double flops, double bytes);
+  ~ScopedTimer();
+};
+
 // 64-lane wave reductions (DPP/ds_swizzle chosen by the compiler from __shfl_xor).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1,6 +1,10 @@
 // Error plumbing + device query for libavid_hip.so.
 #include <stdarg.h>
 
+#include <map>
+#include <string>
+#include <vector>
+
 #include "common.h"
 
 namespace avid {
@@ -12,7 +16,80 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+struct TimingRec {
+  const char* name;
+  double flops, bytes;
+  hipEvent_t e0, e1;
+};
+static bool g_timing = false;
+static std::vector<TimingRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+ScopedTimer::ScopedTimer(hipStream_t stream, const char* name, double flops, double bytes) : s(stream), slot(-1) {
+  if (!g_timing) return;
+  TimingRec r{name, flops, bytes, get_event(), get_event()};
+  (void)hipEventRecord(r.e0, s);
+  slot = (int)g_recs.size();
+  g_recs.push_back(r);
+}
+ScopedTimer::~ScopedTimer() {
+  if (slot >= 0) (void)hipEventRecord(g_recs[slot].e1, s);
+}
 }  // namespace avid
+
+extern "C" int avid_timing_enable(int on) {
+  using namespace avid;
+  for (auto& r : g_recs) {
+    g_pool.push_back(r.e0);
+    g_pool.push_back(r.e1);
+  }
+  g_recs.clear();
+  g_timing = on != 0;
+  return AVID_OK;
+}
+
+// CSV: name,launches,total_ms,total_flops,total_bytes  (one line per kernel; synchronises the events)
+extern "C" int avid_timing_report(char* buf, size_t len) {
+  using namespace avid;
+  if (!buf || len == 0) {
+    set_error("timing_report: bad buffer");
+    return AVID_E_BADARG;
+  }
+  struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::map<std::string, Agg> agg;
+  for (auto& r : g_recs) {
+    if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    Agg& a = agg[r.name];
+    a.n += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+  }
+  std::string out;
+  char line[512];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof(line), "%s;%ld;%.6f;%.6e;%.6e\n", kv.first.c_str(), kv.second.n, kv.second.ms,
+             kv.second.flops, kv.second.bytes);
+    out += line;
+  }
+  if (out.size() + 1 > len) {
+    set_error("timing_report: buffer too small (%zu needed)", out.size() + 1);
+    return AVID_E_BADARG;
+  }
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return AVID_OK;
+}
 
 extern "C" const char* avid_last_error(void) { return avid::g_err; }
 extern "C" int avid_version(void) { return 100; }

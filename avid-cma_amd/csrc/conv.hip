@@ -489,21 +489,36 @@ static int launch_igemm(const ConvArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const unsigned ntm = (a.M + BM - 1) / BM, ntn = a.Cd / BN;
+  static char name[64] = "";
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_kernel<%d,%d,%d,%d,%d>", WM, WN, TM, TN, VEC ? 1 : 0);
+  const double K = (double)a.kt * a.kh * a.kw * a.Cs;
+  // algorithmic work: 2*M*N*K flops; bytes = one read of src + weights, one write of dst (+ addend)
+  const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
+  ScopedTimer t(s, name, 2.0 * a.M * a.Cd * K,
+                4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (a.addend ? 2 : 1)));
   hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), lds, s, a);
   return check_launch("igemm");
 }
 
 // Tile choice: the biggest tile that still gives every CU >= 2 workgroups; small-M late layers fall
 // back to 64x64 / 32x128 tiles (split-K for them is a later optimisation).
+static int pick_tile(long long M, int Cd) {
+  const long long want = 2 * 256;
+  if (Cd % 128 == 0 && ((M + 127) / 128) * (Cd / 128) >= want) return 0;  // 128 x 128
+  if (((M + 127) / 128) * (Cd / 64) >= want) return 1;                    // 128 x 64
+  if (Cd % 128 == 0 && M <= 2048) return 2;                               // 32 x 128
+  return 3;                                                               // 64 x 64
+}
+static const char* kTileName[4] = {"2,2,2,2", "4,1,1,2", "1,4,1,1", "2,2,1,1"};
+
 template <bool VEC>
 static int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
-  const long long M = a.M;
-  const int Cd = a.Cd;
-  const long long want = 2 * 256;
-  if (Cd % 128 == 0 && ((M + 127) / 128) * (Cd / 128) >= want) return launch_igemm<2, 2, 2, 2, VEC>(a, s);
-  if (((M + 127) / 128) * (Cd / 64) >= want) return launch_igemm<4, 1, 1, 2, VEC>(a, s);
-  if (Cd % 128 == 0 && M <= 2048) return launch_igemm<1, 4, 1, 1, VEC>(a, s);  // 32 x 128
-  return launch_igemm<2, 2, 1, 1, VEC>(a, s);                                    // 64 x 64
+  switch (pick_tile(a.M, a.Cd)) {
+    case 0: return launch_igemm<2, 2, 2, 2, VEC>(a, s);
+    case 1: return launch_igemm<4, 1, 1, 2, VEC>(a, s);
+    case 2: return launch_igemm<1, 4, 1, 1, VEC>(a, s);
+    default: return launch_igemm<2, 2, 1, 1, VEC>(a, s);
+  }
 }
 
 }  // namespace avid
@@ -549,8 +564,11 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
   const int ntaps = d->kt * d->kh * d->kw;
   float* wt = static_cast<float*>(ws);
   const long long nw = (long long)d->Cout * ntaps * d->Cin;
-  hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, s, w, wt, d->Cout,
-                     ntaps, d->Cin);
+  {
+    ScopedTimer t(s, "weight_transpose_kernel", 0.0, 8.0 * nw);
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, s, w, wt, d->Cout,
+                       ntaps, d->Cin);
+  }
   rc = check_launch("weight_transpose");
   if (rc) return rc;
   ConvArgs a;
@@ -614,17 +632,44 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
   fill_src_strides(d, a.ssB, a.ssT, a.ssH, a.ssW, a.ssC);
   const size_t lds = sizeof(float) * 4 * 32 * WG_LD + sizeof(int2) * 64;
   dim3 grid((unsigned)(kt_tiles * (d->Cout / 64)), (unsigned)nsplit);
-  if (vec)
-    hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(256), lds, s, a);
-  else
-    hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(256), lds, s, a);
+  {
+    const double K = (double)a.kt * a.kh * a.kw * a.Cs;
+    const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
+    ScopedTimer t(s, vec ? "wgrad_kernel<1>" : "wgrad_kernel<0>", 2.0 * a.M * a.Cd * K,
+                  4.0 * (srcpix * a.Cs + (double)a.M * a.Cd + (double)a.Cd * K));
+    if (vec)
+      hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(256), lds, s, a);
+    else
+      hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(256), lds, s, a);
+  }
   rc = check_launch("wgrad");
   if (rc) return rc;
   if (nsplit > 1) {
     const long long n = (long long)d->Cout * d->kt * d->kh * d->kw * d->Cin;
+    ScopedTimer t(s, "wgrad_reduce_kernel", 0.0, 4.0 * n * (nsplit + 1));
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,
                        static_cast<const float*>(ws), dw, n, nsplit);
     rc = check_launch("wgrad_reduce");
   }
   return rc;
+}
+
+extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* buf, int len) {
+  int rc = validate(d);
+  if (rc) return rc;
+  AVID_REQUIRE(buf && len > 0 && which >= 0 && which <= 2, AVID_E_BADARG, "conv_kernel_name: bad argument");
+  const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
+  if (which == 0) {
+    const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
+    snprintf(buf, len, "igemm_kernel<%s,%d>", kTileName[pick_tile(M, d->Cout)], vec ? 1 : 0);
+  } else if (which == 1) {
+    const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
+    snprintf(buf, len, "igemm_kernel<%s,1>", kTileName[pick_tile(M, d->Cin)]);
+  } else {
+    int kt_tiles, nsplit, cps;
+    bool v;
+    wgrad_plan(d, kt_tiles, nsplit, cps, v);
+    snprintf(buf, len, "wgrad_kernel<%d>", v ? 1 : 0);
+  }
+  return AVID_OK;
 }

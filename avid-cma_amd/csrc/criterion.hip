@@ -333,6 +333,7 @@ extern "C" int avid_bank_scores_fwd(int bs, int R, int D, int64_t N, const int64
   dim3 grid((unsigned)ceil_div(R, SC_ROWS_PER_BLOCK), (unsigned)bs);
   hipStream_t s = (hipStream_t)stream;
   const long long* ix = (const long long*)idx;
+  ScopedTimer t(s, "bank_scores_fwd_kernel", 2.0 * bs * R * D, 4.0 * bs * R * ((double)D * (rows_out ? 2 : 1) + 3));
   switch (D / 64) {
     case 1: hipLaunchKernelGGL(bank_scores_fwd_kernel<1>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N); break;
     case 2: hipLaunchKernelGGL(bank_scores_fwd_kernel<2>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N); break;
@@ -350,6 +351,7 @@ extern "C" int avid_bank_scores_bwd(int bs, int R, int D, int64_t N, const float
   AVID_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, AVID_E_UNSUPPORTED, "bank_scores_bwd: D=%d unsupported", D);
   hipStream_t s = (hipStream_t)stream;
   const long long* ix = (const long long*)idx;
+  ScopedTimer t(s, "bank_scores_bwd_kernel", 2.0 * bs * R * D, 4.0 * bs * R * ((double)D + 1));
   switch (D / 64) {
     case 1: hipLaunchKernelGGL(bank_scores_bwd_kernel<1>, dim3(bs), dim3(1024), 0, s, rows, ix, bank, dscores, inv_T, accumulate, demb, R, (long long)N); break;
     case 2: hipLaunchKernelGGL(bank_scores_bwd_kernel<2>, dim3(bs), dim3(1024), 0, s, rows, ix, bank, dscores, inv_T, accumulate, demb, R, (long long)N); break;

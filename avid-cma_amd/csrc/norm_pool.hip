@@ -410,12 +410,18 @@ extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* 
   float* part = static_cast<float*>(ws);
   float* scale = part + (size_t)p.nblk * 2 * C;
   float* shift = scale + C;
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
-                     p.rows_per_pass, p.rows_per_block);
+  {
+    ScopedTimer t(s, "bn_stats_partial_kernel", 0.0, 4.0 * M * C);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
+                       p.rows_per_pass, p.rows_per_block);
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64), 0, s, part, p.nblk, (long long)M,
                      C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
   const long long n4 = (long long)M * p.G;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, x, y, scale, shift, n4, p.G, relu);
+  {
+    ScopedTimer t(s, "bn_apply_kernel", 0.0, 8.0 * M * C);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, x, y, scale, shift, n4, p.G, relu);
+  }
   return check_launch("bn_fwd_train");
 }
 
@@ -445,13 +451,19 @@ extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* y, con
   float* part = static_cast<float*>(ws);
   float* k1 = part + (size_t)p.nblk * 2 * C;
   float* k2 = k1 + C;
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, y, dy, save_mean, save_invstd, part,
-                     (long long)M, C, p.G, p.rows_per_pass, p.rows_per_block, relu);
+  {
+    ScopedTimer t(s, "bn_bwd_partial_kernel", 0.0, 4.0 * M * C * (relu ? 3 : 2));
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, y, dy, save_mean, save_invstd, part,
+                       (long long)M, C, p.G, p.rows_per_pass, p.rows_per_block, relu);
+  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64), 0, s, part, p.nblk,
                      (long long)M, C, dgamma, dbeta, k1, k2);
   const long long n4 = (long long)M * p.G;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, x, y, dy, gamma, save_mean, save_invstd,
-                     k1, k2, dx, n4, p.G, relu);
+  {
+    ScopedTimer t(s, "bn_bwd_apply_kernel", 0.0, 4.0 * M * C * (relu ? 4 : 3));
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, x, y, dy, gamma, save_mean,
+                       save_invstd, k1, k2, dx, n4, p.G, relu);
+  }
   return check_launch("bn_bwd");
 }
 
@@ -461,6 +473,8 @@ extern "C" int avid_maxpool_hw3s2_fwd(int B, int T, int H, int W, int C, const f
   AVID_REQUIRE(x && y && argmax, AVID_E_BADARG, "maxpool_fwd: null pointer");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long n = (long long)B * T * Ho * Wo * (C / 4);
+  ScopedTimer t((hipStream_t)stream, "maxpool_fwd_kernel", 0.0,
+                4.0 * B * T * C * ((double)H * W + 1.25 * Ho * Wo));
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, B * T, H,
                      W, Ho, Wo, C / 4);
   return check_launch("maxpool_fwd");
@@ -472,6 +486,8 @@ extern "C" int avid_maxpool_hw3s2_bwd(int B, int T, int H, int W, int C, const f
   AVID_REQUIRE(dy && dx && argmax, AVID_E_BADARG, "maxpool_bwd: null pointer");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long n = (long long)B * T * H * W * (C / 4);
+  ScopedTimer t((hipStream_t)stream, "maxpool_bwd_kernel", 0.0,
+                4.0 * B * T * C * ((double)H * W + 1.25 * Ho * Wo));
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, B * T, H,
                      W, Ho, Wo, C / 4);
   return check_launch("maxpool_bwd");

@@ -56,6 +56,7 @@ extern "C" int avid_adam_flat(int64_t n, float* p, const float* g, float* m, flo
   const long long n4 = n / 4;
   long long grid = ceil_div(n4 > 0 ? n4 : 1, 256);
   if (grid > 4096) grid = 4096;
+  ScopedTimer t((hipStream_t)stream, "adam_flat_kernel", 0.0, 28.0 * n);
   hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4,
                      (long long)n, beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale);
   return check_launch("adam_flat");

@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py — the AVID training step on N x MI355X (one process per GPU, RCCL over xGMI).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over one synthetic batch that is already
+resident in HBM: R(2+1)D-18 + Conv2D forward -> AVID criterion (alias draw, bank gather, NCE, EMA
+bank update) -> backward (gradient all-reduce overlapped) -> fused flat Adam.  Workload = BASELINE.json
+configs[1]/[2]: per-GPU batch 64 of 3x8x112x112 video + 1x40x100 audio, 240k x 128 bank, 1024
+negatives, weak scaling (global batch 64*N).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on its launch stream
+inside the timed region) and, at N=1, `cpu_baseline` (the oracle's full step timed on the host cores).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "avid-cma_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FWD_GFLOP_PER_CLIP = 6.418      # 2*MAC of every conv + linear at the benchmark shapes
+STEP_GFLOP_PER_CLIP = 17.83     # fwd + bwd (3x fwd minus the two never-needed stem input gradients)
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(steps=12, warmup=1):
+    """BASELINE config 1 on the host cores with the oracle (a *port*, pinned to the reference by
+    tests/test_oracle_golden.py): bs=4, 1000-row bank, K=1024; full step incl. Adam."""
+    from oracle import avid_oracle as O
+    torch.manual_seed(1234)
+    bs, N, K = 4, 1000, 1024
+    st = O.OracleStep(num_data=N, num_negatives=K)
+    g = torch.Generator().manual_seed(1234)
+    video = torch.randn(bs, 3, 8, 112, 112, generator=g)
+    audio = torch.randn(bs, 1, 40, 100, generator=g)
+    times = []
+    for i in range(warmup + steps):
+        y = torch.randperm(N, generator=g)[:bs]
+        idx = torch.randint(0, N - 1, (bs, K), generator=g)
+        idx = idx + (idx >= y[:, None]).long()
+        t0 = time.perf_counter()
+        st.step(video, audio, y, idx)
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": round(bs / med, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"config1: bs=4 3x8x112x112+1x40x100, bank 1000x128, K=1024, fwd+NCE+bwd+Adam fp32, "
+                      f"median of {steps} steps ({sum(times):.1f} s CPU work), os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1]/[2]: 64)")
+    ap.add_argument("--bank", type=int, default=240000)
+    ap.add_argument("--negatives", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel HIP-event table (stderr)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import models
+    import criterions
+    from avid_hip import lib
+    from avid_hip.parallel import TrainStep
+
+    torch.manual_seed(0)
+    model = models.av_wrapper("R2Plus1D", {"depth": 18}, "Conv2D", {"depth": 10}, proj_dim=[512, 512, 128]).to(dev)
+    model.train()
+    crit = criterions.AVID(num_data=args.bank, embedding_dim=model.out_dim, num_negatives=args.negatives,
+                           momentum=0.5, xModal_coeff=1., wModal_coeff=0., device=local_rank)
+    engine = TrainStep(model, crit, lr=2e-4, weight_decay=1e-5)
+
+    bs = args.batch
+    g = torch.Generator().manual_seed(1234 + rank)
+    video = torch.randn(bs, 3, 8, 112, 112, generator=g).to(dev)
+    audio = torch.randn(bs, 1, 40, 100, generator=g).to(dev)
+    total = args.warmup + args.steps
+    gp = torch.Generator().manual_seed(99)                     # same permutation on every rank, sharded by rank
+    ids = torch.stack([torch.randperm(args.bank, generator=gp)[:bs * world] for _ in range(total)])
+    ids = ids[:, rank * bs:(rank + 1) * bs].contiguous().to(dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        engine.step(video, audio, ids[i])
+    sync()
+    lib.timing_enable(True)                                     # HIP events around every hot kernel launch
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(args.steps):
+        loss = engine.step(video, audio, ids[args.warmup + i])
+    sync()
+    dt = time.perf_counter() - t0
+    kern = lib.timing_report()
+    lib.timing_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_val = float(loss)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        clips = bs * world * args.steps / dt
+        mfma = {k: v for k, v in kern.items() if v["flops"] > 0 and ("igemm" in k or "wgrad_kernel" in k)}
+        dom = max(mfma, key=lambda k: mfma[k]["ms"])
+        d = mfma[dom]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        conv_ms = sum(v["ms"] for v in mfma.values()) / args.steps
+        conv_tf = sum(v["flops"] for v in mfma.values()) / (sum(v["ms"] for v in mfma.values()) * 1e-3) / 1e12
+        out = {
+            "metric": "clips/sec (video+audio fwd+bwd+NCE+Adam)",
+            "value": round(clips, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "AVID Cross-N1024 step: R(2+1)D-18 + Conv2D-10 + heads [512,512,128], "
+                                   "3x8x112x112 video + 1x40x100 audio",
+                       "per_gpu_batch": bs, "global_batch": bs * world, "bank_rows": args.bank,
+                       "negatives": args.negatives, "parallelism": f"dp{world}", "optimizer": "adam(2e-4, wd 1e-5)",
+                       "loss": round(loss_val, 5)},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": d["launches"] / args.steps,
+                         "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                         "all_conv_kernels": {"ms_per_step": round(conv_ms, 3), "achieved": round(conv_tf, 2),
+                                              "frac": round(conv_tf / PEAK_F32_MFMA_TFLOPS, 4)},
+                         "step_algorithmic": {"gflop_per_clip": STEP_GFLOP_PER_CLIP,
+                                              "achieved": round(clips / world * STEP_GFLOP_PER_CLIP / 1e3, 2),
+                                              "frac": round(clips / world * STEP_GFLOP_PER_CLIP / 1e3
+                                                            / PEAK_F32_MFMA_TFLOPS, 4)}},
+        }
+        if args.breakdown:
+            tot = sum(v["ms"] for v in kern.values())
+            print(f"{'kernel':34s} {'launch/step':>11s} {'ms/step':>9s} {'%':>6s} {'TFLOP/s':>9s} {'GB/s(alg)':>10s}",
+                  file=sys.stderr)
+            for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"]):
+                tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0.0
+                gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                print(f"{k:34s} {v['launches'] / args.steps:11.1f} {v['ms'] / args.steps:9.3f} "
+                      f"{100 * v['ms'] / tot:6.1f} {tf:9.2f} {gb:10.1f}", file=sys.stderr)
+            print(f"timed kernels {tot / args.steps:.3f} ms/step of {ms:.3f} ms wall", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

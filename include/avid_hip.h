@@ -43,6 +43,12 @@ int avid_version(void);
 /* CU count / LDS per CU / arch name of `device` ("gfx950" expected). */
 int avid_device_info(int device, int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
+/* Per-kernel timing with HIP events recorded on the launch stream.  enable(1) clears old records and
+ * starts bracketing every hot kernel launch with two events; report() synchronises them and writes
+ * one line per kernel: "name;launches;total_ms;algorithmic_flops;algorithmic_bytes\n". */
+int avid_timing_enable(int on);
+int avid_timing_report(char* buf, size_t len);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolution = implicit GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-fp32 numerics.
  * Replaces nn.Conv3d / nn.Conv2d / nn.Linear forward+backward:
@@ -67,6 +73,10 @@ int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const
 size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d);
 int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* addend,
                     float* dx, void* ws, size_t ws_bytes, avid_stream_t stream);
+
+/* Which kernel instantiation a descriptor dispatches to (which: 0 fwd, 1 dgrad, 2 wgrad), e.g.
+ * "igemm_kernel<4,1,1,2,1>" — lets bench.py attribute HIP-event timings to rocprofv3 kernel names. */
+int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* buf, int len);
 
 /* dw[Cout][kt][kh][kw][Cin] = sum_m dy[m][:]^T x_col[m][:]  (deterministic split-M + tree reduce). */
 size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d);

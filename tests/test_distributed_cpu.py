@@ -1,0 +1,114 @@
+"""World-size-2 gloo tests (CPU) of the multi-GPU path: bucketed overlapped gradient all-reduce over
+the flat gradient buffer, the fused bank-update all-gather, and _gather_from_all's rank order."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def run2(fn):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, fn, ret)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return dict(ret)
+
+
+def _tiny_model():
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                            torch.nn.Linear(16, 4))
+    return m
+
+
+def _grad_job(rank, world):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avid-cma_amd"))
+    from avid_hip.parallel import FlatParams, GradBuckets
+    m = _tiny_model()
+    flat = FlatParams(m)
+    buckets = GradBuckets(flat, bucket_bytes=256)          # tiny buckets -> several async all-reduces
+    assert len(buckets.bounds) >= 3
+    torch.manual_seed(100 + rank)
+    x = torch.randn(5, 8)
+    out = []
+    for _ in range(2):                                     # two steps: hooks re-arm
+        flat.zero_grad()
+        m(x).pow(2).sum().backward()
+        buckets.finish()
+        out.append(flat.grad.clone() / world)
+    return [o.numpy() for o in out], [p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o
+                                      for p, o in zip(flat.params, flat.offsets)]
+
+
+def test_bucketed_allreduce_equals_mean_of_rank_grads():
+    res = run2(_grad_job)
+    ref = []
+    for rank in range(2):
+        m = _tiny_model()
+        torch.manual_seed(100 + rank)
+        x = torch.randn(5, 8)
+        m(x).pow(2).sum().backward()
+        ref.append([p.grad.clone() for p in reversed(list(m.parameters()))])
+    for rank in range(2):
+        grads, seated = res[rank]
+        assert all(seated)
+        flat = torch.from_numpy(grads[0])
+        off = 0
+        for g0, g1 in zip(ref[0], ref[1]):
+            n = g0.numel()
+            torch.testing.assert_close(flat[off:off + n].view_as(g0), (g0 + g1) / 2, rtol=1e-6, atol=1e-7)
+            off += (n + 3) // 4 * 4
+        torch.testing.assert_close(torch.from_numpy(grads[1]), flat, rtol=1e-6, atol=1e-7)   # step 2 == step 1
+    torch.testing.assert_close(torch.from_numpy(res[0][0][0]), torch.from_numpy(res[1][0][0]))
+
+
+def _gather_job(rank, world):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avid-cma_amd"))
+    from criterions.avid import gather_update_records
+    from utils.distributed_utils import _gather_from_all
+    torch.manual_seed(rank)
+    v, a = torch.randn(3, 128), torch.randn(3, 128)
+    y = torch.tensor([10 + rank, 2 ** 40 + rank, 7], dtype=torch.int64)      # ids beyond 2^32 survive the bit-cast
+    va, aa, ya = gather_update_records(v, a, y)
+    g = _gather_from_all(torch.full((2, 2), float(rank)))
+    return va.numpy(), aa.numpy(), ya.numpy(), g.numpy()
+
+
+def test_fused_bank_allgather_and_rank_order():
+    res = run2(_gather_job)
+    vs, as_, ys = [], [], []
+    for rank in range(2):
+        torch.manual_seed(rank)
+        vs.append(torch.randn(3, 128)); as_.append(torch.randn(3, 128))
+        ys.append(torch.tensor([10 + rank, 2 ** 40 + rank, 7], dtype=torch.int64))
+    for rank in range(2):
+        va, aa, ya, g = res[rank]
+        assert (torch.from_numpy(va) == torch.cat(vs)).all() and (torch.from_numpy(aa) == torch.cat(as_)).all()
+        assert ya.tolist() == torch.cat(ys).tolist()
+        assert g.tolist() == [[0, 0], [0, 0], [1, 1], [1, 1]]
