@@ -76,7 +76,8 @@ SIGNATURES = {
     "avid_colsum": (_i, [_i64, _i, _vp, _vp, _vp]),
     "avid_l2norm_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "avid_l2norm_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "avid_alias_draw": (_i, [_i64, _i64, _vp, _vp, _i, _u64, _u64, _vp, _i64, _vp, _vp]),
+    "avid_alias_draw": (_i, [_i64, _i64, _vp, _vp, _i, _u64, _u64, _vp, _vp, _i64, _vp, _vp]),
+    "avid_counter_add": (_i, [_vp, _u64, _vp]),
     "avid_bank_scores_fwd": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "avid_bank_scores_bwd": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
     "avid_mean_exp": (_i, [_i, _i, _i, _vp, _vp, _vp]),
@@ -86,7 +87,7 @@ SIGNATURES = {
     "avid_cma_negatives": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avid_cma_topk_workspace_bytes": (_sz, [_i64, _i, _i]),
     "avid_cma_topk": (_i, [_i64, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "avid_adam_flat": (_i, [_i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i64, _f, _vp]),
+    "avid_adam_flat": (_i, [_i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i64, _vp, _f, _vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

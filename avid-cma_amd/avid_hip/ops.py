@@ -366,13 +366,18 @@ def nce_loss(spos, sneg, Z):
     return _NCELoss.apply(spos, sneg, Z)
 
 
-def alias_draw(n, K, prob, alias, uniform, seed, offset, y=None, per_row=1, device=None):
+def alias_draw(n, K, prob, alias, uniform, seed, offset, y=None, per_row=1, device=None, offset_dev=None):
+    """``offset_dev`` (optional 0-d int64 device tensor): the draw counter is read from it and advanced
+    on the stream — required for hipGraph replay, where by-value arguments are frozen."""
     device = device if device is not None else (y.device if y is not None else prob.device)
     if device.type != "cuda":
         raise AvidHipError("alias_draw: HIP device required")
     out = torch.empty(n, dtype=torch.int64, device=device)
-    lib.call("avid_alias_draw", n, K, _p(prob), _p(alias), int(uniform), int(seed), int(offset), _p(y), int(per_row),
-             _p(out), _stream())
+    st = _stream()
+    lib.call("avid_alias_draw", n, K, _p(prob), _p(alias), int(uniform), int(seed), int(offset), _p(offset_dev),
+             _p(y), int(per_row), _p(out), st)
+    if offset_dev is not None:
+        lib.call("avid_counter_add", _p(offset_dev), 1, st)
     return out
 
 
@@ -393,7 +398,12 @@ def cma_negatives(positive_set, y, rand_idx):
     return pos, neg
 
 
-def adam_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+def adam_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, step_dev=None):
+    """``step_dev`` (optional 0-d int64 device tensor): advanced by one on the stream, then read by the
+    kernel for the bias corrections (hipGraph-replay safe); otherwise ``step`` is used by value."""
     _need_cuda(p, g, m, v)
+    st = _stream()
+    if step_dev is not None:
+        lib.call("avid_counter_add", _p(step_dev), 1, st)
     lib.call("avid_adam_flat", p.numel(), _p(p), _p(g), _p(m), _p(v), float(lr), float(beta1), float(beta2),
-             float(eps), float(wd), int(step), float(grad_scale), _stream())
+             float(eps), float(wd), int(step), _p(step_dev), float(grad_scale), st)

@@ -123,6 +123,9 @@ class TrainStep:
         self.m = torch.zeros_like(self.flat.flat)
         self.v = torch.zeros_like(self.flat.flat)
         self.t = 0
+        self.t_dev = torch.zeros((), dtype=torch.int64, device=self.flat.flat.device) \
+            if self.flat.flat.is_cuda else None
+        self.graph = None
 
     def forward_backward(self, video, audio, index):
         self.flat.zero_grad()
@@ -136,9 +139,31 @@ class TrainStep:
         from . import ops
         self.t += 1
         ops.adam_flat(self.flat.flat, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.wd, self.t, grad_scale=1.0 / self.buckets.world)
+                      self.eps, self.wd, self.t, grad_scale=1.0 / self.buckets.world, step_dev=self.t_dev)
 
     def step(self, video, audio, index):
         loss = self.forward_backward(video, audio, index)
         self.optimizer_step()
         return loss.detach()
+
+    # ---- whole-step hipGraph: ~600 launches replayed with one host call (kills the Python launch overhead)
+    def capture(self, video, audio, index):
+        """Capture one full step into a hipGraph.  Call after >= 2 eager warm-up steps (Z fixed, workspaces
+        sized).  Inputs are copied into static buffers on every ``replay``."""
+        self._sv, self._sa, self._si = video.clone(), audio.clone(), index.clone()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._sloss = self.step(self._sv, self._sa, self._si)
+        return self
+
+    def replay(self, video=None, audio=None, index=None):
+        if video is not None and video.data_ptr() != self._sv.data_ptr():
+            self._sv.copy_(video, non_blocking=True)
+        if audio is not None and audio.data_ptr() != self._sa.data_ptr():
+            self._sa.copy_(audio, non_blocking=True)
+        if index is not None:
+            self._si.copy_(index, non_blocking=True)
+        self.graph.replay()
+        self.t += 1
+        return self._sloss

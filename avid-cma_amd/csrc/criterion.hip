@@ -59,9 +59,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   r1 = c1;
 }
 
+__global__ void counter_add_kernel(unsigned long long* ctr, unsigned long long inc) { *ctr += inc; }
+
 __global__ void alias_draw_kernel(long long n, long long K, const float* __restrict__ prob,
                                   const long long* __restrict__ alias, int uniform, uint64_t seed, uint64_t offset,
+                                  const unsigned long long* __restrict__ offset_dev,
                                   const long long* __restrict__ y, long long per_row, long long* __restrict__ out) {
+  if (offset_dev) offset = *offset_dev;  // graph-replay safe: the draw counter lives in device memory
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     uint32_t r0, r1;
@@ -311,16 +315,24 @@ extern "C" int avid_l2norm_bwd(int bs, int D, const float* y, const float* norm,
   return check_launch("l2norm_bwd");
 }
 
+extern "C" int avid_counter_add(uint64_t* counter, uint64_t inc, avid_stream_t stream) {
+  AVID_REQUIRE(counter, AVID_E_BADARG, "counter_add: null pointer");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)counter,
+                     (unsigned long long)inc);
+  return check_launch("counter_add");
+}
+
 extern "C" int avid_alias_draw(int64_t n, int64_t K, const float* prob, const int64_t* alias, int uniform,
-                               uint64_t seed, uint64_t offset, const int64_t* y, int64_t per_row, int64_t* out,
-                               avid_stream_t stream) {
+                               uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const int64_t* y,
+                               int64_t per_row, int64_t* out, avid_stream_t stream) {
   AVID_REQUIRE(n > 0 && K > 0 && K < (1ll << 32) && out, AVID_E_BADARG, "alias_draw: bad argument");
   AVID_REQUIRE(uniform || (prob && alias), AVID_E_BADARG, "alias_draw: tables missing");
   AVID_REQUIRE(!y || per_row > 0, AVID_E_BADARG, "alias_draw: per_row must be > 0 with y");
   long long g = ceil_div(n, 256);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(alias_draw_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (long long)n,
-                     (long long)K, prob, (const long long*)alias, uniform, seed, offset, (const long long*)y,
+                     (long long)K, prob, (const long long*)alias, uniform, seed, offset,
+                     (const unsigned long long*)offset_dev, (const long long*)y,
                      (long long)(per_row > 0 ? per_row : 1), (long long*)out);
   return check_launch("alias_draw");
 }

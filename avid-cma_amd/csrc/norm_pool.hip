@@ -66,19 +66,43 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// one thread per channel: combine partials in fp64, emit mean / invstd / scale / shift, update running stats
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, long long M, int C,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                   float eps, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                   float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0, ss = 0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)part[(long long)b * 2 * C + c];
-    ss += (double)part[(long long)b * 2 * C + C + c];
-  }
+// Combine the per-block partials in fp64.  Block = 64 channels x 16 slices of the partial list (a single
+// thread per channel walking <= 1024 partials serially cost ~100 us per BN layer); LDS tree over slices.
+constexpr int FIN_SLICES = 16;
+
+__device__ __forceinline__ void finalize_sums(const float* __restrict__ part, int nblk, int C, int c, int slice,
+                                              double (*sh)[2][64], double& s0, double& s1) {
+  double a = 0, b = 0;
+  if (c < C)
+    for (int k = slice; k < nblk; k += FIN_SLICES) {
+      a += (double)part[(long long)k * 2 * C + c];
+      b += (double)part[(long long)k * 2 * C + C + c];
+    }
+  sh[slice][0][threadIdx.x & 63] = a;
+  sh[slice][1][threadIdx.x & 63] = b;
+  __syncthreads();
+  s0 = 0;
+  s1 = 0;
+  if (slice == 0)
+    for (int k = 0; k < FIN_SLICES; ++k) {
+      s0 += sh[k][0][threadIdx.x & 63];
+      s1 += sh[k][1][threadIdx.x & 63];
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nblk, long long M, int C,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float momentum, float eps,
+                                                           float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd, float* __restrict__ scale,
+                                                           float* __restrict__ shift) {
+  __shared__ double sh[FIN_SLICES][2][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  double s, ss;
+  finalize_sums(part, nblk, C, c, slice, sh, s, ss);
+  if (slice != 0 || c >= C) return;
   const double mean = s / (double)M;
   double var = ss / (double)M - mean * mean;
   if (var < 0) var = 0;
@@ -193,16 +217,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, long long M, int C,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ k1,
-                                       float* __restrict__ k2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0, sx = 0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)part[(long long)b * 2 * C + c];
-    sx += (double)part[(long long)b * 2 * C + C + c];
-  }
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, long long M,
+                                                               int C, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ k1,
+                                                               float* __restrict__ k2) {
+  __shared__ double sh[FIN_SLICES][2][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  double s, sx;
+  finalize_sums(part, nblk, C, c, slice, sh, s, sx);
+  if (slice != 0 || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)sx;
   k1[c] = (float)(s / (double)M);
@@ -415,7 +438,7 @@ extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* 
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
                        p.rows_per_pass, p.rows_per_block);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64), 0, s, part, p.nblk, (long long)M,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64 * FIN_SLICES), 0, s, part, p.nblk, (long long)M,
                      C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
   const long long n4 = (long long)M * p.G;
   {
@@ -456,7 +479,7 @@ extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* y, con
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, y, dy, save_mean, save_invstd, part,
                        (long long)M, C, p.G, p.rows_per_pass, p.rows_per_block, relu);
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64), 0, s, part, p.nblk,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64 * FIN_SLICES), 0, s, part, p.nblk,
                      (long long)M, C, dgamma, dbeta, k1, k2);
   const long long n4 = (long long)M * p.G;
   {

@@ -41,10 +41,13 @@ class AliasMethod(object):
             self.alias = torch.from_numpy(alias)
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self.offset = 0
+        self.offset_dev = None      # device-resident draw counter (created by .to(cuda)); hipGraph-replay safe
 
     def to(self, device):
         self.prob = self.prob.to(device)
         self.alias = self.alias.to(device)
+        if self.prob.is_cuda:
+            self.offset_dev = torch.full((), self.offset, dtype=torch.int64, device=self.prob.device)
 
     def cuda(self, device=None):          # reference-era call sites use .cuda()
         self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
@@ -58,6 +61,11 @@ class AliasMethod(object):
         from avid_hip import ops
         K = self.alias.size(0)
         out = ops.alias_draw(int(N), K, self.prob, self.alias, self.uniform, self.seed, self.offset, y, per_row,
-                             device=self.prob.device)
+                             device=self.prob.device, offset_dev=self.offset_dev)
         self.offset += 1
         return out
+
+    def reseed(self, seed, offset=0):
+        self.seed, self.offset = int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset)
+        if self.offset_dev is not None:
+            self.offset_dev.fill_(self.offset)

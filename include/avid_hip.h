@@ -134,10 +134,14 @@ int avid_l2norm_bwd(int bs, int D, const float* y, const float* norm, const floa
 /* AliasMethod.draw + "avoid self" — utils/alias_method.py:56-71, criterions/avid.py:82-86.
  * out[i] = alias_select(prob, alias, kk_i, u_i) with (kk_i, u_i) from Philox4x32-10
  * (counter = (i, offset), key = seed); if y != NULL: out[i] += (out[i] >= y[i / per_row]).
- * uniform != 0 short-circuits the table lookup for the all-ones table (prob == 1, alias == 0). */
+ * uniform != 0 short-circuits the table lookup for the all-ones table (prob == 1, alias == 0).
+ * offset_dev != NULL: the offset is read from device memory instead of the by-value argument. */
 int avid_alias_draw(int64_t n, int64_t K, const float* prob, const int64_t* alias, int uniform,
-                    uint64_t seed, uint64_t offset, const int64_t* y, int64_t per_row,
-                    int64_t* out, avid_stream_t stream);
+                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const int64_t* y,
+                    int64_t per_row, int64_t* out, avid_stream_t stream);
+/* *counter += inc on the stream.  offset_dev (above) / step_dev (avid_adam_flat) point at such device
+ * counters so a captured hipGraph of the whole step advances its RNG stream / Adam step on replay. */
+int avid_counter_add(uint64_t* counter, uint64_t inc, avid_stream_t stream);
 
 /* scores[b][j] = <bank[idx[b][j]], emb[b]> * inv_T — the gather + bmm of criterions/avid.py:57-71.
  * idx [bs][R] int64, bank [N][D], emb [bs][D], D in {64,128,256,512}.  rows_out (nullable,
@@ -188,8 +192,8 @@ int avid_cma_topk(int64_t N, int D, const float* view1, const float* view2, int6
  * over one flat fp32 buffer — utils/main_utils.py:250-261.
  * ---------------------------------------------------------------------------------------------- */
 int avid_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
-                   avid_stream_t stream);
+                   float beta2, float eps, float weight_decay, int64_t step, const int64_t* step_dev,
+                   float grad_scale, avid_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -302,7 +302,7 @@ def test_properties_at_baseline_batch(gpu_device):
         gg = torch.Generator().manual_seed(7)
         crit.nce_average.view1_mem.copy_(torch.nn.functional.normalize(torch.randn(240000, 128, generator=gg), dim=1))
         crit.nce_average.view2_mem.copy_(torch.nn.functional.normalize(torch.randn(240000, 128, generator=gg), dim=1))
-        crit.nce_average.multinomial.seed, crit.nce_average.multinomial.offset = 42, 0
+        crit.nce_average.multinomial.reseed(42, 0)
         y = torch.randperm(240000, generator=gg)[:bs].to(gpu_device)
         e1, e2 = mm(video, audio)
         loss, _ = crit(e1, e2, y)
@@ -319,3 +319,37 @@ def test_properties_at_baseline_batch(gpu_device):
     y = ops.batch_norm_cl(x.view(bs, 8, 28, 28, 64), one, zero, zero.clone(), one.clone(), True, 0.1, 1e-5, False)
     y = y.view(-1, 64)
     assert float(y.mean(0).abs().max()) < 1e-4 and float((y.var(0, unbiased=False) - 1).abs().max()) < 1e-3
+
+
+def test_graph_replay_equals_eager(gpu_device):
+    """A captured hipGraph of the whole step (TrainStep.capture/replay) advances the alias RNG stream and
+    the Adam step on the device and reproduces the eager steps bit for bit."""
+    import criterions
+    from avid_hip.parallel import TrainStep
+    bs, N, K = 4, 5000, 256
+
+    def make():
+        torch.manual_seed(0)
+        m = _build_model(gpu_device).train()
+        crit = criterions.AVID(num_data=N, embedding_dim=128, num_negatives=K, momentum=0.5, device=gpu_device.index)
+        gg = torch.Generator().manual_seed(3)
+        crit.nce_average.view1_mem.copy_(torch.nn.functional.normalize(torch.randn(N, 128, generator=gg), dim=1))
+        crit.nce_average.view2_mem.copy_(torch.nn.functional.normalize(torch.randn(N, 128, generator=gg), dim=1))
+        crit.nce_average.multinomial.reseed(11, 0)
+        return m, crit, TrainStep(m, crit)
+
+    g = torch.Generator().manual_seed(5)
+    video = torch.randn(bs, 3, 8, 64, 64, generator=g).to(gpu_device)
+    audio = torch.randn(bs, 1, 40, 100, generator=g).to(gpu_device)
+    ids = torch.stack([torch.randperm(N, generator=g)[:bs] for _ in range(6)]).to(gpu_device)
+
+    m1, c1, e1 = make()
+    eager = [float(e1.step(video, audio, ids[i])) for i in range(6)]
+    m2, c2, e2 = make()
+    got = [float(e2.step(video, audio, ids[i])) for i in range(3)]
+    e2.capture(video, audio, ids[3])                 # the capture itself executes nothing
+    got += [float(e2.replay(index=ids[i])) for i in range(3, 6)]
+    assert got == eager, (got, eager)
+    assert torch.equal(m1.video_model.conv1[0].weight, m2.video_model.conv1[0].weight)
+    assert torch.equal(c1.nce_average.view1_mem, c2.nce_average.view1_mem)
+    assert int(e2.t_dev) == 6 and int(c2.nce_average.multinomial.offset_dev) == 6

@@ -351,9 +351,14 @@ def test_adam_flat(gpu_device):
     opt = torch.optim.Adam([ref], lr=2e-4, weight_decay=1e-5)
     pd = p.to(gpu_device)
     m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    pd2, m2, v2 = pd.clone(), torch.zeros_like(pd), torch.zeros_like(pd)      # device-resident step counter path
+    t_dev = torch.zeros((), dtype=torch.int64, device=gpu_device)
     for step in range(1, 4):
         g = T(detgen.det_normalish(f"adam:g{step}", (n,)))
         ref.grad = g.clone()
         opt.step()
         ops.adam_flat(pd, g.to(gpu_device), m, v, 2e-4, 0.9, 0.999, 1e-8, 1e-5, step)
+        ops.adam_flat(pd2, g.to(gpu_device), m2, v2, 2e-4, 0.9, 0.999, 1e-8, 1e-5, 0, step_dev=t_dev)
     np.testing.assert_allclose(pd.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
+    assert int(t_dev) == 3
+    np.testing.assert_allclose(pd2.cpu().numpy(), pd.cpu().numpy(), rtol=1e-6, atol=1e-7)
