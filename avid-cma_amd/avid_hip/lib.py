@@ -58,7 +58,8 @@ SIGNATURES = {
     "avid_device_info": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "avid_timing_enable": (_i, [_i]),
     "avid_timing_report": (_i, [C.c_char_p, _sz]),
-    "avid_conv_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "avid_conv_fwd_workspace_bytes": (_sz, [_dp]),
+    "avid_conv_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "avid_conv_dgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_conv_wgrad_workspace_bytes": (_sz, [_dp]),

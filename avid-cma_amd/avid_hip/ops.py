@@ -102,7 +102,10 @@ class _ConvCL(Function):
         y = torch.empty((B, d.To, d.Ho, d.Wo, cout), dtype=torch.float32, device=x.device)
         if addend is not None and (addend.shape != y.shape or not addend.is_contiguous()):
             raise AvidHipError("conv: addend must be a contiguous tensor of the output shape")
-        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(addend), _p(bias), int(relu), _p(y), _stream())
+        nb = lib.raw("avid_conv_fwd_workspace_bytes")(C.byref(d))
+        ws = workspace(x.device, nb) if nb else None
+        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(addend), _p(bias), int(relu), _p(y), _p(ws),
+                 ws.numel() if ws is not None else 0, _stream())
         ctx.d, ctx.relu, ctx.channel_first = d, relu, channel_first
         ctx.has_addend, ctx.has_bias = addend is not None, bias is not None
         ctx.save_for_backward(x, w, y if relu else None)

@@ -1,7 +1,7 @@
 // Implicit-GEMM convolution for gfx950 on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
 //
-//   forward : y[m][n]  = sum_{tap,c} x[pix(m,tap)][c] * w[n][tap][c]           (mode 0)
-//   dgrad   : dx[m][c] = sum_{tap,n} dy[pixT(m,tap)][n] * wT[c][tap][n]        (mode 1, wT = repacked w)
+//   forward : y[m][n]  = sum_{tap,c} x[pix(m,tap)][c] * w[n][tap][c]           (MODE 0)
+//   dgrad   : dx[m][c] = sum_{tap,n} dy[pixT(m,tap)][n] * wT[c][tap][n]        (MODE 1, wT = repacked w)
 //   wgrad   : dw[n][tap][c] = sum_m dy[m][n] * x[pix(m,tap)][c]                (split over m, tree-reduced)
 //
 // Activations are channels-last, so a GEMM-A row is 32 contiguous floats of one (possibly padded)
@@ -9,18 +9,30 @@
 // MFMA fragment reads are conflict-free ds_read_b128.  The MFMA k-index is free to permute as long
 // as A and B agree, so lane-half h consumes k = 8g + 4h + s: one b128 read feeds four MFMAs.
 //
+// Staging uses buffer loads: a padded / out-of-image row gets a voffset past num_records and the
+// hardware returns zeros — no select on the loaded data, so the loads of tile k+1 stay in flight
+// under the 32..64 MFMAs of tile k (register prefetch, double-buffered LDS, one barrier per tile).
+// The per-row tap validity is a 27-bit mask computed once per workgroup; the loader is straight-line.
+//
+// Small-M layers (conv4x/conv5x, audio, heads) keep the big tile and split GEMM-K across workgroups
+// (grid.y), summing the fp32 partial slabs in a fixed order in a reduce kernel that also applies the
+// epilogue (deterministic; no atomics).
+//
 // Reference ops replaced: nn.Conv3d/Conv2d/Linear fwd+bwd — models/video.py:20,
 // models/network_blocks.py:18,20,35,37,40,42,49, models/audio.py:22, models/av_wrapper.py:25.
 #include "common.h"
 
 namespace avid {
 
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+
 struct ConvArgs {
-  const float* __restrict__ src;     // [B,Ts,Hs,Ws,Cs] channels-last (VEC) or strided (scalar)
+  const float* __restrict__ src;     // [B,Ts,Hs,Ws,Cs] channels-last (vector path) or strided (gather path)
   const float* __restrict__ wk;      // [Cd][ntaps][Cs]
   const float* __restrict__ addend;  // [M][Cd] or null
   const float* __restrict__ bias;    // [Cd] or null
   float* __restrict__ dst;           // [M][Cd]
+  float* __restrict__ part;          // split-K partial slabs [nsplit][M][Cd] (nsplit > 1)
   int B, Ts, Hs, Ws, Cs;
   int Td, Hd, Wd, Cd;
   int kt, kh, kw;
@@ -29,12 +41,14 @@ struct ConvArgs {
   int M;      // B*Td*Hd*Wd
   int mode;   // 0: s = d*stride - pad + tap ;  1: s = (d + pad - tap) / stride (exact)
   int relu;
-  long long ssB, ssT, ssH, ssW, ssC;  // scalar-gather source strides (elements)
+  int nsplit, ksteps_per_split;
+  long long ssB, ssT, ssH, ssW, ssC;  // gather-path source strides (elements)
 };
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;  // padded LDS row (floats): 144 B => b128 fragment reads conflict-free
 constexpr int KTAB_MAX = 512;
+constexpr unsigned OOB = 0x80000000u;  // voffset beyond any num_records (< 2 GiB): buffer load returns 0
 
 __device__ __forceinline__ void decode_row(int m, int M, int Wd, int Hd, int Td, int& b, int& td, int& hd,
                                            int& wd, bool& ok) {
@@ -48,37 +62,69 @@ __device__ __forceinline__ void decode_row(int m, int M, int Wd, int Hd, int Td,
   b = r / Td;
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC>
-__global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs p) {
+__device__ __forceinline__ floatx4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  return __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vector path (Cs % 32 == 0, channels-last source): all layers except the two stems.
+//
+// Ping-pong schedule.  A workgroup is 8 waves = two independent groups of 4 waves, each owning its own
+// BM x BN output tile (consecutive M-tiles) and its own single-buffered LDS stage.  The groups run
+// the same loop shifted by one phase:
+//     phase A : ds_read fragments + 32..64 MFMAs of tile k          (matrix pipe)
+//     phase B : ds_write tile k+1 (prefetched in registers), issue buffer loads of tile k+2
+// so on every SIMD exactly one wave is in its MFMA phase while its partner stages — the matrix pipe
+// stays busy without relying on two co-resident workgroups happening to drift out of phase
+// (measured before: both in phase => pipe 52 % busy, SQ_WAIT_INST_ANY 60 %).
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int PA = BM / 32, PB = BN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                  // [2][BM][LDK]
-  float* Bs = smem + 2 * BM * LDK;   // [2][BN][LDK]
-  int2* ktab = reinterpret_cast<int2*>(smem + 2 * (BM + BN) * LDK);  // scalar mode only
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);   // wave-uniform by construction
+  float* As = smem + grp * (BM + BN) * LDK;   // [BM][LDK]
+  float* Bs = As + BM * LDK;                  // [BN][LDK]
   const int wm = wave / WN, wn = wave % WN;
   const int lrow = tid >> 3, lcol = (tid & 7) * 4;
 
   // XCD-aware tile order: consecutive M-tiles (which share input halos) stay on one XCD's L2.
-  const unsigned ntm = (p.M + BM - 1) / BM, ntn = p.Cd / BN;
-  const unsigned tile = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const unsigned ntm = (p.M + BM - 1) / BM, ntm2 = (ntm + 1) / 2, ntn = p.Cd / BN, ntiles = ntm2 * ntn;
+  const unsigned lin = xcd_remap(blockIdx.x, ntiles * p.nsplit);
+  const unsigned split = lin / ntiles, tile = lin - split * ntiles;
+  const int m0 = ((tile / ntn) * 2 + grp) * BM, n0 = (tile % ntn) * BN;
 
   const int ntaps = p.kt * p.kh * p.kw;
-  const int K = ntaps * p.Cs;
-  const int nk = VEC ? ntaps * (p.Cs / BK) : (K + BK - 1) / BK;
+  const int cpt = p.Cs / BK;
+  const int nk_total = ntaps * cpt;
+  const int ks0 = split * p.ksteps_per_split;
+  const int ks1 = min(ks0 + p.ksteps_per_split, nk_total);
 
-  // ---- per-thread row bookkeeping for the A loader (rows are fixed for the whole K loop)
+  // Buffer descriptors.  A: based at the first batch item this group touches, so 32-bit byte
+  // offsets are enough for any tensor size.  B: the (small) weight tensor.
+  const int pix_per_b = p.Ts * p.Hs * p.Ws;
+  int b_lo = m0 / (p.Td * p.Hd * p.Wd);
+  if (b_lo >= p.B) b_lo = p.B - 1;            // group past the end of M: every row is masked anyway
+  const long long a_base = (long long)b_lo * pix_per_b * p.Cs;
+  long long a_bytes = ((long long)p.B * pix_per_b * p.Cs - a_base) * 4;
+  if (a_bytes > 0x7fffffffll) a_bytes = 0x7fffffffll;
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + a_base), 0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.wk, 0, (int)((long long)p.Cd * ntaps * p.Cs * 4), 0x00020000);
+
+  // ---- per-thread row bookkeeping (rows are fixed for the whole K loop)
   int a_t0[PA], a_h0[PA], a_w0[PA];
-  long long a_base[PA];
+  unsigned a_off[PA], a_mask[PA];
+  const int cs4 = p.Cs * 4;
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     int b, td, hd, wd;
     bool ok;
     decode_row(m0 + lrow + 32 * i, p.M, p.Wd, p.Hd, p.Td, b, td, hd, wd, ok);
-    if (p.mode == 0) {
+    if (MODE == 0) {
       a_t0[i] = td * p.st - p.pt;
       a_h0[i] = hd * p.sh - p.ph;
       a_w0[i] = wd * p.sw - p.pw;
@@ -87,105 +133,244 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs p) {
       a_h0[i] = hd + p.ph;
       a_w0[i] = wd + p.pw;
     }
-    if (!ok) a_t0[i] = -(1 << 28);
-    if (VEC)
-      a_base[i] = (long long)b * p.Ts * p.Hs * p.Ws;  // pixel index of (b,0,0,0)
-    else
-      a_base[i] = (long long)b * p.ssB + (long long)a_t0[i] * p.ssT + (long long)a_h0[i] * p.ssH +
-                  (long long)a_w0[i] * p.ssW;
-  }
-
-  if (!VEC) {
-    for (int k = tid; k < nk * BK; k += 256) {
-      int2 e;
-      if (k < K) {
-        int tap = k / p.Cs, c = k - tap * p.Cs;
-        int dw = tap % p.kw, r = tap / p.kw;
-        int dh = r % p.kh, dt = r / p.kh;
-        e.x = (int)(dt * p.ssT + dh * p.ssH + dw * p.ssW + c * p.ssC);
-        e.y = dt | (dh << 8) | (dw << 16);
-      } else {
-        e.x = 0;
-        e.y = -1;
-      }
-      ktab[k] = e;
+    // per-dimension tap validity (bit d set <=> tap offset d lands inside the source along that axis)
+    unsigned mt = 0, mh = 0, mw = 0;
+    for (int dt = 0; dt < p.kt; ++dt) {
+      int ts = MODE == 0 ? a_t0[i] + dt : a_t0[i] - dt;
+      bool v = ts >= 0;
+      if (MODE == 1) { v &= (ts & (p.st - 1)) == 0; ts >>= (p.st - 1); }
+      mt |= ((v & (ts < p.Ts)) ? 1u : 0u) << dt;
     }
-    __syncthreads();
+    for (int dh = 0; dh < p.kh; ++dh) {
+      int hs = MODE == 0 ? a_h0[i] + dh : a_h0[i] - dh;
+      bool v = hs >= 0;
+      if (MODE == 1) { v &= (hs & (p.sh - 1)) == 0; hs >>= (p.sh - 1); }
+      mh |= ((v & (hs < p.Hs)) ? 1u : 0u) << dh;
+    }
+    for (int dw = 0; dw < p.kw; ++dw) {
+      int ws = MODE == 0 ? a_w0[i] + dw : a_w0[i] - dw;
+      bool v = ws >= 0;
+      if (MODE == 1) { v &= (ws & (p.sw - 1)) == 0; ws >>= (p.sw - 1); }
+      mw |= ((v & (ws < p.Ws)) ? 1u : 0u) << dw;
+    }
+    a_mask[i] = ok ? (mt | (mh << 8) | (mw << 16)) : 0u;
+    if (MODE == 0)  // pixel offset of tap (0,0,0); taps add a uniform offset
+      a_off[i] = (unsigned)((((b - b_lo) * p.Ts + a_t0[i]) * p.Hs + a_h0[i]) * p.Ws + a_w0[i]) * cs4 + lcol * 4;
+    else
+      a_off[i] = (unsigned)((b - b_lo) * pix_per_b) * cs4 + lcol * 4;
   }
+  unsigned b_off[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + 32 * i) * ntaps * p.Cs + lcol) * 4;
 
   floatx4 va[PA], vb[PB];
 
   auto load_tile = [&](int ks) {
-    if (VEC) {
-      const int cpt = p.Cs / BK;
-      const int tap = ks / cpt, c0 = (ks - tap * cpt) * BK;
-      const int dw = tap % p.kw, r = tap / p.kw;
-      const int dh = r % p.kh, dt = r / p.kh;
+    const int tap = ks / cpt, c0 = (ks - tap * cpt) * BK;
+    const int dw = tap % p.kw, r = tap / p.kw;
+    const int dh = r % p.kh, dt = r / p.kh;
+    const unsigned tap_off = (MODE == 0 ? (unsigned)(((dt * p.Hs + dh) * p.Ws + dw) * cs4) : 0u) + c0 * 4;
 #pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        int ts, hs, ws;
-        bool ok;
-        if (p.mode == 0) {
-          ts = a_t0[i] + dt;
-          hs = a_h0[i] + dh;
-          ws = a_w0[i] + dw;
-          ok = true;
-        } else {
-          ts = a_t0[i] - dt;
-          hs = a_h0[i] - dh;
-          ws = a_w0[i] - dw;
-          ok = (ts >= 0) & (hs >= 0) & (ws >= 0);
-          if (p.st == 2) { ok &= !(ts & 1); ts >>= 1; }
-          if (p.sh == 2) { ok &= !(hs & 1); hs >>= 1; }
-          if (p.sw == 2) { ok &= !(ws & 1); ws >>= 1; }
-        }
-        ok &= ((unsigned)ts < (unsigned)p.Ts) & ((unsigned)hs < (unsigned)p.Hs) & ((unsigned)ws < (unsigned)p.Ws);
-        long long pix = a_base[i] + ((long long)ts * p.Hs + hs) * p.Ws + ws;
-        pix = ok ? pix : 0;  // clamp: the load below is unconditional (branch-free), never out of bounds
-        const floatx4 v = *reinterpret_cast<const floatx4*>(p.src + pix * p.Cs + c0 + lcol);
-        const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-        va[i] = ok ? v : z;
+    for (int i = 0; i < PA; ++i) {
+      unsigned off;
+      if (MODE == 0) {
+        off = a_off[i] + tap_off;
+      } else {
+        const int ts = (a_t0[i] - dt) >> (p.st - 1), hs = (a_h0[i] - dh) >> (p.sh - 1),
+                  ws = (a_w0[i] - dw) >> (p.sw - 1);
+        off = a_off[i] + (unsigned)((ts * p.Hs + hs) * p.Ws + ws) * cs4 + tap_off;
       }
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const int n = n0 + lrow + 32 * i;
-        const floatx4* ptr =
-            reinterpret_cast<const floatx4*>(p.wk + ((long long)n * ntaps + tap) * p.Cs + c0 + lcol);
-        vb[i] = *ptr;  // Cd % BN == 0 is enforced on the host
-      }
-    } else {
-      const int kb = ks * BK + lcol;
-      int2 e[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) e[j] = ktab[kb + j];
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        floatx4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int dt = e[j].y & 0xff, dh = (e[j].y >> 8) & 0xff, dw = (e[j].y >> 16) & 0xff;
-          const int ts = a_t0[i] + dt, hs = a_h0[i] + dh, ws = a_w0[i] + dw;
-          const bool ok = (e[j].y >= 0) & ((unsigned)ts < (unsigned)p.Ts) & ((unsigned)hs < (unsigned)p.Hs) &
-                          ((unsigned)ws < (unsigned)p.Ws);
-          const float t = p.src[ok ? a_base[i] + e[j].x : 0];
-          v[j] = ok ? t : 0.f;
-        }
-        va[i] = v;
-      }
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const int n = n0 + lrow + 32 * i;
-        floatx4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float t = p.wk[(kb + j < K) ? (long long)n * K + kb + j : 0];
-          v[j] = (kb + j < K) ? t : 0.f;
-        }
-        vb[i] = v;
-      }
+      const unsigned okb = (a_mask[i] >> dt) & (a_mask[i] >> (8 + dh)) & (a_mask[i] >> (16 + dw)) & 1u;
+      off = okb ? off : OOB;
+      va[i] = buf_load4(rsA, off);
     }
+    const unsigned wtap = (unsigned)(tap * p.Cs + c0) * 4;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) vb[i] = buf_load4(rsB, b_off[i] + wtap);
   };
 
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<floatx4*>(&As[(lrow + 32 * i) * LDK + lcol]) = va[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) *reinterpret_cast<floatx4*>(&Bs[(lrow + 32 * i) * LDK + lcol]) = vb[i];
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int h = lane >> 5, l31 = lane & 31;
+  const float* Ab = As + (wm * TM * 32 + l31) * LDK + h * 4;
+  const float* Bb = Bs + (wn * TN * 32 + l31) * LDK + h * 4;
+
+  // prologue: tile ks0 -> LDS, tile ks0+1 -> registers
+  load_tile(ks0);
+  store_tile();
+  if (ks0 + 1 < ks1) load_tile(ks0 + 1);
+  __syncthreads();
+  if (grp == 1) __syncthreads();   // shift group 1 by one phase
+
+  for (int ks = ks0; ks < ks1; ++ks) {
+    // ---- phase A: matrix pipe
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      floatx4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK + g * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const floatx4*>(Bb + j * 32 * LDK + g * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    // ---- phase B: stage (the partner group is in its phase A)
+    if (ks + 1 < ks1) {
+      store_tile();
+      if (ks + 2 < ks1) load_tile(ks + 2);
+    }
+    __syncthreads();
+  }
+  if (grp == 0) __syncthreads();   // balance the barrier count of the two groups
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool direct = p.nsplit == 1;
+  float* outp = direct ? p.dst : p.part + (long long)split * p.M * p.Cd;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+      const float bv = (direct && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < p.M) {
+          const long long o = (long long)row * p.Cd + col;
+          float v = acc[i][j][r] + bv;
+          if (direct) {
+            if (p.addend) v += p.addend[o];
+            if (p.relu) v = fmaxf(v, 0.f);
+          }
+          outp[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// dst = sum_s part[s] (+ bias)(+ addend)(relu) — fixed summation order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst,
+                                                            const float* __restrict__ addend,
+                                                            const float* __restrict__ bias, long long n4, int G,
+                                                            int nsplit, int relu) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    floatx4 s = reinterpret_cast<const floatx4*>(part)[i];
+    for (int k = 1; k < nsplit; ++k) s += reinterpret_cast<const floatx4*>(part)[(long long)k * n4 + i];
+    if (bias) s += reinterpret_cast<const floatx4*>(bias)[i % G];
+    if (addend) s += reinterpret_cast<const floatx4*>(addend)[i];
+    if (relu) {
+      s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
+    }
+    reinterpret_cast<floatx4*>(dst)[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gather path (the two stems: Cin = 3 / 1, channel-first source, K = 441 / 49): per-element loads
+// through a k -> (tap offset, dt, dh, dw) table held in LDS.
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void igemm_gather_kernel(const ConvArgs p) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int PA = BM / 32, PB = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * BM * LDK;
+  int2* ktab = reinterpret_cast<int2*>(smem + 2 * (BM + BN) * LDK);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+  const unsigned ntm = (p.M + BM - 1) / BM, ntn = p.Cd / BN;
+  const unsigned tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const int ntaps = p.kt * p.kh * p.kw;
+  const int K = ntaps * p.Cs;
+  const int nk = (K + BK - 1) / BK;
+
+  int a_t0[PA], a_h0[PA], a_w0[PA];
+  long long a_base[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    int b, td, hd, wd;
+    bool ok;
+    decode_row(m0 + lrow + 32 * i, p.M, p.Wd, p.Hd, p.Td, b, td, hd, wd, ok);
+    a_t0[i] = td * p.st - p.pt;
+    a_h0[i] = hd * p.sh - p.ph;
+    a_w0[i] = wd * p.sw - p.pw;
+    if (!ok) a_t0[i] = -(1 << 28);
+    a_base[i] = (long long)b * p.ssB + (long long)a_t0[i] * p.ssT + (long long)a_h0[i] * p.ssH +
+                (long long)a_w0[i] * p.ssW;
+  }
+  for (int k = tid; k < nk * BK; k += 256) {
+    int2 e;
+    if (k < K) {
+      int tap = k / p.Cs, c = k - tap * p.Cs;
+      int dw = tap % p.kw, r = tap / p.kw;
+      int dh = r % p.kh, dt = r / p.kh;
+      e.x = (int)(dt * p.ssT + dh * p.ssH + dw * p.ssW + c * p.ssC);
+      e.y = dt | (dh << 8) | (dw << 16);
+    } else {
+      e.x = 0;
+      e.y = -1;
+    }
+    ktab[k] = e;
+  }
+  __syncthreads();
+
+  floatx4 va[PA], vb[PB];
+  auto load_tile = [&](int ks) {
+    const int kb = ks * BK + lcol;
+    int2 e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = ktab[kb + j];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      floatx4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int dt = e[j].y & 0xff, dh = (e[j].y >> 8) & 0xff, dw = (e[j].y >> 16) & 0xff;
+        const int ts = a_t0[i] + dt, hs = a_h0[i] + dh, ws = a_w0[i] + dw;
+        const bool ok = (e[j].y >= 0) & ((unsigned)ts < (unsigned)p.Ts) & ((unsigned)hs < (unsigned)p.Hs) &
+                        ((unsigned)ws < (unsigned)p.Ws);
+        const float t = p.src[ok ? a_base[i] + e[j].x : 0];
+        v[j] = ok ? t : 0.f;
+      }
+      va[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int n = n0 + lrow + 32 * i;
+      floatx4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = p.wk[(kb + j < K) ? (long long)n * K + kb + j : 0];
+        v[j] = (kb + j < K) ? t : 0.f;
+      }
+      vb[i] = v;
+    }
+  };
   auto store_tile = [&](int buf) {
     float* Ab = As + buf * BM * LDK;
     float* Bb = Bs + buf * BN * LDK;
@@ -202,17 +387,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int h = lane >> 5, l31 = lane & 31;
 
   load_tile(0);
   store_tile(0);
   __syncthreads();
-
   for (int ks = 0; ks < nk; ++ks) {
     const int cur = ks & 1;
-    if (ks + 1 < nk) load_tile(ks + 1);  // global loads in flight under the MFMAs below
-
+    if (ks + 1 < nk) load_tile(ks + 1);
     const float* Ab = As + cur * BM * LDK + (wm * TM * 32 + l31) * LDK + h * 4;
     const float* Bb = Bs + cur * BN * LDK + (wn * TN * 32 + l31) * LDK + h * 4;
 #pragma unroll
@@ -230,12 +412,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
-
     if (ks + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
   }
-
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -258,9 +437,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// wgrad: one workgroup owns a 64(n) x 64(c) tile of dw for ONE tap and one m-range (split).
-// GEMM-K runs over m (pixels).  LDS tiles are [32 m][64 + 4]; fragments are ds_read_b32 (lanes of
-// a half-wave read consecutive n / c of one m-row => conflict-free).
+// wgrad.  GEMM-K runs over m (pixels) in chunks of 32 rows; a workgroup owns a
+// (64*NB)(n) x (64*KC)(k-columns) tile of dw for one m-range (split).  A k-column chunk of 64 is one
+// (tap, 64-channel) pair, so KC = 3 covers a kernel row of a 64-channel (1,3,3) conv and KC = 2 two
+// channel chunks of one tap.  4 waves as 2(n) x 2(k): each wave NB x KC MFMA tiles, fragments are
+// conflict-free ds_read_b32 (a half-wave reads 32 consecutive n / c of one m-row).
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
   const float* __restrict__ src;  // x
@@ -273,66 +454,185 @@ struct WgradArgs {
   int pt, ph, pw;
   int M;
   int nsplit, chunks_per_split;  // chunks of 32 rows
-  int kt_tiles;                  // number of 64-wide k tiles (VEC: ntaps * Cs/64; scalar: ceil(K/64))
+  int kt_tiles;                  // k tiles per n tile
   long long ssB, ssT, ssH, ssW, ssC;
 };
 
 constexpr int WG_LD = 64 + 4;
 
-template <bool VEC>
+template <int NB, int KC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ds = smem;                    // [2][32][WG_LD]  dy tile  (m, n)
-  float* Xs = smem + 2 * 32 * WG_LD;   // [2][32][WG_LD]  x tile   (m, k)
-  int2* ktab = reinterpret_cast<int2*>(smem + 4 * 32 * WG_LD);  // scalar mode: 64 entries
-
+  constexpr int DW = 64 * NB + 4;                 // dy tile row (floats)
+  constexpr int BUF = 32 * (DW + KC * WG_LD);     // one stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;  // wm: n half (rows of dw), wn: k half
+  const int wm = wave >> 1, wn = wave & 1;
   const int ntaps = p.kt * p.kh * p.kw;
   const int K = ntaps * p.Cs;
+  const int cpt = p.Cs / 64, nchunks = ntaps * cpt;
 
-  // tile decode: blockIdx.x = ktile + kt_tiles * ntile ; blockIdx.y = split
   const int ktile = blockIdx.x % p.kt_tiles, ntile = blockIdx.x / p.kt_tiles;
-  const int n0 = ntile * 64;
-  int tap = 0, c0 = 0, dt = 0, dh = 0, dw = 0;
-  if (VEC) {
-    const int cpt = p.Cs / 64;
-    tap = ktile / cpt;
-    c0 = (ktile - tap * cpt) * 64;
-    dw = tap % p.kw;
-    int r = tap / p.kw;
-    dh = r % p.kh;
-    dt = r / p.kh;
-  } else {
-    if (tid < 64) {
-      int k = ktile * 64 + tid;
-      int2 e;
-      if (k < K) {
-        int tp = k / p.Cs, c = k - tp * p.Cs;
-        int ew = tp % p.kw, r = tp / p.kw;
-        int eh = r % p.kh, et = r / p.kh;
-        e.x = (int)(et * p.ssT + eh * p.ssH + ew * p.ssW + c * p.ssC);
-        e.y = et | (eh << 8) | (ew << 16);
-      } else {
-        e.x = 0;
-        e.y = -1;
+  const int n0 = ntile * 64 * NB;
+  // the KC (tap, c0) chunks of this k tile (uniform)
+  int q_tap[KC], q_c0[KC], q_dt[KC], q_dh[KC], q_dw[KC];
+  bool q_ok[KC];
+#pragma unroll
+  for (int j = 0; j < KC; ++j) {
+    const int q = ktile * KC + j;
+    q_ok[j] = q < nchunks;
+    const int qq = q_ok[j] ? q : 0;
+    q_tap[j] = qq / cpt;
+    q_c0[j] = (qq - q_tap[j] * cpt) * 64;
+    q_dw[j] = q_tap[j] % p.kw;
+    const int r = q_tap[j] / p.kw;
+    q_dh[j] = r % p.kh;
+    q_dt[j] = r / p.kh;
+  }
+
+  const int total_chunks = (p.M + 31) / 32;
+  const int chunk0 = blockIdx.y * p.chunks_per_split;
+  const int chunk1 = min(chunk0 + p.chunks_per_split, total_chunks);
+
+  // buffer descriptors (dy and x based at the first batch item this split touches)
+  const int pix_out = p.Td * p.Hd * p.Wd, pix_in = p.Ts * p.Hs * p.Ws;
+  const int b_lo = (chunk0 * 32) / pix_out;
+  const long long x_base = (long long)b_lo * pix_in * p.Cs;
+  long long x_bytes = ((long long)p.B * pix_in * p.Cs - x_base) * 4;
+  if (x_bytes > 0x7fffffffll) x_bytes = 0x7fffffffll;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + x_base), 0, (int)x_bytes, 0x00020000);
+  const long long d_base = (long long)chunk0 * 32 * p.Cd;
+  long long d_bytes = ((long long)p.M * p.Cd - d_base) * 4;
+  if (d_bytes > 0x7fffffffll) d_bytes = 0x7fffffffll;
+  const __amdgpu_buffer_rsrc_t rsD =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + d_base), 0, (int)(d_bytes > 0 ? d_bytes : 0), 0x00020000);
+
+  const int lrow = tid >> 4;         // 0..15 (+16)
+  const int lcol = (tid & 15) * 4;   // 0..60
+  const int cs4 = p.Cs * 4;
+
+  floatx4 vd[2][NB], vx[2][KC];
+
+  auto load_chunk = [&](int ch) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mrel = (ch - chunk0) * 32 + lrow + 16 * i;   // row relative to the split base
+      const int m = chunk0 * 32 + mrel;
+      int b, td, hd, wd;
+      bool ok;
+      decode_row(m, p.M, p.Wd, p.Hd, p.Td, b, td, hd, wd, ok);
+      const unsigned doff = ok ? (unsigned)(mrel * p.Cd + n0 + lcol) * 4 : OOB;
+#pragma unroll
+      for (int t = 0; t < NB; ++t) vd[i][t] = buf_load4(rsD, ok ? doff + t * 256 : OOB);
+      const int t0 = td * p.st - p.pt, h0 = hd * p.sh - p.ph, w0 = wd * p.sw - p.pw;
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        const int ts = t0 + q_dt[j], hs = h0 + q_dh[j], ws = w0 + q_dw[j];
+        const bool okx = ok & q_ok[j] & ((unsigned)ts < (unsigned)p.Ts) & ((unsigned)hs < (unsigned)p.Hs) &
+                         ((unsigned)ws < (unsigned)p.Ws);
+        const unsigned off = (unsigned)((((b - b_lo) * p.Ts + ts) * p.Hs + hs) * p.Ws + ws) * cs4 +
+                             (q_c0[j] + lcol) * 4;
+        vx[i][j] = buf_load4(rsX, okx ? off : OOB);
       }
-      ktab[tid] = e;
     }
+  };
+  auto store_chunk = [&](int buf) {
+    float* Ds = smem + buf * BUF;
+    float* Xs = Ds + 32 * DW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+        *reinterpret_cast<floatx4*>(&Ds[(lrow + 16 * i) * DW + t * 64 + lcol]) = vd[i][t];
+#pragma unroll
+      for (int j = 0; j < KC; ++j)
+        *reinterpret_cast<floatx4*>(&Xs[j * 32 * WG_LD + (lrow + 16 * i) * WG_LD + lcol]) = vx[i][j];
+    }
+  };
+
+  floatx16 acc[NB][KC];
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  if (chunk0 < chunk1) {
+    load_chunk(chunk0);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int ch = chunk0; ch < chunk1; ++ch) {
+    const int cur = (ch - chunk0) & 1;
+    if (ch + 1 < chunk1) load_chunk(ch + 1);
+    const float* Db = smem + cur * BUF + wm * 32 * NB + l31;
+    const float* Xb = smem + cur * BUF + 32 * DW + wn * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[NB], b[KC];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) a[t] = Db[(2 * kk + h) * DW + t * 32];             // A[i = n][k = m]
+#pragma unroll
+      for (int j = 0; j < KC; ++j) b[j] = Xb[j * 32 * WG_LD + (2 * kk + h) * WG_LD];  // B[k = m][j = c]
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int j = 0; j < KC; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[j], acc[t][j], 0, 0, 0);
+    }
+    if (ch + 1 < chunk1) store_chunk(cur ^ 1);
     __syncthreads();
   }
 
-  const int chunk0 = blockIdx.y * p.chunks_per_split;
+  float* o = p.out + (long long)blockIdx.y * p.Cd * K;
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      if (!q_ok[j]) continue;
+      const int kcol = q_tap[j] * p.Cs + q_c0[j] + wn * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 32 * NB + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        o[(long long)n * K + kcol] = acc[t][j][r];
+      }
+    }
+}
+
+// gather-path wgrad (stems): 64(n) x 64(k) tile, k -> tap table in LDS
+__global__ __launch_bounds__(256) void wgrad_gather_kernel(const WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ds = smem;
+  float* Xs = smem + 2 * 32 * WG_LD;
+  int2* ktab = reinterpret_cast<int2*>(smem + 4 * 32 * WG_LD);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntaps = p.kt * p.kh * p.kw;
+  const int K = ntaps * p.Cs;
+  const int ktile = blockIdx.x % p.kt_tiles, ntile = blockIdx.x / p.kt_tiles;
+  const int n0 = ntile * 64;
+  if (tid < 64) {
+    int k = ktile * 64 + tid;
+    int2 e;
+    if (k < K) {
+      int tp = k / p.Cs, c = k - tp * p.Cs;
+      int ew = tp % p.kw, r = tp / p.kw;
+      int eh = r % p.kh, et = r / p.kh;
+      e.x = (int)(et * p.ssT + eh * p.ssH + ew * p.ssW + c * p.ssC);
+      e.y = et | (eh << 8) | (ew << 16);
+    } else {
+      e.x = 0;
+      e.y = -1;
+    }
+    ktab[tid] = e;
+  }
+  __syncthreads();
   const int total_chunks = (p.M + 31) / 32;
-  int chunk1 = chunk0 + p.chunks_per_split;
-  if (chunk1 > total_chunks) chunk1 = total_chunks;
-
-  // loader mapping: 32 rows x 16 float4 per tile = 512 float4 -> 2 per thread
-  const int lrow = tid >> 4;         // 0..15 (+16)
-  const int lcol = (tid & 15) * 4;   // 0..60
-
+  const int chunk0 = blockIdx.y * p.chunks_per_split;
+  const int chunk1 = min(chunk0 + p.chunks_per_split, total_chunks);
+  const int lrow = tid >> 4, lcol = (tid & 15) * 4;
   floatx4 vd[2], vx[2];
-
   auto load_chunk = [&](int ch) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -344,30 +644,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
       const floatx4 tdy = *reinterpret_cast<const floatx4*>(p.dy + (long long)(ok ? m : 0) * p.Cd + n0 + lcol);
       vd[i] = ok ? tdy : z;
       const int t0 = td * p.st - p.pt, h0 = hd * p.sh - p.ph, w0 = wd * p.sw - p.pw;
-      if (VEC) {
-        const int ts = t0 + dt, hs = h0 + dh, ws = w0 + dw;
-        const bool okx = ok & ((unsigned)ts < (unsigned)p.Ts) & ((unsigned)hs < (unsigned)p.Hs) &
-                         ((unsigned)ws < (unsigned)p.Ws);
-        long long pix = (((long long)b * p.Ts + ts) * p.Hs + hs) * p.Ws + ws;
-        pix = okx ? pix : 0;
-        const floatx4 tx = *reinterpret_cast<const floatx4*>(p.src + pix * p.Cs + c0 + lcol);
-        vx[i] = okx ? tx : z;
-      } else {
-        const long long base = (long long)b * p.ssB + (long long)t0 * p.ssT + (long long)h0 * p.ssH +
-                               (long long)w0 * p.ssW;
-        floatx4 v;
+      const long long base = (long long)b * p.ssB + (long long)t0 * p.ssT + (long long)h0 * p.ssH +
+                             (long long)w0 * p.ssW;
+      floatx4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int2 e = ktab[lcol + j];
-          const int et = e.y & 0xff, eh = (e.y >> 8) & 0xff, ew = (e.y >> 16) & 0xff;
-          const int ts = t0 + et, hs = h0 + eh, ws = w0 + ew;
-          const bool okx = ok & (e.y >= 0) & ((unsigned)ts < (unsigned)p.Ts) &
-                           ((unsigned)hs < (unsigned)p.Hs) & ((unsigned)ws < (unsigned)p.Ws);
-          const float t = p.src[okx ? base + e.x : 0];
-          v[j] = okx ? t : 0.f;
-        }
-        vx[i] = v;
+      for (int j = 0; j < 4; ++j) {
+        const int2 e = ktab[lcol + j];
+        const int et = e.y & 0xff, eh = (e.y >> 8) & 0xff, ew = (e.y >> 16) & 0xff;
+        const int ts = t0 + et, hs = h0 + eh, ws = w0 + ew;
+        const bool okx = ok & (e.y >= 0) & ((unsigned)ts < (unsigned)p.Ts) & ((unsigned)hs < (unsigned)p.Hs) &
+                         ((unsigned)ws < (unsigned)p.Ws);
+        const float t = p.src[okx ? base + e.x : 0];
+        v[j] = okx ? t : 0.f;
       }
+      vx[i] = v;
     }
   };
   auto store_chunk = [&](int buf) {
@@ -377,12 +667,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
       *reinterpret_cast<floatx4*>(&Xs[buf * 32 * WG_LD + (lrow + 16 * i) * WG_LD + lcol]) = vx[i];
     }
   };
-
   floatx16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int h = lane >> 5, l31 = lane & 31;
-
   if (chunk0 < chunk1) {
     load_chunk(chunk0);
     store_chunk(0);
@@ -394,18 +682,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const float* Db = Ds + cur * 32 * WG_LD + wm * 32 + l31;
     const float* Xb = Xs + cur * 32 * WG_LD + wn * 32 + l31;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const float a = Db[(2 * kk + h) * WG_LD];  // A[i = n][k = m]
-      const float b = Xb[(2 * kk + h) * WG_LD];  // B[k = m][j = c]
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
+    for (int kk = 0; kk < 16; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Db[(2 * kk + h) * WG_LD], Xb[(2 * kk + h) * WG_LD], acc, 0, 0, 0);
     if (ch + 1 < chunk1) store_chunk(cur ^ 1);
     __syncthreads();
   }
-
-  // write the partial tile: out[split][n][k]
   float* o = p.out + (long long)blockIdx.y * p.Cd * K;
-  const int kcol = (VEC ? tap * p.Cs + c0 : ktile * 64) + wn * 32 + l31;
+  const int kcol = ktile * 64 + wn * 32 + l31;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int n = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -413,13 +696,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
   }
 }
 
-// sum partials over splits (fixed order => deterministic)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long long n, int nsplit) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// sum partials over splits in a fixed order (deterministic): block = 32 elements x 8 split slices
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           long long n, int nsplit) {
+  __shared__ float sh[8][32];
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long long i = (long long)blockIdx.x * 32 + e;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += part[(long long)k * n + i];
-  dw[i] = s;
+  if (i < n)
+    for (int k = sl; k < nsplit; k += 8) s += part[(long long)k * n + i];
+  sh[sl][e] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    float t = sh[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += sh[k][e];
+    dw[i] = t;
+  }
 }
 
 // w[co][tap][ci] -> wT[ci][tap][co]
@@ -451,13 +744,24 @@ static int validate(const avid_conv_desc* d) {
                "conv: output extent (%d,%d,%d) does not match (%d,%d,%d)", d->To, d->Ho, d->Wo, To, Ho, Wo);
   AVID_REQUIRE(d->Cout % 64 == 0, AVID_E_UNSUPPORTED, "conv: Cout=%d must be a multiple of 64", d->Cout);
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
+  const int ntaps = d->kt * d->kh * d->kw;
   if (!vec) {
-    AVID_REQUIRE(d->kt * d->kh * d->kw * d->Cin <= KTAB_MAX - 32, AVID_E_UNSUPPORTED,
-                 "conv: gather path supports K <= %d (got %d)", KTAB_MAX - 32, d->kt * d->kh * d->kw * d->Cin);
+    AVID_REQUIRE(ntaps * d->Cin <= KTAB_MAX - 32, AVID_E_UNSUPPORTED,
+                 "conv: gather path supports K <= %d (got %d)", KTAB_MAX - 32, ntaps * d->Cin);
+  } else {
+    AVID_REQUIRE(d->kt <= 8 && d->kh <= 8 && d->kw <= 8, AVID_E_UNSUPPORTED, "conv: vector path supports kernel extents <= 8");
+    AVID_REQUIRE((long long)d->Cout * ntaps * d->Cin * 4 < (1ll << 31), AVID_E_UNSUPPORTED, "conv: weights >= 2 GiB");
   }
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
   const long long Mi = (long long)d->B * d->Ti * d->Hi * d->Wi;
   AVID_REQUIRE(M < (1ll << 31) && Mi < (1ll << 31), AVID_E_UNSUPPORTED, "conv: more than 2^31 pixels");
+  // 32-bit byte offsets inside one workgroup's batch span (<= 128 rows + one batch item)
+  const long long per_b_in = (long long)d->Ti * d->Hi * d->Wi * d->Cin * 4;
+  const long long per_b_out = (long long)d->To * d->Ho * d->Wo * d->Cout * 4;
+  AVID_REQUIRE(per_b_in * 130 < (1ll << 31) || per_b_in < (1ll << 24), AVID_E_UNSUPPORTED,
+               "conv: one batch item of x is too large for 32-bit tile offsets");
+  AVID_REQUIRE(per_b_out * 130 < (1ll << 31) || per_b_out < (1ll << 24), AVID_E_UNSUPPORTED,
+               "conv: one batch item of y is too large for 32-bit tile offsets");
   return AVID_OK;
 }
 
@@ -478,76 +782,158 @@ static void fill_src_strides(const avid_conv_desc* d, long long& sB, long long& 
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC>
+// ---- tile / split-K plan (shared by the launcher, the workspace query and the name query)
+struct IgemmPlan {
+  int tile;    // 0: 128x128, 1: 128x64, 3: 64x64
+  int BM, BN;
+  int nsplit, ksteps_per_split;
+};
+static const char* kTileName[4] = {"2,2,2,2", "4,1,1,2", "1,4,1,1", "2,2,1,1"};
+
+static IgemmPlan plan_igemm(long long M, int Cd, int nk_total, bool allow_split) {
+  IgemmPlan pl;
+  const long long t128 = (M + 127) / 128;
+  if (Cd % 128 == 0 && t128 * (Cd / 128) >= 2 * 256) {
+    pl.tile = 0; pl.BM = 128; pl.BN = 128;       // plenty of work: the biggest tile
+  } else if (M > 64) {
+    pl.tile = 1; pl.BM = 128; pl.BN = 64;
+  } else {
+    pl.tile = 3; pl.BM = 64; pl.BN = 64;         // heads at tiny batch
+  }
+  const long long tiles = ((((M + pl.BM - 1) / pl.BM) + 1) / 2) * (Cd / pl.BN);  // workgroups (2 M-tiles each)
+  int ns = 1;
+  if (allow_split && tiles < 256) {              // fewer than one workgroup per CU: split GEMM-K
+    ns = (int)(2 * 256 / tiles);
+    const int max_ns = nk_total / 4 > 0 ? nk_total / 4 : 1;  // >= 4 k-steps per split
+    if (ns > max_ns) ns = max_ns;
+    if (ns > 64) ns = 64;
+    if (ns < 1) ns = 1;
+  }
+  pl.ksteps_per_split = (nk_total + ns - 1) / ns;
+  pl.nsplit = (nk_total + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
+  return pl;
+}
+
+template <int WM, int WN, int TM, int TN, int MODE>
 static int launch_igemm(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + (VEC ? 0 : sizeof(int2) * KTAB_MAX);
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;   // two groups, one stage each
   static bool attr_set = false;
-  auto kern = igemm_kernel<WM, WN, TM, TN, VEC>;
+  auto kern = igemm_kernel<WM, WN, TM, TN, MODE>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const unsigned ntm = (a.M + BM - 1) / BM, ntn = a.Cd / BN;
   static char name[64] = "";
-  if (!name[0]) snprintf(name, sizeof(name), "igemm_kernel<%d,%d,%d,%d,%d>", WM, WN, TM, TN, VEC ? 1 : 0);
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_kernel<%d,%d,%d,%d,%d>", WM, WN, TM, TN, MODE);
   const double K = (double)a.kt * a.kh * a.kw * a.Cs;
   // algorithmic work: 2*M*N*K flops; bytes = one read of src + weights, one write of dst (+ addend)
   const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
   ScopedTimer t(s, name, 2.0 * a.M * a.Cd * K,
                 4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (a.addend ? 2 : 1)));
-  hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(((ntm + 1) / 2) * ntn * a.nsplit), dim3(512), lds, s, a);
   return check_launch("igemm");
 }
 
-// Tile choice: the biggest tile that still gives every CU >= 2 workgroups; small-M late layers fall
-// back to 64x64 / 32x128 tiles (split-K for them is a later optimisation).
-static int pick_tile(long long M, int Cd) {
-  const long long want = 2 * 256;
-  if (Cd % 128 == 0 && ((M + 127) / 128) * (Cd / 128) >= want) return 0;  // 128 x 128
-  if (((M + 127) / 128) * (Cd / 64) >= want) return 1;                    // 128 x 64
-  if (Cd % 128 == 0 && M <= 2048) return 2;                               // 32 x 128
-  return 3;                                                               // 64 x 64
-}
-static const char* kTileName[4] = {"2,2,2,2", "4,1,1,2", "1,4,1,1", "2,2,1,1"};
-
-template <bool VEC>
-static int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
-  switch (pick_tile(a.M, a.Cd)) {
-    case 0: return launch_igemm<2, 2, 2, 2, VEC>(a, s);
-    case 1: return launch_igemm<4, 1, 1, 2, VEC>(a, s);
-    case 2: return launch_igemm<1, 4, 1, 1, VEC>(a, s);
-    default: return launch_igemm<2, 2, 1, 1, VEC>(a, s);
+template <int MODE>
+static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s) {
+  const int nk_total = a.kt * a.kh * a.kw * (a.Cs / BK);
+  IgemmPlan pl = plan_igemm(a.M, a.Cd, nk_total, true);
+  if (pl.nsplit > 1 && (ws == nullptr || ws_bytes < sizeof(float) * (size_t)pl.nsplit * a.M * a.Cd)) {
+    pl = plan_igemm(a.M, a.Cd, nk_total, false);  // no scratch: single pass
   }
+  a.nsplit = pl.nsplit;
+  a.ksteps_per_split = pl.ksteps_per_split;
+  a.part = static_cast<float*>(ws);
+  int rc;
+  switch (pl.tile) {
+    case 0: rc = launch_igemm<2, 2, 2, 2, MODE>(a, s); break;
+    case 1: rc = launch_igemm<4, 1, 1, 2, MODE>(a, s); break;
+    default: rc = launch_igemm<2, 2, 1, 1, MODE>(a, s); break;
+  }
+  if (rc || pl.nsplit == 1) return rc;
+  const long long n4 = (long long)a.M * a.Cd / 4;
+  long long grid = ceil_div(n4, 256);
+  if (grid > 2048) grid = 2048;
+  ScopedTimer t(s, "splitk_reduce_kernel", 0.0, 4.0 * a.M * a.Cd * (pl.nsplit + 1 + (a.addend ? 1 : 0)));
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, a.part, a.dst, a.addend, a.bias, n4,
+                     a.Cd / 4, pl.nsplit, a.relu);
+  return check_launch("splitk_reduce");
+}
+
+static int launch_gather(const ConvArgs& a, hipStream_t s) {
+  const long long M = a.M;
+  const bool big = ((M + 127) / 128) * (a.Cd / 64) >= 256;
+  const double K = (double)a.kt * a.kh * a.kw * a.Cs;
+  const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
+  if (big) {
+    const size_t lds = sizeof(float) * 2 * (128 + 64) * LDK + sizeof(int2) * KTAB_MAX;
+    ScopedTimer t(s, "igemm_gather_kernel<4,1,1,2>", 2.0 * a.M * a.Cd * K,
+                  4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd));
+    hipLaunchKernelGGL((igemm_gather_kernel<4, 1, 1, 2>), dim3((unsigned)(((M + 127) / 128) * (a.Cd / 64))), dim3(256),
+                       lds, s, a);
+  } else {
+    const size_t lds = sizeof(float) * 2 * (64 + 64) * LDK + sizeof(int2) * KTAB_MAX;
+    ScopedTimer t(s, "igemm_gather_kernel<2,2,1,1>", 2.0 * a.M * a.Cd * K,
+                  4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd));
+    hipLaunchKernelGGL((igemm_gather_kernel<2, 2, 1, 1>), dim3((unsigned)(((M + 63) / 64) * (a.Cd / 64))), dim3(256),
+                       lds, s, a);
+  }
+  return check_launch("igemm_gather");
+}
+
+static void fill_common(ConvArgs& a, const avid_conv_desc* d) {
+  a.kt = d->kt; a.kh = d->kh; a.kw = d->kw;
+  a.st = d->st; a.sh = d->sh; a.sw = d->sw;
+  a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
+  a.B = d->B;
+  a.nsplit = 1;
+  a.ksteps_per_split = 1 << 30;
+  a.part = nullptr;
 }
 
 }  // namespace avid
 
 using namespace avid;
 
+extern "C" size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d) {
+  if (!d || validate(d)) return 0;
+  const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
+  if (!vec) return 0;
+  const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
+  IgemmPlan pl = plan_igemm(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK), true);
+  return pl.nsplit > 1 ? sizeof(float) * (size_t)pl.nsplit * M * d->Cout : 0;
+}
+
 extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* addend,
-                             const float* bias, int relu, float* y, avid_stream_t stream) {
+                             const float* bias, int relu, float* y, void* ws, size_t ws_bytes,
+                             avid_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
   AVID_REQUIRE(x && w && y, AVID_E_BADARG, "conv_fwd: null pointer");
   ConvArgs a;
+  fill_common(a, d);
   a.src = x; a.wk = w; a.addend = addend; a.bias = bias; a.dst = y;
-  a.B = d->B; a.Ts = d->Ti; a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Cin;
+  a.Ts = d->Ti; a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Cin;
   a.Td = d->To; a.Hd = d->Ho; a.Wd = d->Wo; a.Cd = d->Cout;
-  a.kt = d->kt; a.kh = d->kh; a.kw = d->kw;
-  a.st = d->st; a.sh = d->sh; a.sw = d->sw;
-  a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
   a.M = d->B * d->To * d->Ho * d->Wo;
   a.mode = 0;
   a.relu = relu;
   fill_src_strides(d, a.ssB, a.ssT, a.ssH, a.ssW, a.ssC);
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
-  return vec ? dispatch_igemm<true>(a, (hipStream_t)stream) : dispatch_igemm<false>(a, (hipStream_t)stream);
+  return vec ? dispatch_igemm<0>(a, ws, ws_bytes, (hipStream_t)stream) : launch_gather(a, (hipStream_t)stream);
+}
+
+static size_t dgrad_wt_bytes(const avid_conv_desc* d) {
+  return (sizeof(float) * (size_t)d->Cout * d->kt * d->kh * d->kw * d->Cin + 255) / 256 * 256;
 }
 
 extern "C" size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d) {
-  if (!d) return 0;
-  return sizeof(float) * (size_t)d->Cout * d->kt * d->kh * d->kw * d->Cin;
+  if (!d || validate(d)) return 0;
+  const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
+  IgemmPlan pl = plan_igemm(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK), true);
+  return dgrad_wt_bytes(d) + (pl.nsplit > 1 ? sizeof(float) * (size_t)pl.nsplit * M * d->Cin : 0);
 }
 
 extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* addend,
@@ -559,7 +945,7 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
                "conv_dgrad: needs channels-last x, Cin %% 64 == 0 and Cout %% 32 == 0 (Cin=%d Cout=%d)", d->Cin,
                d->Cout);
   AVID_REQUIRE(d->st <= 2 && d->sh <= 2 && d->sw <= 2, AVID_E_UNSUPPORTED, "conv_dgrad: stride > 2");
-  AVID_REQUIRE(ws_bytes >= avid_conv_dgrad_workspace_bytes(d), AVID_E_BADARG, "conv_dgrad: workspace too small");
+  AVID_REQUIRE(ws_bytes >= dgrad_wt_bytes(d), AVID_E_BADARG, "conv_dgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int ntaps = d->kt * d->kh * d->kw;
   float* wt = static_cast<float*>(ws);
@@ -572,40 +958,60 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
   rc = check_launch("weight_transpose");
   if (rc) return rc;
   ConvArgs a;
+  fill_common(a, d);
   a.src = dy; a.wk = wt; a.addend = addend; a.bias = nullptr; a.dst = dx;
-  a.B = d->B; a.Ts = d->To; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
+  a.Ts = d->To; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
   a.Td = d->Ti; a.Hd = d->Hi; a.Wd = d->Wi; a.Cd = d->Cin;
-  a.kt = d->kt; a.kh = d->kh; a.kw = d->kw;
-  a.st = d->st; a.sh = d->sh; a.sw = d->sw;
-  a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
   a.M = d->B * d->Ti * d->Hi * d->Wi;
   a.mode = 1;
   a.relu = 0;
   a.ssB = a.ssT = a.ssH = a.ssW = a.ssC = 0;
-  return dispatch_igemm<true>(a, s);
+  return dispatch_igemm<1>(a, static_cast<char*>(ws) + dgrad_wt_bytes(d), ws_bytes - dgrad_wt_bytes(d), s);
 }
 
-static void wgrad_plan(const avid_conv_desc* d, int& kt_tiles, int& nsplit, int& cps, bool& vec) {
+// ---- wgrad plan
+struct WgradPlan {
+  bool vec;
+  int NB, KC;
+  int kt_tiles, n_tiles, nsplit, cps;
+};
+
+static WgradPlan wgrad_plan(const avid_conv_desc* d) {
+  WgradPlan pl;
   const int ntaps = d->kt * d->kh * d->kw;
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
-  vec = (d->Cin % 64 == 0) && !d->x_channel_first;
-  kt_tiles = vec ? ntaps * (d->Cin / 64) : (int)ceil_div((long long)ntaps * d->Cin, 64);
-  const long long tiles = (long long)kt_tiles * (d->Cout / 64);
+  pl.vec = (d->Cin % 64 == 0) && !d->x_channel_first;
+  if (pl.vec) {
+    pl.NB = d->Cout % 128 == 0 ? 2 : 1;
+    pl.KC = pl.NB == 1 ? 3 : 2;
+    const int nchunks = ntaps * (d->Cin / 64);
+    pl.kt_tiles = (nchunks + pl.KC - 1) / pl.KC;
+    pl.n_tiles = d->Cout / (64 * pl.NB);
+  } else {
+    pl.NB = pl.KC = 1;
+    pl.kt_tiles = (int)ceil_div((long long)ntaps * d->Cin, 64);
+    pl.n_tiles = d->Cout / 64;
+  }
+  const long long tiles = (long long)pl.kt_tiles * pl.n_tiles;
   const long long chunks = ceil_div(M, 32);
-  long long want = ceil_div(4 * 256, tiles);           // ~4 workgroups per CU
+  long long want = (2 * 256) / tiles;                     // fill 2 workgroups per CU, never one more
   long long max_split = chunks / 8 > 0 ? chunks / 8 : 1;  // >= 8 chunks (256 rows) per split
-  nsplit = (int)(want < 1 ? 1 : (want > max_split ? max_split : want));
-  if (nsplit > 256) nsplit = 256;
-  cps = (int)ceil_div(chunks, nsplit);
-  nsplit = (int)ceil_div(chunks, cps);
+  long long ns = want < 1 ? 1 : (want > max_split ? max_split : want);
+  if (ns > 256) ns = 256;
+  // 32-bit byte offsets inside one split: (batch items touched) * bytes per input item < 2 GiB
+  const long long pix_out = (long long)d->To * d->Ho * d->Wo;
+  const long long per_b_in = (long long)d->Ti * d->Hi * d->Wi * d->Cin * 4;
+  while (ns < chunks && (ceil_div(chunks, ns) * 32 / pix_out + 2) * per_b_in >= (1ll << 31)) ns *= 2;
+  if (ns > chunks) ns = chunks;
+  pl.cps = (int)ceil_div(chunks, ns);
+  pl.nsplit = (int)ceil_div(chunks, pl.cps);
+  return pl;
 }
 
 extern "C" size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d) {
-  if (!d) return 0;
-  int kt_tiles, nsplit, cps;
-  bool vec;
-  wgrad_plan(d, kt_tiles, nsplit, cps, vec);
-  return sizeof(float) * (size_t)nsplit * d->Cout * d->kt * d->kh * d->kw * d->Cin;
+  if (!d || validate(d)) return 0;
+  WgradPlan pl = wgrad_plan(d);
+  return sizeof(float) * (size_t)pl.nsplit * d->Cout * d->kt * d->kh * d->kw * d->Cin;
 }
 
 extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,
@@ -613,42 +1019,57 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
   int rc = validate(d);
   if (rc) return rc;
   AVID_REQUIRE(x && dy && dw, AVID_E_BADARG, "conv_wgrad: null pointer");
-  int kt_tiles, nsplit, cps;
-  bool vec;
-  wgrad_plan(d, kt_tiles, nsplit, cps, vec);
-  AVID_REQUIRE(nsplit == 1 || (ws && ws_bytes >= avid_conv_wgrad_workspace_bytes(d)), AVID_E_BADARG,
+  WgradPlan pl = wgrad_plan(d);
+  AVID_REQUIRE(pl.nsplit == 1 || (ws && ws_bytes >= avid_conv_wgrad_workspace_bytes(d)), AVID_E_BADARG,
                "conv_wgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   WgradArgs a;
   a.src = x; a.dy = dy;
-  a.out = nsplit == 1 ? dw : static_cast<float*>(ws);
+  a.out = pl.nsplit == 1 ? dw : static_cast<float*>(ws);
   a.B = d->B; a.Ts = d->Ti; a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Cin;
   a.Td = d->To; a.Hd = d->Ho; a.Wd = d->Wo; a.Cd = d->Cout;
   a.kt = d->kt; a.kh = d->kh; a.kw = d->kw;
   a.st = d->st; a.sh = d->sh; a.sw = d->sw;
   a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
   a.M = d->B * d->To * d->Ho * d->Wo;
-  a.nsplit = nsplit; a.chunks_per_split = cps; a.kt_tiles = kt_tiles;
+  a.nsplit = pl.nsplit; a.chunks_per_split = pl.cps; a.kt_tiles = pl.kt_tiles;
   fill_src_strides(d, a.ssB, a.ssT, a.ssH, a.ssW, a.ssC);
-  const size_t lds = sizeof(float) * 4 * 32 * WG_LD + sizeof(int2) * 64;
-  dim3 grid((unsigned)(kt_tiles * (d->Cout / 64)), (unsigned)nsplit);
+  dim3 grid((unsigned)(pl.kt_tiles * pl.n_tiles), (unsigned)pl.nsplit);
   {
     const double K = (double)a.kt * a.kh * a.kw * a.Cs;
     const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
-    ScopedTimer t(s, vec ? "wgrad_kernel<1>" : "wgrad_kernel<0>", 2.0 * a.M * a.Cd * K,
-                  4.0 * (srcpix * a.Cs + (double)a.M * a.Cd + (double)a.Cd * K));
-    if (vec)
-      hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(256), lds, s, a);
-    else
-      hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(256), lds, s, a);
+    const char* name = !pl.vec ? "wgrad_gather_kernel" : (pl.NB == 1 ? "wgrad_kernel<1,3>" : "wgrad_kernel<2,2>");
+    ScopedTimer t(s, name, 2.0 * a.M * a.Cd * K, 4.0 * (srcpix * a.Cs + (double)a.M * a.Cd + (double)a.Cd * K));
+    if (!pl.vec) {
+      const size_t lds = sizeof(float) * 4 * 32 * WG_LD + sizeof(int2) * 64;
+      hipLaunchKernelGGL(wgrad_gather_kernel, grid, dim3(256), lds, s, a);
+    } else if (pl.NB == 1) {
+      const size_t lds = sizeof(float) * 2 * 32 * (64 * 1 + 4 + 3 * WG_LD);
+      static bool set = false;
+      if (!set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set = true;
+      }
+      hipLaunchKernelGGL((wgrad_kernel<1, 3>), grid, dim3(256), lds, s, a);
+    } else {
+      const size_t lds = sizeof(float) * 2 * 32 * (64 * 2 + 4 + 2 * WG_LD);
+      static bool set = false;
+      if (!set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<2, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set = true;
+      }
+      hipLaunchKernelGGL((wgrad_kernel<2, 2>), grid, dim3(256), lds, s, a);
+    }
   }
   rc = check_launch("wgrad");
   if (rc) return rc;
-  if (nsplit > 1) {
+  if (pl.nsplit > 1) {
     const long long n = (long long)d->Cout * d->kt * d->kh * d->kw * d->Cin;
-    ScopedTimer t(s, "wgrad_reduce_kernel", 0.0, 4.0 * n * (nsplit + 1));
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s,
-                       static_cast<const float*>(ws), dw, n, nsplit);
+    ScopedTimer t(s, "wgrad_reduce_kernel", 0.0, 4.0 * n * (pl.nsplit + 1));
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(n, 32)), dim3(256), 0, s,
+                       static_cast<const float*>(ws), dw, n, pl.nsplit);
     rc = check_launch("wgrad_reduce");
   }
   return rc;
@@ -661,15 +1082,22 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
   if (which == 0) {
     const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
-    snprintf(buf, len, "igemm_kernel<%s,%d>", kTileName[pick_tile(M, d->Cout)], vec ? 1 : 0);
+    if (!vec) {
+      snprintf(buf, len, "igemm_gather_kernel<%s>", ((M + 127) / 128) * (d->Cout / 64) >= 256 ? "4,1,1,2" : "2,2,1,1");
+    } else {
+      IgemmPlan pl = plan_igemm(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK), true);
+      snprintf(buf, len, "igemm_kernel<%s,0> splitk=%d", kTileName[pl.tile], pl.nsplit);
+    }
   } else if (which == 1) {
     const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
-    snprintf(buf, len, "igemm_kernel<%s,1>", kTileName[pick_tile(M, d->Cin)]);
+    IgemmPlan pl = plan_igemm(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK), true);
+    snprintf(buf, len, "igemm_kernel<%s,1> splitk=%d", kTileName[pl.tile], pl.nsplit);
   } else {
-    int kt_tiles, nsplit, cps;
-    bool v;
-    wgrad_plan(d, kt_tiles, nsplit, cps, v);
-    snprintf(buf, len, "wgrad_kernel<%d>", v ? 1 : 0);
+    WgradPlan pl = wgrad_plan(d);
+    if (!pl.vec)
+      snprintf(buf, len, "wgrad_gather_kernel splits=%d", pl.nsplit);
+    else
+      snprintf(buf, len, "wgrad_kernel<%d,%d> splits=%d", pl.NB, pl.KC, pl.nsplit);
   }
   return AVID_OK;
 }

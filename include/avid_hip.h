@@ -65,11 +65,14 @@ typedef struct avid_conv_desc {
 } avid_conv_desc;
 
 /* y = conv(x, w) [+ addend] [+ bias] [relu].  addend: [B,To,Ho,Wo,Cout] or NULL (residual add of
- * models/network_blocks.py:59 fused into tmp_conv2/res_conv); bias: [Cout] or NULL. */
+ * models/network_blocks.py:59 fused into tmp_conv2/res_conv); bias: [Cout] or NULL.
+ * ws: scratch for the split-K partial slabs of small-M layers (may be NULL: single pass, slower). */
+size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d);
 int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* addend,
-                  const float* bias, int relu, float* y, avid_stream_t stream);
+                  const float* bias, int relu, float* y, void* ws, size_t ws_bytes,
+                  avid_stream_t stream);
 
-/* dx = conv_transpose(dy, w) [+ addend].  ws: scratch for the transposed weights. */
+/* dx = conv_transpose(dy, w) [+ addend].  ws: scratch for the transposed weights (+ split-K slabs). */
 size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d);
 int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* addend,
                     float* dx, void* ws, size_t ws_bytes, avid_stream_t stream);

@@ -1,0 +1,68 @@
+"""Per-layer conv micro-benchmark (dev tool): TF/s of fwd / dgrad / wgrad for every distinct conv shape
+of the R(2+1)D-18 + Conv2D step at a given batch, timed with the library's HIP-event timers."""
+import os, sys, ctypes as C
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "avid-cma_amd"))
+import torch
+from avid_hip import lib, ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+only = sys.argv[2] if len(sys.argv) > 2 else ""
+reps = 5
+dev = torch.device("cuda:0")
+# name, Cin, Cout, k, stride, pad, (T,H,W) in
+L = [
+ ("c2.spt", 64, 64, (1,3,3), (1,1,1), (0,1,1), (8,28,28)),
+ ("c2.tmp", 64, 64, (3,1,1), (1,1,1), (1,0,0), (8,28,28)),
+ ("c3.spt_s2", 64, 128, (1,3,3), (1,2,2), (0,1,1), (8,28,28)),
+ ("c3.tmp_s2", 128, 128, (3,1,1), (2,1,1), (1,0,0), (8,14,14)),
+ ("c3.res", 64, 128, (1,1,1), (2,2,2), (0,0,0), (8,28,28)),
+ ("c3.spt", 128, 128, (1,3,3), (1,1,1), (0,1,1), (4,14,14)),
+ ("c3.tmp", 128, 128, (3,1,1), (1,1,1), (1,0,0), (4,14,14)),
+ ("c4.spt_s2", 128, 256, (1,3,3), (1,2,2), (0,1,1), (4,14,14)),
+ ("c4.spt", 256, 256, (1,3,3), (1,1,1), (0,1,1), (2,7,7)),
+ ("c4.tmp", 256, 256, (3,1,1), (1,1,1), (1,0,0), (2,7,7)),
+ ("c5.spt_s2", 256, 512, (1,3,3), (1,2,2), (0,1,1), (2,7,7)),
+ ("c5.spt", 512, 512, (1,3,3), (1,1,1), (0,1,1), (1,4,4)),
+ ("c5.tmp", 512, 512, (3,1,1), (1,1,1), (1,0,0), (1,4,4)),
+ ("a.b1", 64, 64, (1,3,3), (1,1,1), (0,1,1), (1,10,25)),
+ ("a.b4", 512, 512, (1,3,3), (1,1,1), (0,1,1), (1,3,7)),
+]
+print(f"{'layer':10s} {'M':>8s} {'K':>5s} {'N':>4s} | {'fwd us':>8s} {'TF':>6s} | {'dgrad us':>8s} {'TF':>6s} | {'wgrad us':>8s} {'TF':>6s}  kernels")
+for name, cin, cout, k, st, pd, (T, H, W) in L:
+    if only and only not in name: continue
+    x = torch.randn(B, T, H, W, cin, device=dev).requires_grad_(True)
+    w = ops.make_weight(cout, cin, *k).normal_().to(dev).requires_grad_(True)
+    y = ops.conv_cl(x, w, st, pd)
+    g = torch.randn_like(y)
+    y.backward(g)
+    torch.cuda.synchronize()
+    res = {}
+    for which in ("fwd", "bwd"):
+        lib.timing_enable(True)
+        for _ in range(reps):
+            if which == "fwd":
+                y = ops.conv_cl(x, w, st, pd)
+            else:
+                x.grad = None; w.grad = None
+                y.backward(g, retain_graph=True)
+        torch.cuda.synchronize()
+        res[which] = lib.timing_report()
+        lib.timing_enable(False)
+    M = y.numel() // cout
+    K = cin * k[0] * k[1] * k[2]
+    fl = 2.0 * M * cout * K
+    def pick(rep, pref, mode=None):
+        t = 0.0; names = []
+        for n, v in rep.items():
+            if n.startswith(pref) and (mode is None or n.endswith(f",{mode}>")):
+                t += v["ms"]; names.append(n)
+        return t / reps * 1e3, names
+    f_us, fn = pick(res["fwd"], "igemm_kernel", 0)
+    fr_us, _ = pick(res["fwd"], "splitk")
+    d_us, dn = pick(res["bwd"], "igemm_kernel", 1)
+    dr_us, _ = pick(res["bwd"], "splitk"); dt_us, _ = pick(res["bwd"], "weight_tr")
+    w_us, wn = pick(res["bwd"], "wgrad_kernel")
+    wr_us, _ = pick(res["bwd"], "wgrad_reduce")
+    print(f"{name:10s} {M:8d} {K:5d} {cout:4d} | {f_us+fr_us:8.1f} {fl/(f_us+fr_us)/1e6:6.1f} | {d_us+dr_us+dt_us:8.1f} {fl/(d_us+dr_us+dt_us)/1e6:6.1f} | "
+          f"{w_us+wr_us:8.1f} {fl/(w_us+wr_us)/1e6:6.1f}  {fn+dn+wn} (+red {fr_us:.0f}/{dr_us+dt_us:.0f}/{wr_us:.0f})")
