@@ -42,6 +42,10 @@ struct ScopedTimer {
   ~ScopedTimer();
 };
 
+// conv.hip: C[M][N] = A[M][K].Bq[N][K]^T (op 0) / min(.,Cin) (1) / max(.,Cin) (2) on the MFMA igemm kernel
+int sim_gemm_nt(const float* A, const float* Bq, float* C, const float* Cin, int op, long long M, int N, int K,
+                hipStream_t s);
+
 // 64-lane wave reductions (DPP/ds_swizzle chosen by the compiler from __shfl_xor).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

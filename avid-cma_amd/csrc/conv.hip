@@ -41,6 +41,7 @@ struct ConvArgs {
   int M;      // B*Td*Hd*Wd
   int mode;   // 0: s = d*stride - pad + tap ;  1: s = (d + pad - tap) / stride (exact)
   int relu;
+  int epi_op;  // how `addend` combines: 0 add, 1 min, 2 max (CMA agreement scores)
   int nsplit, ksteps_per_split;
   long long ssB, ssT, ssH, ssW, ssC;  // gather-path source strides (elements)
 };
@@ -258,7 +259,10 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
           const long long o = (long long)row * p.Cd + col;
           float v = acc[i][j][r] + bv;
           if (direct) {
-            if (p.addend) v += p.addend[o];
+            if (p.addend) {
+              const float ad = p.addend[o];
+              v = p.epi_op == 0 ? v + ad : (p.epi_op == 1 ? fminf(v, ad) : fmaxf(v, ad));
+            }
             if (p.relu) v = fmaxf(v, 0.f);
           }
           outp[o] = v;
@@ -891,6 +895,25 @@ static void fill_common(ConvArgs& a, const avid_conv_desc* d) {
   a.nsplit = 1;
   a.ksteps_per_split = 1 << 30;
   a.part = nullptr;
+  a.epi_op = 0;
+}
+
+// C[M][N] = A[M][K] . Bq[N][K]^T, optionally combined with Cin by min / max — the similarity GEMMs of
+// the CMA search run on the same MFMA kernel as a 1x1x1 convolution over M "pixels".
+int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin, int op, long long M, int N, int K,
+                hipStream_t s) {
+  AVID_REQUIRE(N % 64 == 0 && K % 32 == 0 && M > 0 && M < (1ll << 31), AVID_E_UNSUPPORTED,
+               "sim_gemm: need N %% 64 == 0, K %% 32 == 0 (N=%d K=%d)", N, K);
+  ConvArgs a;
+  a.kt = a.kh = a.kw = 1; a.st = a.sh = a.sw = 1; a.pt = a.ph = a.pw = 0;
+  a.B = 1; a.Ts = 1; a.Hs = 1; a.Ws = (int)M; a.Cs = K;
+  a.Td = 1; a.Hd = 1; a.Wd = (int)M; a.Cd = N;
+  a.M = (int)M;
+  a.src = A; a.wk = Bq; a.addend = Cin; a.bias = nullptr; a.dst = Cout_;
+  a.mode = 0; a.relu = 0; a.epi_op = op;
+  a.nsplit = 1; a.ksteps_per_split = 1 << 30; a.part = nullptr;
+  a.ssB = a.ssT = a.ssH = a.ssW = a.ssC = 0;
+  return launch_igemm<4, 1, 1, 2, 0>(a, s);
 }
 
 }  // namespace avid

@@ -358,3 +358,50 @@ def test_graph_replay_equals_eager(gpu_device):
     assert torch.equal(m1.video_model.conv1[0].weight, m2.video_model.conv1[0].weight)
     assert torch.equal(c1.nce_average.view1_mem, c2.nce_average.view1_mem)
     assert int(e2.t_dev) == 6 and int(c2.nce_average.multinomial.offset_dev) == 6
+
+
+def test_cma_topk_vs_reference_golden(golden, gpu_device):
+    """find_correspondences on the 500 x 128 golden banks: all four agreement types vs the reference's
+    CMASampler output (sets compared; at most one boundary tie may differ per row), rows sorted, self excluded."""
+    from avid_hip import topk
+    g = golden("cma")
+    N, Pk = 500, 32
+    v1, v2 = det_bank("cma:v1", N).to(gpu_device), det_bank("cma:v2", N).to(gpu_device)
+    for kind, name in enumerate(["consensus", "union", "video", "audio"]):
+        got = topk.cma_topk(v1, v2, 0, N, Pk, kind, batch=128).cpu().numpy()
+        ref = g[f"topk_{name}"]
+        assert got.shape == ref.shape
+        same = [set(got[i]) == set(ref[i]) for i in range(N)]
+        assert np.mean(same) > 0.995, (name, np.mean(same))
+        for i in range(N):
+            assert i not in set(got[i]) and len(set(got[i]) & set(ref[i])) >= Pk - 1
+        assert (np.diff(got, axis=1) > 0).all()
+    # sharded query ranges give the same rows (multi-GPU path shards [q0, q1) by rank)
+    a = topk.cma_topk(v1, v2, 0, 250, Pk, 0, batch=64)
+    b = topk.cma_topk(v1, v2, 250, 500, Pk, 0, batch=64)
+    full = topk.cma_topk(v1, v2, 0, N, Pk, 0, batch=128)
+    assert torch.equal(torch.cat([a, b]), full)
+
+
+def test_avid_cma_constructor_end_to_end(gpu_device):
+    """criterions.AVID_CMA(...) builds its positive_set with the HIP search and trains one step."""
+    import criterions
+    N, bs = 3000, 8
+    crit = criterions.AVID_CMA(num_data=N, embedding_dim=128, num_negatives=256, num_negatives_within=64,
+                               momentum=0.5, sampling_args={"type": "consensus", "pos_k": 32},
+                               resample_freq=5, device=gpu_device.index)
+    ps = crit.nce_average.positive_set
+    assert ps.shape == (N, 32) and ps.dtype == torch.int32
+    want = O.cma_topk(crit.nce_average.view1_mem.cpu(), crit.nce_average.view2_mem.cpu(), 32, "consensus")
+    agree = np.mean([len(set(ps[i].tolist()) & set(want[i])) for i in range(N)]) / 32
+    assert agree > 0.999
+    assert sorted(crit.state_dict().keys()) == ["criterion.avg_exp_score", "nce_average.positive_set",
+                                                "nce_average.view1_mem", "nce_average.view2_mem"]
+    v = torch.randn(bs, 128, device=gpu_device, requires_grad=True)
+    a = torch.randn(bs, 128, device=gpu_device, requires_grad=True)
+    y = torch.randperm(N)[:bs].to(gpu_device)
+    loss, tb = crit(v, a, y)
+    loss.backward()
+    assert torch.isfinite(loss) and set(tb) == {"Loss/inst-v2a", "Loss/inst-a2v", "Loss/pos-v2v", "Loss/pos-a2a"}
+    crit.set_epoch(5)                                   # resample
+    assert crit.nce_average.positive_set.shape == (N, 32)
