@@ -19,6 +19,17 @@ from . import lib
 from .lib import AvidHipError, ConvDesc
 
 _WS = {}
+_SIDE = {}
+OVERLAP_IN_CAPTURE = bool(int(__import__('os').environ.get('AVID_OVERLAP_IN_CAPTURE', '0')))
+OVERLAP_WGRAD = bool(int(__import__('os').environ.get('AVID_OVERLAP_WGRAD', '0')))     # run wgrad on a side stream concurrently with dgrad (fills each other's tail waves)
+
+
+def side_stream(device, slot=0):
+    """A per-device helper stream (slot 0: wgrad, slot 1: the audio tower)."""
+    key = (device.index, slot)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 def _stream():
@@ -62,6 +73,31 @@ def _kdims(w):
     return (1,) * (3 - len(k)) + k
 
 
+_DESC_CACHE = {}
+_BN_WS_CACHE = {}
+
+
+def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
+    """(ConvDesc, fwd_ws_bytes, dgrad_ws_bytes, wgrad_ws_bytes) — built once per distinct layer geometry."""
+    key = (xs, cin, cout, k, stride, pad, channel_first)
+    hit = _DESC_CACHE.get(key)
+    if hit is None:
+        d = _desc(xs, cin, cout, k, stride, pad, channel_first)
+        hit = (d, lib.raw("avid_conv_fwd_workspace_bytes")(C.byref(d)),
+               0 if channel_first else lib.raw("avid_conv_dgrad_workspace_bytes")(C.byref(d)),
+               lib.raw("avid_conv_wgrad_workspace_bytes")(C.byref(d)))
+        _DESC_CACHE[key] = hit
+    return hit
+
+
+def _bn_ws_bytes(M, Cc):
+    key = (M, Cc)
+    nb = _BN_WS_CACHE.get(key)
+    if nb is None:
+        nb = _BN_WS_CACHE[key] = lib.raw("avid_bn_workspace_bytes")(M, Cc)
+    return nb
+
+
 def _desc(xs, cin, cout, k, stride, pad, channel_first):
     B, Ti, Hi, Wi = xs
     d = ConvDesc()
@@ -98,11 +134,10 @@ class _ConvCL(Function):
             B, Ti, Hi, Wi, c = x.shape
         if c != cin:
             raise AvidHipError(f"conv: input has {c} channels, weight expects {cin}")
-        d = _desc((B, Ti, Hi, Wi), cin, cout, k, stride, pad, channel_first)
+        d, nb, ctx.nb_dgrad, ctx.nb_wgrad = _desc_cached((B, Ti, Hi, Wi), cin, cout, k, stride, pad, channel_first)
         y = torch.empty((B, d.To, d.Ho, d.Wo, cout), dtype=torch.float32, device=x.device)
         if addend is not None and (addend.shape != y.shape or not addend.is_contiguous()):
             raise AvidHipError("conv: addend must be a contiguous tensor of the output shape")
-        nb = lib.raw("avid_conv_fwd_workspace_bytes")(C.byref(d))
         ws = workspace(x.device, nb) if nb else None
         lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(addend), _p(bias), int(relu), _p(y), _p(ws),
                  ws.numel() if ws is not None else 0, _stream())
@@ -122,20 +157,37 @@ class _ConvCL(Function):
             lib.call("avid_relu_bwd", dy.numel(), _p(y), _p(dy), _p(g), st)
             dy = g
         dx = dw = dadd = dbias = None
-        if ctx.needs_input_grad[0]:
-            if ctx.channel_first:
-                raise AvidHipError("conv: input gradient of a channel-first stem is not implemented (never needed)")
-            nb = lib.raw("avid_conv_dgrad_workspace_bytes")(C.byref(d))
-            ws = workspace(x.device, nb)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_dx and ctx.channel_first:
+            raise AvidHipError("conv: input gradient of a channel-first stem is not implemented (never needed)")
+
+        def run_wgrad():
+            ws = workspace(x.device, ctx.nb_wgrad)
+            g = torch.empty_like(w)          # preserve_format keeps the [Cout][k][Cin] memory
+            if g.stride() != w.stride() and not weight_layout_ok(g):
+                raise AvidHipError("conv: empty_like did not preserve the weight layout")
+            lib.call("avid_conv_wgrad", C.byref(d), _p(x), _p(dy), _p(g), _p(ws), ws.numel(), _stream())
+            return g
+
+        side = None
+        if need_dw and need_dx and OVERLAP_WGRAD and (OVERLAP_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()):
+            # dgrad (this stream) and wgrad (side stream) are independent: issue both, join afterwards
+            main = torch.cuda.current_stream()
+            side = side_stream(x.device, 0)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dw = run_wgrad()
+        if need_dx:
+            ws = workspace(x.device, ctx.nb_dgrad)
             dx = torch.empty_like(x)
             lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), None, _p(dx), _p(ws), ws.numel(), st)
-        if ctx.needs_input_grad[1]:
-            nb = lib.raw("avid_conv_wgrad_workspace_bytes")(C.byref(d))
-            ws = workspace(x.device, nb)
-            dw = torch.empty_like(w)          # preserve_format keeps the [Cout][k][Cin] memory
-            if dw.stride() != w.stride() and not weight_layout_ok(dw):
-                raise AvidHipError("conv: empty_like did not preserve the weight layout")
-            lib.call("avid_conv_wgrad", C.byref(d), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), st)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                dw.record_stream(torch.cuda.current_stream())
+                dy.record_stream(side)
+        elif need_dw:
+            dw = run_wgrad()
         if ctx.has_addend and ctx.needs_input_grad[2]:
             dadd = dy
         if ctx.has_bias and ctx.needs_input_grad[3]:
@@ -172,8 +224,7 @@ class _BatchNormCL(Function):
         if training:
             mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
             invstd = torch.empty(Cc, dtype=torch.float32, device=x.device)
-            nb = lib.raw("avid_bn_workspace_bytes")(M, Cc)
-            ws = workspace(x.device, nb)
+            ws = workspace(x.device, _bn_ws_bytes(M, Cc))
             lib.call("avid_bn_fwd_train", M, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv), float(momentum),
                      float(eps), int(relu), _p(y), _p(mean), _p(invstd), _p(ws), ws.numel(), st)
             ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
@@ -193,8 +244,7 @@ class _BatchNormCL(Function):
         dx = torch.empty_like(x)
         dgamma = torch.empty(ctx.C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(ctx.C, dtype=torch.float32, device=x.device)
-        nb = lib.raw("avid_bn_workspace_bytes")(ctx.M, ctx.C)
-        ws = workspace(x.device, nb)
+        ws = workspace(x.device, _bn_ws_bytes(ctx.M, ctx.C))
         lib.call("avid_bn_bwd", ctx.M, ctx.C, _p(x), _p(y), _p(dy), _p(gamma), _p(mean), _p(invstd), int(ctx.relu),
                  _p(dx), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream())
         return dx, dgamma, dbeta, None, None, None, None, None

@@ -20,6 +20,8 @@
 //
 // Reference ops replaced: nn.Conv3d/Conv2d/Linear fwd+bwd — models/video.py:20,
 // models/network_blocks.py:18,20,35,37,40,42,49, models/audio.py:22, models/av_wrapper.py:25.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace avid {
@@ -821,7 +823,8 @@ static IgemmPlan plan_igemm(long long M, int Cd, int nk_total, bool allow_split)
 template <int WM, int WN, int TM, int TN, int MODE>
 static int launch_igemm(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;   // two groups, one stage each
+  static const size_t lds_pad = getenv("AVID_IGEMM_LDS_PAD") ? (size_t)atoi(getenv("AVID_IGEMM_LDS_PAD")) : 0;
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + lds_pad;   // two groups, one stage each (+ tuning pad)
   static bool attr_set = false;
   auto kern = igemm_kernel<WM, WN, TM, TN, MODE>;
   if (!attr_set) {

@@ -67,15 +67,34 @@ class AV_Wrapper(nn.Module):
         else:
             self.out_dim = video_model.out_dim
 
-    def forward(self, video, audio):
-        video_emb = self.video_model(video)
-        video_emb = video_emb.view(video_emb.shape[0], video_emb.shape[1])
-        if self.use_linear_proj:
-            video_emb = self.video_proj(video_emb)
+    overlap_towers = bool(int(__import__('os').environ.get('AVID_OVERLAP_TOWERS', '1')))    # run the (small) audio tower on a side stream under the video tower's tail waves
+
+    def _audio(self, audio):
         audio_emb = self.audio_model(audio)
         audio_emb = audio_emb.view(audio_emb.shape[0], audio_emb.shape[1])
         if self.use_linear_proj:
             audio_emb = self.audio_proj(audio_emb)
+        return audio_emb
+
+    def forward(self, video, audio):
+        side = None
+        if self.overlap_towers and audio.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # The towers are independent until the criterion.  autograd replays each op's backward on the
+            # stream its forward ran on, so the audio backward overlaps the video backward as well.
+            main = torch.cuda.current_stream()
+            side = ops.side_stream(audio.device, 1)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                audio_emb = self._audio(audio)
+        video_emb = self.video_model(video)
+        video_emb = video_emb.view(video_emb.shape[0], video_emb.shape[1])
+        if self.use_linear_proj:
+            video_emb = self.video_proj(video_emb)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            audio_emb.record_stream(torch.cuda.current_stream())
+        else:
+            audio_emb = self._audio(audio)
         return video_emb, audio_emb
 
 
