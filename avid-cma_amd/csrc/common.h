@@ -46,6 +46,14 @@ struct ScopedTimer {
 int sim_gemm_nt(const float* A, const float* Bq, float* C, const float* Cin, int op, long long M, int N, int K,
                 hipStream_t s);
 
+// stem.hip: direct-from-LDS-patch stem convolutions (Cin 3 / 1, 7x7 stride 2)
+bool stem_fwd_supported(const avid_conv_desc* d);
+bool stem_wgrad_supported(const avid_conv_desc* d);
+size_t stem_fwd_ws_bytes(const avid_conv_desc* d);
+size_t stem_wgrad_ws_bytes(const avid_conv_desc* d);
+int stem_fwd(const avid_conv_desc* d, const float* x, const float* w, float* y, void* ws, hipStream_t s);
+int stem_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, hipStream_t s);
+
 // 64-lane wave reductions (DPP/ds_swizzle chosen by the compiler from __shfl_xor).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -926,7 +926,7 @@ using namespace avid;
 extern "C" size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
-  if (!vec) return 0;
+  if (!vec) return stem_fwd_supported(d) ? stem_fwd_ws_bytes(d) : 0;
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
   IgemmPlan pl = plan_igemm(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK), true);
   return pl.nsplit > 1 ? sizeof(float) * (size_t)pl.nsplit * M * d->Cout : 0;
@@ -938,6 +938,8 @@ extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const floa
   int rc = validate(d);
   if (rc) return rc;
   AVID_REQUIRE(x && w && y, AVID_E_BADARG, "conv_fwd: null pointer");
+  if (stem_fwd_supported(d) && !addend && !bias && !relu && ws && ws_bytes >= stem_fwd_ws_bytes(d))
+    return stem_fwd(d, x, w, y, ws, (hipStream_t)stream);
   ConvArgs a;
   fill_common(a, d);
   a.src = x; a.wk = w; a.addend = addend; a.bias = bias; a.dst = y;
@@ -1037,7 +1039,9 @@ static WgradPlan wgrad_plan(const avid_conv_desc* d) {
 extern "C" size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   WgradPlan pl = wgrad_plan(d);
-  return sizeof(float) * (size_t)pl.nsplit * d->Cout * d->kt * d->kh * d->kw * d->Cin;
+  size_t nb = sizeof(float) * (size_t)pl.nsplit * d->Cout * d->kt * d->kh * d->kw * d->Cin;
+  if (stem_wgrad_supported(d) && stem_wgrad_ws_bytes(d) > nb) nb = stem_wgrad_ws_bytes(d);
+  return nb;
 }
 
 extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,
@@ -1045,6 +1049,8 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
   int rc = validate(d);
   if (rc) return rc;
   AVID_REQUIRE(x && dy && dw, AVID_E_BADARG, "conv_wgrad: null pointer");
+  if (stem_wgrad_supported(d) && ws && ws_bytes >= stem_wgrad_ws_bytes(d))
+    return stem_wgrad(d, x, dy, dw, ws, (hipStream_t)stream);
   WgradPlan pl = wgrad_plan(d);
   AVID_REQUIRE(pl.nsplit == 1 || (ws && ws_bytes >= avid_conv_wgrad_workspace_bytes(d)), AVID_E_BADARG,
                "conv_wgrad: workspace too small");

@@ -1,0 +1,378 @@
+// Stem convolutions (models/video.py:20  Conv3d(3,64,(3,7,7),s(1,2,2),p(1,3,3));
+//                    models/audio.py:22  Conv2d(1,64,7,s2,p3)) as a DIRECT convolution from an LDS patch.
+//
+// With Cin = 3 / 1 an im2col row is 441 / 49 scattered scalars, so the generic gather kernel was
+// load-issue bound (61 TF fwd / 46 TF wgrad).  Here a workgroup (8 waves) owns 256 consecutive output
+// pixels of one (b, t) frame, stages the input patch they touch (<= 19 rows x (W + 6) cols x Cin*kt
+// planes, zero padded, read once with coalesced row loads from the reference's channel-first tensor)
+// in LDS, and feeds the fp32 MFMA straight from it:
+//     k' = ((c*kt + dt)*7 + dh)*8 + dw      (dw padded 7 -> 8 with zero weights)
+//     A[pixel i][k'] = patch[plane(c,dt)][2*(ho_i - ho_lo) + dh][2*wo_i + dw]
+// so lane (i, h) reads patch[base_i + rowoff + 2q + h] — one ds_read_b32 per MFMA, no address tables.
+// Weights are repacked once per call to Wt[k'][64] and streamed through a double-buffered 16 KB LDS
+// stage (8 kernel rows per chunk).  441 of the 504 padded k' are useful (87.5 %).
+#include "common.h"
+
+namespace avid {
+
+struct StemArgs {
+  const float* __restrict__ x;    // [B][CIN][Ti][Hi][Wi]
+  const float* __restrict__ wt;   // [R*8][64]  repacked weights
+  float* __restrict__ y;          // [B][To][Ho][Wo][64]
+  const float* __restrict__ w;    // [64][kt][7][7][CIN]  (for wgrad / repack)
+  const float* __restrict__ dy;   // wgrad: [B][To][Ho][Wo][64]
+  float* __restrict__ part;       // wgrad partials [G][64][R*8]
+  int B, Ti, Hi, Wi, Ho, Wo;
+  int PW, rows_in_max, tiles_per_frame;
+  int ntiles;                     // B*Ti*tiles_per_frame
+};
+
+constexpr int STEM_TILE = 256;    // output pixels per workgroup tile
+constexpr int WS_LD = 64 + 4;     // padded weight-stage row
+
+// Wt[k'][n] = w[n][dt][dh][dw][c]   (k' = ((c*KT+dt)*7+dh)*8+dw ; dw == 7 -> 0)
+template <int CIN, int KT>
+__global__ void stem_repack_kernel(const float* __restrict__ w, float* __restrict__ wt) {
+  constexpr int R = CIN * KT * 7;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * 8 * 64) return;
+  const int n = i & 63, kp = i >> 6;
+  const int dw = kp & 7, row = kp >> 3;
+  const int dh = row % 7, pl = row / 7;
+  const int dt = pl % KT, c = pl / KT;
+  wt[i] = dw < 7 ? w[(((n * KT + dt) * 7 + dh) * 7 + dw) * CIN + c] : 0.f;
+}
+
+// patch[plane = c*KT+dt][row][col] ; row 0 <-> hi = 2*ho_lo - 3 ; col 0 <-> wi = -4 (4-float left pad keeps
+// the 16-B row copies aligned on both sides; PW % 4 == 0).  One float4 per (row, 4 cols) work item.
+template <int CIN, int KT>
+__device__ __forceinline__ void stem_load_patch(const StemArgs& p, float* P, int b, int to, int ho_lo, int nrows_in) {
+  const int q4 = p.PW >> 2;                         // float4 slots per patch row
+  const int total = CIN * KT * nrows_in * q4;
+  const bool vec = (p.Wi & 3) == 0;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int cq = e % q4;
+    int r = e / q4;
+    const int row = r % nrows_in;
+    const int pl = r / nrows_in;
+    const int dt = pl % KT, c = pl / KT;
+    const int ti = to + dt - KT / 2, hi = 2 * ho_lo - 3 + row, wi = cq * 4 - 4;
+    const bool rok = ((unsigned)ti < (unsigned)p.Ti) & ((unsigned)hi < (unsigned)p.Hi);
+    const long long rbase = ((((long long)b * CIN + c) * p.Ti + (rok ? ti : 0)) * p.Hi + (rok ? hi : 0)) * p.Wi;
+    floatx4 v = {0.f, 0.f, 0.f, 0.f};
+    if (rok && wi >= 0 && wi + 3 < p.Wi && vec) {
+      v = *reinterpret_cast<const floatx4*>(p.x + rbase + wi);
+    } else if (rok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((unsigned)(wi + j) < (unsigned)p.Wi) v[j] = p.x[rbase + wi + j];
+    }
+    *reinterpret_cast<floatx4*>(P + (long long)r * p.PW + cq * 4) = v;
+  }
+}
+
+constexpr int FWD_TILE = 128;     // forward: 128 pixels / 4 waves per workgroup -> two workgroups per CU
+constexpr int FWD_CH = 4;         // kernel rows per weight chunk (32 k')
+
+template <int CIN, int KT>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs p) {
+  constexpr int R = CIN * KT * 7;             // kernel rows (c, dt, dh)
+  constexpr int NCH = (R + FWD_CH - 1) / FWD_CH;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                           // [2][FWD_CH*8][WS_LD]
+  float* P = smem + 2 * FWD_CH * 8 * WS_LD;   // patch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int tile = blockIdx.x;
+  const int tf = tile % p.tiles_per_frame, frame = tile / p.tiles_per_frame;
+  const int to = frame % p.Ti, b = frame / p.Ti;
+  const int npix = p.Ho * p.Wo;
+  const int p0 = tf * FWD_TILE;
+  const int p1 = min(p0 + FWD_TILE, npix);
+  const int ho_lo = p0 / p.Wo, ho_hi = (p1 - 1) / p.Wo;
+  const int nrows_in = 2 * (ho_hi - ho_lo) + 7;
+
+  // weight chunk: 32 rows x 16 float4 = 512 float4 -> 2 per thread
+  const int wrow = tid >> 4, wcol = (tid & 15) * 4;   // 16 rows per pass
+  floatx4 wv[2];
+  auto load_w = [&](int ch) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kp = ch * FWD_CH * 8 + wrow + 16 * i;
+      const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+      wv[i] = kp < R * 8 ? *reinterpret_cast<const floatx4*>(p.wt + (long long)kp * 64 + wcol) : z;
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<floatx4*>(&Ws[buf * FWD_CH * 8 * WS_LD + (wrow + 16 * i) * WS_LD + wcol]) = wv[i];
+  };
+  load_w(0);
+  stem_load_patch<CIN, KT>(p, P, b, to, ho_lo, nrows_in);
+  store_w(0);
+
+  // this lane's pixel; patch col of tap dw = 2*wo + dw + 1 (4-float left pad, conv pad 3)
+  const int pi = p0 + wave * 32 + l31;
+  const bool pok = pi < p1;
+  const int ho = (pok ? pi : p0) / p.Wo, wo = (pok ? pi : p0) - ho * p.Wo;
+  const int base = (2 * (ho - ho_lo)) * p.PW + 2 * wo + 1 + h;
+  const int plane = nrows_in * p.PW;
+
+  floatx16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  __syncthreads();
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int cur = ch & 1;
+    if (ch + 1 < NCH) load_w(ch + 1);
+    const float* Wb = Ws + cur * FWD_CH * 8 * WS_LD + l31;
+#pragma unroll
+    for (int rr = 0; rr < FWD_CH; ++rr) {
+      const int row = ch * FWD_CH + rr;
+      if (row < R) {   // uniform
+        const int dh = row % 7, pl = row / 7;
+        const float* Pr = P + pl * plane + dh * p.PW + base;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float a = Pr[2 * q];
+          const float b0 = Wb[(rr * 8 + 2 * q + h) * WS_LD];
+          const float b1 = Wb[(rr * 8 + 2 * q + h) * WS_LD + 32];
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        }
+      }
+    }
+    if (ch + 1 < NCH) store_w(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: row = (r&3) + 8*(r>>2) + 4*h within the wave's 32 pixels, col = l31 (+32)
+  const long long m_base = (long long)frame * npix + p0 + wave * 32;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (p0 + wave * 32 + rr < p1) p.y[(m_base + rr) * 64 + j * 32 + l31] = acc[j][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem wgrad: dW[n][k'] = sum_pixels dy[pixel][n] * patch(pixel, k').  Persistent workgroups (one per
+// CU) walk tiles of 256 pixels, keep the 64 x (R*8) accumulator in registers (each of the 8 waves owns
+// 2 n-tiles x NKT k'-tiles), and write one partial slab each; a fixed-order reduce finishes.
+//   A[i = n][k = pixel] = dyS[pixel][n]         (LDS, [256][64+4])
+//   B[k = pixel][j = k'] = patch[pixbase[pixel] + koff(k'_j)]
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int KT>
+__global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
+  constexpr int R = CIN * KT * 7;
+  constexpr int KP = R * 8;                       // padded k' count
+  constexpr int NKT_ALL = (KP + 31) / 32;         // k' tiles of 32
+  constexpr int NKT = (NKT_ALL + 7) / 8;          // k' tiles per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ds = smem;                               // [256][WS_LD]
+  int* pixbase = reinterpret_cast<int*>(smem + STEM_TILE * WS_LD);   // [256]
+  float* P = smem + STEM_TILE * WS_LD + STEM_TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int npix = p.Ho * p.Wo;
+
+  // this lane's k' columns: tile kt = wave + 8*j -> k' = kt*32 + l31 ; koff = patch offset of that tap
+  int koff[NKT];
+  bool kok[NKT];
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) {
+    const int kp = (wave + 8 * j) * 32 + l31;
+    kok[j] = kp < KP && (kp & 7) < 7;
+    koff[j] = 0;
+  }
+
+  floatx16 acc[2][NKT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < NKT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int tf = tile % p.tiles_per_frame, frame = tile / p.tiles_per_frame;
+    const int to = frame % p.Ti, b = frame / p.Ti;
+    const int p0 = tf * STEM_TILE;
+    const int p1 = min(p0 + STEM_TILE, npix);
+    const int ho_lo = p0 / p.Wo, ho_hi = (p1 - 1) / p.Wo;
+    const int nrows_in = 2 * (ho_hi - ho_lo) + 7;
+    const int plane = nrows_in * p.PW;
+    __syncthreads();                               // previous tile fully consumed
+    stem_load_patch<CIN, KT>(p, P, b, to, ho_lo, nrows_in);
+    // dy tile (zero rows past the frame end) + per-pixel patch base
+    for (int e = tid; e < STEM_TILE * 16; e += 512) {
+      const int px = e >> 4, c4 = (e & 15) * 4;
+      const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+      const bool ok = p0 + px < p1;
+      const floatx4 v = *reinterpret_cast<const floatx4*>(p.dy + ((long long)frame * npix + (ok ? p0 + px : p0)) * 64 + c4);
+      *reinterpret_cast<floatx4*>(&Ds[px * WS_LD + c4]) = ok ? v : z;
+    }
+    if (tid < STEM_TILE) {
+      const int pi = min(p0 + tid, p1 - 1);
+      const int ho = pi / p.Wo, wo = pi - ho * p.Wo;
+      pixbase[tid] = (2 * (ho - ho_lo)) * p.PW + 2 * wo + 1;
+    }
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int kp = (wave + 8 * j) * 32 + l31;
+      const int dw = kp & 7, row = kp >> 3;
+      const int dh = row % 7, pl = row / 7;
+      koff[j] = kok[j] ? pl * plane + dh * p.PW + dw : 0;
+    }
+    __syncthreads();
+    for (int kk = 0; kk < STEM_TILE / 2; ++kk) {
+      const int px = 2 * kk + h;
+      const float a0 = Ds[px * WS_LD + l31], a1 = Ds[px * WS_LD + 32 + l31];
+      const int pb = pixbase[px];
+#pragma unroll
+      for (int j = 0; j < NKT; ++j) {
+        const float bv = kok[j] ? P[pb + koff[j]] : 0.f;
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][j], 0, 0, 0);
+      }
+    }
+  }
+  // partial slab [blockIdx.x][n][k']
+  float* o = p.part + (long long)blockIdx.x * 64 * KP;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int kp = (wave + 8 * j) * 32 + l31;
+      if (kp < KP) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          o[(long long)n * KP + kp] = acc[t][j][r];
+        }
+      }
+    }
+}
+
+// dw[n][dt][dh][dw][c] = sum_g part[g][n][k'(c,dt,dh,dw)]
+template <int CIN, int KT>
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int G) {
+  constexpr int R = CIN * KT * 7, KP = R * 8;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over n * K (K = R*7)
+  if (i >= 64 * R * 7) return;
+  const int c = i % CIN;
+  int r = i / CIN;
+  const int dwi = r % 7; r /= 7;
+  const int dh = r % 7; r /= 7;
+  const int dt = r % KT;
+  const int n = r / KT;
+  const int kp = (((c * KT + dt) * 7 + dh) * 8) + dwi;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += part[((long long)g * 64 + n) * KP + kp];
+  dw[i] = s;
+}
+
+static bool stem_match(const avid_conv_desc* d) {
+  return d->x_channel_first && d->Cout == 64 && d->kh == 7 && d->kw == 7 && d->sh == 2 && d->sw == 2 && d->st == 1 &&
+         d->ph == 3 && d->pw == 3 && ((d->Cin == 3 && d->kt == 3 && d->pt == 1) || (d->Cin == 1 && d->kt == 1 && d->pt == 0)) &&
+         d->To == d->Ti;
+}
+
+static void stem_geometry(const avid_conv_desc* d, StemArgs& a, int tile) {
+  a.B = d->B; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.PW = (d->Wi + 4 + 4 + 3) / 4 * 4;                       // 4 left pad + >= 4 right pad (taps reach wi = W+3)
+  const int npix = d->Ho * d->Wo;
+  a.tiles_per_frame = (npix + tile - 1) / tile;
+  const int rows_out = (tile - 1 + d->Wo - 1) / d->Wo + 1;
+  a.rows_in_max = 2 * (rows_out - 1) + 7;
+  a.ntiles = d->B * d->Ti * a.tiles_per_frame;
+}
+
+size_t stem_patch_floats(const avid_conv_desc* d, int tile) {
+  StemArgs a;
+  stem_geometry(d, a, tile);
+  return (size_t)d->Cin * d->kt * a.rows_in_max * a.PW + 16;
+}
+
+static size_t stem_fwd_lds(const avid_conv_desc* d) {
+  return sizeof(float) * (2 * FWD_CH * 8 * WS_LD + stem_patch_floats(d, FWD_TILE));
+}
+static size_t stem_wgrad_lds(const avid_conv_desc* d) {
+  return sizeof(float) * (STEM_TILE * WS_LD + STEM_TILE + stem_patch_floats(d, STEM_TILE));
+}
+
+bool stem_fwd_supported(const avid_conv_desc* d) { return stem_match(d) && stem_fwd_lds(d) <= 160 * 1024; }
+bool stem_wgrad_supported(const avid_conv_desc* d) { return stem_match(d) && stem_wgrad_lds(d) <= 160 * 1024; }
+
+size_t stem_fwd_ws_bytes(const avid_conv_desc* d) { return sizeof(float) * (size_t)d->Cin * d->kt * 7 * 8 * 64; }
+int stem_wgrad_groups() { return 256; }
+size_t stem_wgrad_ws_bytes(const avid_conv_desc* d) {
+  return sizeof(float) * (size_t)stem_wgrad_groups() * 64 * d->Cin * d->kt * 7 * 8;
+}
+
+template <int CIN, int KT>
+static int stem_fwd_launch(const avid_conv_desc* d, const float* x, const float* w, float* y, void* ws, hipStream_t s) {
+  StemArgs a{};
+  stem_geometry(d, a, FWD_TILE);
+  a.x = x; a.w = w; a.y = y; a.wt = static_cast<float*>(ws);
+  constexpr int R = CIN * KT * 7;
+  hipLaunchKernelGGL((stem_repack_kernel<CIN, KT>), dim3((R * 8 * 64 + 255) / 256), dim3(256), 0, s, w,
+                     static_cast<float*>(ws));
+  const size_t lds = stem_fwd_lds(d);
+  static bool set = false;
+  if (!set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<CIN, KT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    set = true;
+  }
+  const double M = (double)d->B * d->To * d->Ho * d->Wo, K = (double)CIN * KT * 49;
+  ScopedTimer t(s, CIN == 3 ? "stem_fwd_kernel<3,3>" : "stem_fwd_kernel<1,1>", 2.0 * M * 64 * K,
+                4.0 * ((double)d->B * CIN * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
+  hipLaunchKernelGGL((stem_fwd_kernel<CIN, KT>), dim3(a.ntiles), dim3(256), lds, s, a);
+  return check_launch("stem_fwd");
+}
+
+template <int CIN, int KT>
+static int stem_wgrad_launch(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,
+                             hipStream_t s) {
+  StemArgs a{};
+  stem_geometry(d, a, STEM_TILE);
+  a.x = x; a.dy = dy; a.part = static_cast<float*>(ws);
+  int G = stem_wgrad_groups();
+  if (G > a.ntiles) G = a.ntiles;
+  const size_t lds = stem_wgrad_lds(d);
+  static bool set = false;
+  if (!set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_kernel<CIN, KT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    set = true;
+  }
+  const double M = (double)d->B * d->To * d->Ho * d->Wo, K = (double)CIN * KT * 49;
+  {
+    ScopedTimer t(s, CIN == 3 ? "stem_wgrad_kernel<3,3>" : "stem_wgrad_kernel<1,1>", 2.0 * M * 64 * K,
+                  4.0 * ((double)d->B * CIN * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
+    hipLaunchKernelGGL((stem_wgrad_kernel<CIN, KT>), dim3(G), dim3(512), lds, s, a);
+  }
+  int rc = check_launch("stem_wgrad");
+  if (rc) return rc;
+  const int n = 64 * CIN * KT * 49;
+  hipLaunchKernelGGL((stem_wgrad_reduce_kernel<CIN, KT>), dim3((n + 255) / 256), dim3(256), 0, s,
+                     static_cast<const float*>(ws), dw, G);
+  return check_launch("stem_wgrad_reduce");
+}
+
+int stem_fwd(const avid_conv_desc* d, const float* x, const float* w, float* y, void* ws, hipStream_t s) {
+  return d->Cin == 3 ? stem_fwd_launch<3, 3>(d, x, w, y, ws, s) : stem_fwd_launch<1, 1>(d, x, w, y, ws, s);
+}
+int stem_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, hipStream_t s) {
+  return d->Cin == 3 ? stem_wgrad_launch<3, 3>(d, x, dy, dw, ws, s) : stem_wgrad_launch<1, 1>(d, x, dy, dw, ws, s);
+}
+
+}  // namespace avid
