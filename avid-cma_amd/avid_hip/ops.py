@@ -222,12 +222,12 @@ class _BatchNormCL(Function):
         y = torch.empty_like(x)
         st = _stream()
         if training:
-            mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
-            invstd = torch.empty(Cc, dtype=torch.float32, device=x.device)
+            stats4 = torch.empty((4, Cc), dtype=torch.float32, device=x.device)   # mean, invstd, scale, shift
             ws = workspace(x.device, _bn_ws_bytes(M, Cc))
             lib.call("avid_bn_fwd_train", M, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv), float(momentum),
-                     float(eps), int(relu), _p(y), _p(mean), _p(invstd), _p(ws), ws.numel(), st)
-            ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+                     float(eps), int(relu), _p(y), _p(stats4[0]), _p(stats4[1]), _p(stats4[2]), _p(stats4[3]), _p(ws),
+                     ws.numel(), st)
+            ctx.save_for_backward(x, gamma, stats4)
         else:
             lib.call("avid_bn_fwd_eval", M, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv), float(eps), int(relu),
                      _p(y), st)
@@ -239,14 +239,14 @@ class _BatchNormCL(Function):
     def backward(ctx, dy):
         if not ctx.training:
             raise AvidHipError("bn: backward through eval-mode BatchNorm is not implemented")
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, gamma, stats4 = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dgamma = torch.empty(ctx.C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(ctx.C, dtype=torch.float32, device=x.device)
         ws = workspace(x.device, _bn_ws_bytes(ctx.M, ctx.C))
-        lib.call("avid_bn_bwd", ctx.M, ctx.C, _p(x), _p(y), _p(dy), _p(gamma), _p(mean), _p(invstd), int(ctx.relu),
-                 _p(dx), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream())
+        lib.call("avid_bn_bwd", ctx.M, ctx.C, _p(x), _p(dy), _p(gamma), _p(stats4[0]), _p(stats4[1]), _p(stats4[2]),
+                 _p(stats4[3]), int(ctx.relu), _p(dx), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream())
         return dx, dgamma, dbeta, None, None, None, None, None
 
 

@@ -46,6 +46,12 @@ struct ConvArgs {
   int epi_op;  // how `addend` combines: 0 add, 1 min, 2 max (CMA agreement scores)
   int nsplit, ksteps_per_split;
   long long ssB, ssT, ssH, ssW, ssC;  // gather-path source strides (elements)
+  // Strided dgrad only: destination pixels are processed per stride-parity class (only taps of matching
+  // parity contribute), each class a dense sub-problem with its own tap subset.
+  int ncls, cls_ptiles_total;
+  int cls_begin[9];                     // first pair-tile of class c (prefix sums)
+  int cls_p0[8][3], cls_n[8][3];        // first position / position count per (t,h,w)
+  int cls_d0[8][3], cls_nd[8][3];       // first tap / tap count per (t,h,w) (tap step = stride)
 };
 
 constexpr int BK = 32;
@@ -81,10 +87,11 @@ __device__ __forceinline__ floatx4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsign
 // stays busy without relying on two co-resident workgroups happening to drift out of phase
 // (measured before: both in phase => pipe 52 % busy, SQ_WAIT_INST_ANY 60 %).
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, int MODE>
+template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
 __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int PA = BM / 32, PB = BN / 32;
+  static_assert(!STRIDED || MODE == 1, "parity classes are a dgrad construct");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);   // wave-uniform by construction
@@ -94,21 +101,38 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
   const int lrow = tid >> 3, lcol = (tid & 7) * 4;
 
   // XCD-aware tile order: consecutive M-tiles (which share input halos) stay on one XCD's L2.
-  const unsigned ntm = (p.M + BM - 1) / BM, ntm2 = (ntm + 1) / 2, ntn = p.Cd / BN, ntiles = ntm2 * ntn;
+  const unsigned ntm = (p.M + BM - 1) / BM, ntn = p.Cd / BN;
+  const unsigned ntm2 = STRIDED ? (unsigned)p.cls_ptiles_total : (ntm + 1) / 2, ntiles = ntm2 * ntn;
   const unsigned lin = xcd_remap(blockIdx.x, ntiles * p.nsplit);
   const unsigned split = lin / ntiles, tile = lin - split * ntiles;
-  const int m0 = ((tile / ntn) * 2 + grp) * BM, n0 = (tile % ntn) * BN;
+  const int n0 = (tile % ntn) * BN;
+  int m0 = ((tile / ntn) * 2 + grp) * BM;     // first row of this group's tile (class-local row when STRIDED)
 
   const int ntaps = p.kt * p.kh * p.kw;
   const int cpt = p.Cs / BK;
-  const int nk_total = ntaps * cpt;
+  // class geometry (trivial single class unless STRIDED)
+  int cT = p.Td, cH = p.Hd, cW = p.Wd, cM = p.M;
+  int p0t = 0, p0h = 0, p0w = 0, d0t = 0, d0h = 0, d0w = 0, ndt = p.kt, ndh = p.kh, ndw = p.kw;
+  if (STRIDED) {
+    const int ptile = tile / ntn;
+    int c = 0;
+    while (c + 1 < p.ncls && ptile >= p.cls_begin[c + 1]) ++c;
+    m0 = ((ptile - p.cls_begin[c]) * 2 + grp) * BM;
+    cT = p.cls_n[c][0]; cH = p.cls_n[c][1]; cW = p.cls_n[c][2];
+    cM = p.B * cT * cH * cW;
+    p0t = p.cls_p0[c][0]; p0h = p.cls_p0[c][1]; p0w = p.cls_p0[c][2];
+    d0t = p.cls_d0[c][0]; d0h = p.cls_d0[c][1]; d0w = p.cls_d0[c][2];
+    ndt = p.cls_nd[c][0]; ndh = p.cls_nd[c][1]; ndw = p.cls_nd[c][2];
+  }
+  const int nk_total = STRIDED ? ndt * ndh * ndw * cpt : ntaps * cpt;
   const int ks0 = split * p.ksteps_per_split;
   const int ks1 = min(ks0 + p.ksteps_per_split, nk_total);
+  int* drow = reinterpret_cast<int*>(smem + 2 * (BM + BN) * LDK) + grp * BM;   // STRIDED: tile row -> dst row
 
   // Buffer descriptors.  A: based at the first batch item this group touches, so 32-bit byte
   // offsets are enough for any tensor size.  B: the (small) weight tensor.
   const int pix_per_b = p.Ts * p.Hs * p.Ws;
-  int b_lo = m0 / (p.Td * p.Hd * p.Wd);
+  int b_lo = m0 / (cT * cH * cW);
   if (b_lo >= p.B) b_lo = p.B - 1;            // group past the end of M: every row is masked anyway
   const long long a_base = (long long)b_lo * pix_per_b * p.Cs;
   long long a_bytes = ((long long)p.B * pix_per_b * p.Cs - a_base) * 4;
@@ -126,7 +150,11 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
   for (int i = 0; i < PA; ++i) {
     int b, td, hd, wd;
     bool ok;
-    decode_row(m0 + lrow + 32 * i, p.M, p.Wd, p.Hd, p.Td, b, td, hd, wd, ok);
+    decode_row(m0 + lrow + 32 * i, cM, cW, cH, cT, b, td, hd, wd, ok);
+    if (STRIDED) {   // class-local coordinates -> destination pixel
+      td = p0t + td * p.st; hd = p0h + hd * p.sh; wd = p0w + wd * p.sw;
+      if ((tid & 7) == 0) drow[lrow + 32 * i] = ok ? ((b * p.Td + td) * p.Hd + hd) * p.Wd + wd : -1;
+    }
     if (MODE == 0) {
       a_t0[i] = td * p.st - p.pt;
       a_h0[i] = hd * p.sh - p.ph;
@@ -169,9 +197,11 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
   floatx4 va[PA], vb[PB];
 
   auto load_tile = [&](int ks) {
-    const int tap = ks / cpt, c0 = (ks - tap * cpt) * BK;
-    const int dw = tap % p.kw, r = tap / p.kw;
-    const int dh = r % p.kh, dt = r / p.kh;
+    const int tapi = ks / cpt, c0 = (ks - tapi * cpt) * BK;
+    int dw = tapi % ndw, r = tapi / ndw;
+    int dh = r % ndh, dt = r / ndh;
+    if (STRIDED) { dt = d0t + dt * p.st; dh = d0h + dh * p.sh; dw = d0w + dw * p.sw; }
+    const int tap = (dt * p.kh + dh) * p.kw + dw;
     const unsigned tap_off = (MODE == 0 ? (unsigned)(((dt * p.Hs + dh) * p.Ws + dw) * cs4) : 0u) + c0 * 4;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
@@ -211,10 +241,12 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
   const float* Ab = As + (wm * TM * 32 + l31) * LDK + h * 4;
   const float* Bb = Bs + (wn * TN * 32 + l31) * LDK + h * 4;
 
-  // prologue: tile ks0 -> LDS, tile ks0+1 -> registers
-  load_tile(ks0);
-  store_tile();
-  if (ks0 + 1 < ks1) load_tile(ks0 + 1);
+  // prologue: tile ks0 -> LDS, tile ks0+1 -> registers  (a parity class may have no taps at all)
+  if (ks0 < ks1) {
+    load_tile(ks0);
+    store_tile();
+    if (ks0 + 1 < ks1) load_tile(ks0 + 1);
+  }
   __syncthreads();
   if (grp == 1) __syncthreads();   // shift group 1 by one phase
 
@@ -256,8 +288,9 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
       const float bv = (direct && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < p.M) {
+        const int trow = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int row = STRIDED ? drow[trow] : m0 + trow;
+        if (STRIDED ? row >= 0 : row < p.M) {
           const long long o = (long long)row * p.Cd + col;
           float v = acc[i][j][r] + bv;
           if (direct) {
@@ -820,31 +853,74 @@ static IgemmPlan plan_igemm(long long M, int Cd, int nk_total, bool allow_split)
   return pl;
 }
 
-template <int WM, int WN, int TM, int TN, int MODE>
+template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
 static int launch_igemm(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  static const size_t lds_pad = getenv("AVID_IGEMM_LDS_PAD") ? (size_t)atoi(getenv("AVID_IGEMM_LDS_PAD")) : 0;
-  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + lds_pad;   // two groups, one stage each (+ tuning pad)
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + sizeof(int) * 2 * BM;   // two groups, one stage each
   static bool attr_set = false;
-  auto kern = igemm_kernel<WM, WN, TM, TN, MODE>;
+  auto kern = igemm_kernel<WM, WN, TM, TN, MODE, STRIDED>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const unsigned ntm = (a.M + BM - 1) / BM, ntn = a.Cd / BN;
   static char name[64] = "";
-  if (!name[0]) snprintf(name, sizeof(name), "igemm_kernel<%d,%d,%d,%d,%d>", WM, WN, TM, TN, MODE);
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, MODE, STRIDED ? "s2" : "");
   const double K = (double)a.kt * a.kh * a.kw * a.Cs;
   // algorithmic work: 2*M*N*K flops; bytes = one read of src + weights, one write of dst (+ addend)
   const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
   ScopedTimer t(s, name, 2.0 * a.M * a.Cd * K,
                 4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (a.addend ? 2 : 1)));
-  hipLaunchKernelGGL(kern, dim3(((ntm + 1) / 2) * ntn * a.nsplit), dim3(512), lds, s, a);
+  const unsigned ptiles = STRIDED ? (unsigned)a.cls_ptiles_total : (ntm + 1) / 2;
+  hipLaunchKernelGGL(kern, dim3(ptiles * ntn * a.nsplit), dim3(512), lds, s, a);
   return check_launch("igemm");
+}
+
+// Parity-class table of a strided dgrad (strides are 1 or 2 per axis).
+static void build_classes(ConvArgs& a, int BM) {
+  const int S[3] = {a.st, a.sh, a.sw}, P[3] = {a.pt, a.ph, a.pw}, Kd[3] = {a.kt, a.kh, a.kw}, D[3] = {a.Td, a.Hd, a.Wd};
+  int np[3];
+  for (int x = 0; x < 3; ++x) np[x] = S[x];   // number of parities along axis x
+  a.ncls = 0;
+  int begin = 0;
+  for (int ct = 0; ct < np[0]; ++ct)
+    for (int ch = 0; ch < np[1]; ++ch)
+      for (int cw = 0; cw < np[2]; ++cw) {
+        const int c[3] = {ct, ch, cw};
+        const int k = a.ncls;
+        long long pixels = a.B;
+        for (int x = 0; x < 3; ++x) {
+          if (S[x] == 1) {
+            a.cls_p0[k][x] = 0; a.cls_n[k][x] = D[x]; a.cls_d0[k][x] = 0; a.cls_nd[k][x] = Kd[x];
+          } else {   // positions p with (p + pad) % 2 == c ; taps d with d % 2 == c
+            const int p0 = (c[x] + P[x]) & 1;
+            a.cls_p0[k][x] = p0;
+            a.cls_n[k][x] = p0 < D[x] ? (D[x] - p0 + 1) / 2 : 0;
+            a.cls_d0[k][x] = c[x];
+            a.cls_nd[k][x] = c[x] < Kd[x] ? (Kd[x] - c[x] + 1) / 2 : 0;
+          }
+          pixels *= a.cls_n[k][x];
+        }
+        if (pixels == 0) continue;
+        a.cls_begin[k] = begin;
+        begin += (int)((((pixels + BM - 1) / BM) + 1) / 2);
+        a.ncls++;
+      }
+  a.cls_begin[a.ncls] = begin;
+  a.cls_ptiles_total = begin;
 }
 
 template <int MODE>
 static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (MODE == 1 && (a.st > 1 || a.sh > 1 || a.sw > 1)) {   // strided dgrad: per-parity-class dense sub-problems
+    a.nsplit = 1;
+    a.ksteps_per_split = 1 << 30;
+    a.part = nullptr;
+    build_classes(a, 128);
+    if (a.Cd % 128 == 0 && (long long)a.cls_ptiles_total * (a.Cd / 128) >= 2 * 256)
+      return launch_igemm<2, 2, 2, 2, 1, true>(a, s);
+    return launch_igemm<4, 1, 1, 2, 1, true>(a, s);
+  }
   const int nk_total = a.kt * a.kh * a.kw * (a.Cs / BK);
   IgemmPlan pl = plan_igemm(a.M, a.Cd, nk_total, true);
   if (pl.nsplit > 1 && (ws == nullptr || ws_bytes < sizeof(float) * (size_t)pl.nsplit * a.M * a.Cd)) {
@@ -899,6 +975,8 @@ static void fill_common(ConvArgs& a, const avid_conv_desc* d) {
   a.ksteps_per_split = 1 << 30;
   a.part = nullptr;
   a.epi_op = 0;
+  a.ncls = 1;
+  a.cls_ptiles_total = 0;
 }
 
 // C[M][N] = A[M][K] . Bq[N][K]^T, optionally combined with Cin by min / max — the similarity GEMMs of
@@ -914,7 +992,7 @@ int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin,
   a.M = (int)M;
   a.src = A; a.wk = Bq; a.addend = Cin; a.bias = nullptr; a.dst = Cout_;
   a.mode = 0; a.relu = 0; a.epi_op = op;
-  a.nsplit = 1; a.ksteps_per_split = 1 << 30; a.part = nullptr;
+  a.nsplit = 1; a.ksteps_per_split = 1 << 30; a.part = nullptr; a.ncls = 1; a.cls_ptiles_total = 0;
   a.ssB = a.ssT = a.ssH = a.ssW = a.ssC = 0;
   return launch_igemm<4, 1, 1, 2, 0>(a, s);
 }

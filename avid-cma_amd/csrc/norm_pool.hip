@@ -139,9 +139,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const floatx4 v = reinterpret_cast<const floatx4*>(x)[i];
     const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g];
     const floatx4 sh = reinterpret_cast<const floatx4*>(shift)[g];
-    floatx4 o = v * sc + sh;
-    if (relu) {
-      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    floatx4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = fmaf(v[j], sc[j], sh[j]);   // explicit fma: the backward kernels recompute exactly this for the ReLU mask
+      if (relu) o[j] = fmaxf(o[j], 0.f);
     }
     reinterpret_cast<floatx4*>(y)[i] = o;
   }
@@ -173,7 +175,9 @@ __global__ __launch_bounds__(256) void bn_apply_eval_kernel(const float* __restr
 }
 
 // backward partials: part[blk][0][C] = sum dy_m, part[blk][1][C] = sum dy_m * xhat
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
                                                              const float* __restrict__ dy,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, float* __restrict__ part,
@@ -187,16 +191,17 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   if (r < rows_per_pass) {
     const floatx4 mu = reinterpret_cast<const floatx4*>(mean)[g];
     const floatx4 is = reinterpret_cast<const floatx4*>(invstd)[g];
+    const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g];
+    const floatx4 sh = reinterpret_cast<const floatx4*>(shift)[g];
     for (int k = r; k < rows_per_block; k += rows_per_pass) {
       const long long row = row0 + k;
       if (row < M) {
         const long long o = row * C + g * 4;
         floatx4 d = *reinterpret_cast<const floatx4*>(dy + o);
         const floatx4 xv = *reinterpret_cast<const floatx4*>(x + o);
-        if (relu) {
-          const floatx4 yv = *reinterpret_cast<const floatx4*>(y + o);
+        if (relu) {   // ReLU mask recomputed from x with the forward's exact fma (no read of the saved output)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) d[j] = yv[j] > 0.f ? d[j] : 0.f;
+          for (int j = 0; j < 4; ++j) d[j] = fmaf(xv[j], sc[j], sh[j]) > 0.f ? d[j] : 0.f;
         }
         s += d;
         sx += d * ((xv - mu) * is);
@@ -233,7 +238,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 }
 
 // dx = gamma*invstd * (dy_m - mean(dy_m) - xhat * mean(dy_m*xhat))
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
                                                            const float* __restrict__ dy, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ k1,
@@ -245,9 +252,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     floatx4 d = reinterpret_cast<const floatx4*>(dy)[i];
     const floatx4 xv = reinterpret_cast<const floatx4*>(x)[i];
     if (relu) {
-      const floatx4 yv = reinterpret_cast<const floatx4*>(y)[i];
+      const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g];
+      const floatx4 sh = reinterpret_cast<const floatx4*>(shift)[g];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[j] = yv[j] > 0.f ? d[j] : 0.f;
+      for (int j = 0; j < 4; ++j) d[j] = fmaf(xv[j], sc[j], sh[j]) > 0.f ? d[j] : 0.f;
     }
     const floatx4 mu = reinterpret_cast<const floatx4*>(mean)[g];
     const floatx4 is = reinterpret_cast<const floatx4*>(invstd)[g];
@@ -422,17 +430,18 @@ static int bn_check(int64_t M, int C, const char* who) {
 
 extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, int relu,
-                                 float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
-                                 avid_stream_t stream) {
+                                 float* y, float* save_mean, float* save_invstd, float* save_scale,
+                                 float* save_shift, void* ws, size_t ws_bytes, avid_stream_t stream) {
   int rc = bn_check(M, C, "bn_fwd_train");
   if (rc) return rc;
-  AVID_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, AVID_E_BADARG, "bn_fwd_train: null pointer");
+  AVID_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && save_scale && save_shift && ws, AVID_E_BADARG,
+               "bn_fwd_train: null pointer");
   AVID_REQUIRE(ws_bytes >= avid_bn_workspace_bytes(M, C), AVID_E_BADARG, "bn_fwd_train: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   BnPlan p = bn_plan(M, C);
   float* part = static_cast<float*>(ws);
-  float* scale = part + (size_t)p.nblk * 2 * C;
-  float* shift = scale + C;
+  float* scale = save_scale;
+  float* shift = save_shift;
   {
     ScopedTimer t(s, "bn_stats_partial_kernel", 0.0, 4.0 * M * C);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
@@ -460,14 +469,15 @@ extern "C" int avid_bn_fwd_eval(int64_t M, int C, const float* x, const float* g
   return check_launch("bn_fwd_eval");
 }
 
-extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* y, const float* dy, const float* gamma,
-                           const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
-                           float* dbeta, void* ws, size_t ws_bytes, avid_stream_t stream) {
+extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, const float* gamma,
+                           const float* save_mean, const float* save_invstd, const float* save_scale,
+                           const float* save_shift, int relu, float* dx, float* dgamma, float* dbeta, void* ws,
+                           size_t ws_bytes, avid_stream_t stream) {
   int rc = bn_check(M, C, "bn_bwd");
   if (rc) return rc;
   AVID_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, AVID_E_BADARG,
                "bn_bwd: null pointer");
-  AVID_REQUIRE(!relu || y, AVID_E_BADARG, "bn_bwd: relu needs the saved output y");
+  AVID_REQUIRE(!relu || (save_scale && save_shift), AVID_E_BADARG, "bn_bwd: relu needs the saved scale/shift");
   AVID_REQUIRE(ws_bytes >= avid_bn_workspace_bytes(M, C), AVID_E_BADARG, "bn_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   BnPlan p = bn_plan(M, C);
@@ -475,16 +485,18 @@ extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* y, con
   float* k1 = part + (size_t)p.nblk * 2 * C;
   float* k2 = k1 + C;
   {
-    ScopedTimer t(s, "bn_bwd_partial_kernel", 0.0, 4.0 * M * C * (relu ? 3 : 2));
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, y, dy, save_mean, save_invstd, part,
+    ScopedTimer t(s, "bn_bwd_partial_kernel", 0.0, 4.0 * M * C * 2);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, save_scale, save_shift, dy, save_mean,
+                       save_invstd, part,
                        (long long)M, C, p.G, p.rows_per_pass, p.rows_per_block, relu);
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64 * FIN_SLICES), 0, s, part, p.nblk,
                      (long long)M, C, dgamma, dbeta, k1, k2);
   const long long n4 = (long long)M * p.G;
   {
-    ScopedTimer t(s, "bn_bwd_apply_kernel", 0.0, 4.0 * M * C * (relu ? 4 : 3));
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, x, y, dy, gamma, save_mean,
+    ScopedTimer t(s, "bn_bwd_apply_kernel", 0.0, 4.0 * M * C * 3);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, x, save_scale, save_shift, dy, gamma,
+                       save_mean,
                        save_invstd, k1, k2, dx, n4, p.G, relu);
   }
   return check_launch("bn_bwd");

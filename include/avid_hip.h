@@ -93,20 +93,22 @@ int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const float* dy, fl
  * ---------------------------------------------------------------------------------------------- */
 size_t avid_bn_workspace_bytes(int64_t M, int C);
 /* Train: batch mean / biased var -> save_mean, save_invstd [C]; running stats updated in place
- * (momentum, unbiased var); y = [relu](gamma * (x - mean) * invstd + beta). */
+ * (momentum, unbiased var); y = [relu](fma(x, scale, shift)) with scale = gamma * invstd,
+ * shift = beta - mean * scale, both also saved ([C]) so backward can recompute the ReLU mask bit-exactly. */
 int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps, int relu,
-                      float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
-                      avid_stream_t stream);
+                      float* y, float* save_mean, float* save_invstd, float* save_scale,
+                      float* save_shift, void* ws, size_t ws_bytes, avid_stream_t stream);
 /* Eval: uses running stats. */
 int avid_bn_fwd_eval(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                      const float* running_mean, const float* running_var, float eps, int relu,
                      float* y, avid_stream_t stream);
-/* Backward of train-mode BN(+ReLU): y is the saved forward output (ReLU mask = y > 0). */
-int avid_bn_bwd(int64_t M, int C, const float* x, const float* y, const float* dy,
-                const float* gamma, const float* save_mean, const float* save_invstd, int relu,
-                float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                avid_stream_t stream);
+/* Backward of train-mode BN(+ReLU).  The ReLU mask is fma(x, scale, shift) > 0 recomputed from the conv
+ * output x (the forward's exact expression), so the saved activation is not re-read: 2 + 3 passes. */
+int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, const float* gamma,
+                const float* save_mean, const float* save_invstd, const float* save_scale,
+                const float* save_shift, int relu, float* dx, float* dgamma, float* dbeta, void* ws,
+                size_t ws_bytes, avid_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pooling.  MaxPool3d((1,3,3),(1,2,2),(0,1,1)) — models/video.py:23;  AdaptiveMaxPool{3,2}d(1) —
