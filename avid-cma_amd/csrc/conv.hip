@@ -500,7 +500,161 @@ struct WgradArgs {
 constexpr int WG_LD = 64 + 4;
 
 template <int NB, int KC>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(512) void wgrad_kernel(const WgradArgs p) {
+  // Ping-pong like igemm_kernel: two groups of 4 waves, each reducing its own pixel range (split
+  // 2*blockIdx.y + grp) of the same dw tile through a private single-buffered LDS stage, shifted by one
+  // phase so one wave per SIMD is always in its MFMA phase.
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int DW = 64 * NB + 4;                 // dy tile row (floats)
+  constexpr int STAGE = 32 * (DW + KC * WG_LD);   // one group's stage
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  float* Ds = smem + grp * STAGE;
+  float* Xs = Ds + 32 * DW;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntaps = p.kt * p.kh * p.kw;
+  const int K = ntaps * p.Cs;
+  const int cpt = p.Cs / 64, nchunks = ntaps * cpt;
+
+  const int ktile = blockIdx.x % p.kt_tiles, ntile = blockIdx.x / p.kt_tiles;
+  const int n0 = ntile * 64 * NB;
+  // the KC (tap, c0) chunks of this k tile (uniform)
+  int q_tap[KC], q_c0[KC], q_dt[KC], q_dh[KC], q_dw[KC];
+  bool q_ok[KC];
+#pragma unroll
+  for (int j = 0; j < KC; ++j) {
+    const int q = ktile * KC + j;
+    q_ok[j] = q < nchunks;
+    const int qq = q_ok[j] ? q : 0;
+    q_tap[j] = qq / cpt;
+    q_c0[j] = (qq - q_tap[j] * cpt) * 64;
+    q_dw[j] = q_tap[j] % p.kw;
+    const int r = q_tap[j] / p.kw;
+    q_dh[j] = r % p.kh;
+    q_dt[j] = r / p.kh;
+  }
+
+  const int split = blockIdx.y * 2 + grp;
+  const int total_chunks = (p.M + 31) / 32;
+  const int chunk0 = min(split * p.chunks_per_split, total_chunks);
+  const int nloop = p.chunks_per_split;           // both groups run the same trip count (barriers!)
+
+  // buffer descriptors (dy and x based at the first batch item this split touches)
+  const int pix_out = p.Td * p.Hd * p.Wd, pix_in = p.Ts * p.Hs * p.Ws;
+  int b_lo = (chunk0 * 32) / pix_out;
+  if (b_lo >= p.B) b_lo = p.B - 1;
+  const long long x_base = (long long)b_lo * pix_in * p.Cs;
+  long long x_bytes = ((long long)p.B * pix_in * p.Cs - x_base) * 4;
+  if (x_bytes > 0x7fffffffll) x_bytes = 0x7fffffffll;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + x_base), 0, (int)x_bytes, 0x00020000);
+  const long long d_base = (long long)min(chunk0 * 32, p.M - 1) * p.Cd;
+  long long d_bytes = ((long long)p.M * p.Cd - d_base) * 4;
+  if (d_bytes > 0x7fffffffll) d_bytes = 0x7fffffffll;
+  const __amdgpu_buffer_rsrc_t rsD =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + d_base), 0, (int)d_bytes, 0x00020000);
+
+  const int lrow = tid >> 4;         // 0..15 (+16)
+  const int lcol = (tid & 15) * 4;   // 0..60
+  const int cs4 = p.Cs * 4;
+
+  floatx4 vd[2][NB], vx[2][KC];
+
+  auto load_chunk = [&](int it) {     // it = chunk index relative to chunk0
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mrel = it * 32 + lrow + 16 * i;   // row relative to the split base
+      const int m = chunk0 * 32 + mrel;
+      int b, td, hd, wd;
+      bool ok;
+      decode_row(m, p.M, p.Wd, p.Hd, p.Td, b, td, hd, wd, ok);
+      const unsigned doff = (unsigned)(mrel * p.Cd + n0 + lcol) * 4;
+#pragma unroll
+      for (int t = 0; t < NB; ++t) vd[i][t] = buf_load4(rsD, ok ? doff + t * 256 : OOB);
+      const int t0 = td * p.st - p.pt, h0 = hd * p.sh - p.ph, w0 = wd * p.sw - p.pw;
+#pragma unroll
+      for (int j = 0; j < KC; ++j) {
+        const int ts = t0 + q_dt[j], hs = h0 + q_dh[j], ws = w0 + q_dw[j];
+        const bool okx = ok & q_ok[j] & ((unsigned)ts < (unsigned)p.Ts) & ((unsigned)hs < (unsigned)p.Hs) &
+                         ((unsigned)ws < (unsigned)p.Ws);
+        const unsigned off = (unsigned)((((b - b_lo) * p.Ts + ts) * p.Hs + hs) * p.Ws + ws) * cs4 +
+                             (q_c0[j] + lcol) * 4;
+        vx[i][j] = buf_load4(rsX, okx ? off : OOB);
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+        *reinterpret_cast<floatx4*>(&Ds[(lrow + 16 * i) * DW + t * 64 + lcol]) = vd[i][t];
+#pragma unroll
+      for (int j = 0; j < KC; ++j)
+        *reinterpret_cast<floatx4*>(&Xs[j * 32 * WG_LD + (lrow + 16 * i) * WG_LD + lcol]) = vx[i][j];
+    }
+  };
+
+  floatx16 acc[NB][KC];
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+  const int h = lane >> 5, l31 = lane & 31;
+  const float* Db = Ds + wm * 32 * NB + l31;
+  const float* Xb = Xs + wn * 32 + l31;
+
+  load_chunk(0);
+  store_chunk();
+  if (1 < nloop) load_chunk(1);
+  __syncthreads();
+  if (grp == 1) __syncthreads();
+  for (int it = 0; it < nloop; ++it) {
+    // phase A: matrix pipe
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[NB], b[KC];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) a[t] = Db[(2 * kk + h) * DW + t * 32];             // A[i = n][k = m]
+#pragma unroll
+      for (int j = 0; j < KC; ++j) b[j] = Xb[j * 32 * WG_LD + (2 * kk + h) * WG_LD];  // B[k = m][j = c]
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int j = 0; j < KC; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[j], acc[t][j], 0, 0, 0);
+    }
+    __syncthreads();
+    // phase B: stage
+    if (it + 1 < nloop) {
+      store_chunk();
+      if (it + 2 < nloop) load_chunk(it + 2);
+    }
+    __syncthreads();
+  }
+  if (grp == 0) __syncthreads();
+
+  if (split >= p.nsplit) return;                  // odd split count: the partner group had no slab
+  float* o = p.out + (long long)split * p.Cd * K;
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      if (!q_ok[j]) continue;
+      const int kcol = q_tap[j] * p.Cs + q_c0[j] + wn * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 32 * NB + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        o[(long long)n * K + kcol] = acc[t][j][r];
+      }
+    }
+}
+
+// Double-buffered 4-wave variant (one split per workgroup): used for the 128x128 tile, whose 64
+// accumulator registers do not leave room for two 8-wave workgroups per CU.
+template <int NB, int KC>
+__global__ __launch_bounds__(256) void wgrad_db_kernel(const WgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int DW = 64 * NB + 4;                 // dy tile row (floats)
   constexpr int BUF = 32 * (DW + KC * WG_LD);     // one stage
@@ -1100,10 +1254,10 @@ static WgradPlan wgrad_plan(const avid_conv_desc* d) {
   }
   const long long tiles = (long long)pl.kt_tiles * pl.n_tiles;
   const long long chunks = ceil_div(M, 32);
-  long long want = (2 * 256) / tiles;                     // fill 2 workgroups per CU, never one more
+  long long want = (pl.vec && pl.NB == 1 ? 2 : 1) * ((2 * 256) / tiles);   // ping-pong workgroups take two splits
   long long max_split = chunks / 8 > 0 ? chunks / 8 : 1;  // >= 8 chunks (256 rows) per split
   long long ns = want < 1 ? 1 : (want > max_split ? max_split : want);
-  if (ns > 256) ns = 256;
+  if (ns > 512) ns = 512;
   // 32-bit byte offsets inside one split: (batch items touched) * bytes per input item < 2 GiB
   const long long pix_out = (long long)d->To * d->Ho * d->Wo;
   const long long per_b_in = (long long)d->Ti * d->Hi * d->Wi * d->Cin * 4;
@@ -1145,6 +1299,7 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
   a.nsplit = pl.nsplit; a.chunks_per_split = pl.cps; a.kt_tiles = pl.kt_tiles;
   fill_src_strides(d, a.ssB, a.ssT, a.ssH, a.ssW, a.ssC);
   dim3 grid((unsigned)(pl.kt_tiles * pl.n_tiles), (unsigned)pl.nsplit);
+  dim3 grid_pp((unsigned)(pl.kt_tiles * pl.n_tiles), (unsigned)((pl.nsplit + 1) / 2));   // two splits per workgroup
   {
     const double K = (double)a.kt * a.kh * a.kw * a.Cs;
     const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
@@ -1154,23 +1309,23 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
       const size_t lds = sizeof(float) * 4 * 32 * WG_LD + sizeof(int2) * 64;
       hipLaunchKernelGGL(wgrad_gather_kernel, grid, dim3(256), lds, s, a);
     } else if (pl.NB == 1) {
-      const size_t lds = sizeof(float) * 2 * 32 * (64 * 1 + 4 + 3 * WG_LD);
+      const size_t lds = sizeof(float) * 2 * 32 * (64 * 1 + 4 + 3 * WG_LD);   // two groups, one stage each
       static bool set = false;
       if (!set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1, 3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         set = true;
       }
-      hipLaunchKernelGGL((wgrad_kernel<1, 3>), grid, dim3(256), lds, s, a);
+      hipLaunchKernelGGL((wgrad_kernel<1, 3>), grid_pp, dim3(512), lds, s, a);
     } else {
       const size_t lds = sizeof(float) * 2 * 32 * (64 * 2 + 4 + 2 * WG_LD);
       static bool set = false;
       if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<2, 2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_db_kernel<2, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         set = true;
       }
-      hipLaunchKernelGGL((wgrad_kernel<2, 2>), grid, dim3(256), lds, s, a);
+      hipLaunchKernelGGL((wgrad_db_kernel<2, 2>), grid, dim3(256), lds, s, a);
     }
   }
   rc = check_launch("wgrad");
