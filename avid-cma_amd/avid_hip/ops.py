@@ -20,7 +20,7 @@ from .lib import AvidHipError, ConvDesc
 
 _WS = {}
 _SIDE = {}
-OVERLAP_IN_CAPTURE = bool(int(__import__('os').environ.get('AVID_OVERLAP_IN_CAPTURE', '0')))
+OVERLAP_IN_CAPTURE = bool(int(__import__('os').environ.get('AVID_OVERLAP_IN_CAPTURE', '1')))
 OVERLAP_WGRAD = bool(int(__import__('os').environ.get('AVID_OVERLAP_WGRAD', '0')))     # run wgrad on a side stream concurrently with dgrad (fills each other's tail waves)
 
 

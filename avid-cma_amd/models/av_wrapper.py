@@ -78,7 +78,8 @@ class AV_Wrapper(nn.Module):
 
     def forward(self, video, audio):
         side = None
-        if self.overlap_towers and audio.is_cuda and not torch.cuda.is_current_stream_capturing():
+        capturing = audio.is_cuda and torch.cuda.is_current_stream_capturing()
+        if self.overlap_towers and audio.is_cuda and (ops.OVERLAP_IN_CAPTURE or not capturing):
             # The towers are independent until the criterion.  autograd replays each op's backward on the
             # stream its forward ran on, so the audio backward overlaps the video backward as well.
             main = torch.cuda.current_stream()
@@ -92,7 +93,8 @@ class AV_Wrapper(nn.Module):
             video_emb = self.video_proj(video_emb)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
-            audio_emb.record_stream(torch.cuda.current_stream())
+            if not capturing:
+                audio_emb.record_stream(torch.cuda.current_stream())
         else:
             audio_emb = self._audio(audio)
         return video_emb, audio_emb
