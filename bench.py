@@ -121,6 +121,9 @@ def main():
     sync()
     # Per-kernel HIP-event pass (events on the launch stream, library-side): a few eager steps of the same
     # workload OUTSIDE the timed region, so the instrumentation does not perturb `value`.
+    # The pass runs single-stream (tower overlap off) so an event pair brackets exactly one kernel.
+    overlap = model.overlap_towers
+    model.overlap_towers = False
     lib.timing_enable(True)
     kern_steps = min(3, args.steps)
     for i in range(kern_steps):
@@ -128,6 +131,7 @@ def main():
     torch.cuda.synchronize()
     kern = lib.timing_report()
     lib.timing_enable(False)
+    model.overlap_towers = overlap
     if use_graph:
         engine.capture(video, audio, ids[0])
         engine.replay(index=ids[0])
@@ -154,6 +158,12 @@ def main():
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         d = mfma[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        # HBM traffic of the dominant kernel from the committed PMC passes (tools/pmc.sh + tools/pmc_traffic.py:
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note, + WRITE_SIZE), bytes per launch
+        traffic = None
+        tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(dom)
         conv_ms = sum(v["ms"] for v in mfma.values()) / kern_steps
         conv_tf = sum(v["flops"] for v in mfma.values()) / (sum(v["ms"] for v in mfma.values()) * 1e-3) / 1e12
         out = {
@@ -168,7 +178,8 @@ def main():
                        "hipgraph": use_graph,
                        "loss": round(loss_val, 5)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                          "launches_per_step": d["launches"] / kern_steps,
                          "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                          "all_conv_kernels": {"ms_per_step": round(conv_ms, 3), "achieved": round(conv_tf, 2),

@@ -1,0 +1,25 @@
+"""profiles/<pmc_summary>.csv (+ the kernel trace of the same run for launch counts) -> profiles/pmc_traffic.json:
+HBM bytes per launch per kernel = (2 * FETCH_SIZE + WRITE_SIZE) KiB / launches  (FETCH_SIZE is doubled as
+MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is uncalibrated there and taken as is)."""
+import csv, json, re, sys, collections
+summary, trace, out = sys.argv[1], sys.argv[2], sys.argv[3]
+calls = collections.Counter()
+for r in csv.DictReader(open(trace)):
+    calls[r["Kernel_Name"].split("(")[0]] += 1
+res = {}
+for r in csv.DictReader(open(summary)):
+    name = r["kernel"].replace(";", ",")
+    key = next((k for k in calls if k.replace(" ", "")[:60] == name.replace(" ", "")[:60]), None)
+    n = calls.get(key, 0)
+    if not n: continue
+    m = re.match(r"(?:void )?avid::(\w+)(?:<(.*)>)?", name)
+    if not m: continue
+    short = m.group(1)
+    if m.group(2):
+        args = [a.strip() for a in m.group(2).split(",")]
+        strided = args[-1] == "true" if args[-1] in ("true", "false") else False
+        if args[-1] in ("true", "false"): args = args[:-1]
+        short += "<" + ",".join(args) + ">" + ("s2" if strided else "")
+    res[short] = round((2 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024 / n)
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+print(json.dumps(res, indent=1, sort_keys=True))
