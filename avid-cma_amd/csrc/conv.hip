@@ -948,13 +948,12 @@ static int validate(const avid_conv_desc* d) {
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
   const long long Mi = (long long)d->B * d->Ti * d->Hi * d->Wi;
   AVID_REQUIRE(M < (1ll << 31) && Mi < (1ll << 31), AVID_E_UNSUPPORTED, "conv: more than 2^31 pixels");
-  // 32-bit byte offsets inside one workgroup's batch span (<= 128 rows + one batch item)
-  const long long per_b_in = (long long)d->Ti * d->Hi * d->Wi * d->Cin * 4;
-  const long long per_b_out = (long long)d->To * d->Ho * d->Wo * d->Cout * 4;
-  AVID_REQUIRE(per_b_in * 130 < (1ll << 31) || per_b_in < (1ll << 24), AVID_E_UNSUPPORTED,
-               "conv: one batch item of x is too large for 32-bit tile offsets");
-  AVID_REQUIRE(per_b_out * 130 < (1ll << 31) || per_b_out < (1ll << 24), AVID_E_UNSUPPORTED,
-               "conv: one batch item of y is too large for 32-bit tile offsets");
+  // 32-bit byte offsets inside one group's batch span: a 128-row tile touches at most 128/pixels + 2 items
+  const long long pix_in = (long long)d->Ti * d->Hi * d->Wi, pix_out = (long long)d->To * d->Ho * d->Wo;
+  const long long span_in = (128 / pix_out + 2) * pix_in * d->Cin * 4;      // fwd / wgrad read x
+  const long long span_out = (128 / pix_in + 2) * pix_out * d->Cout * 4;    // dgrad reads dy
+  AVID_REQUIRE(span_in < (1ll << 31) && span_out < (1ll << 31), AVID_E_UNSUPPORTED,
+               "conv: one batch item is too large for 32-bit tile offsets");
   return AVID_OK;
 }
 

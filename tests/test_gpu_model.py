@@ -401,3 +401,37 @@ def test_avid_cma_constructor_end_to_end(gpu_device):
     assert torch.isfinite(loss) and set(tb) == {"Loss/inst-v2a", "Loss/inst-a2v", "Loss/pos-v2v", "Loss/pos-a2a"}
     crit.set_epoch(5)                                   # resample
     assert crit.nce_average.positive_set.shape == (N, 32)
+
+
+def test_real_dataset_shapes_vs_oracle(gpu_device):
+    """the shipped configs feed 3x8x224x224 video and 1x200x257 audio
+    (configs/main/avid/kinetics/Cross-N1024.yaml:19-25): odd extents (257 -> 129 -> 65 -> 33 -> 17) hit the
+    tile-edge paths, 224^2 the stem's fallback selection.  One clip pair, forward + backward vs the oracle
+    with the device's ReLU pattern pinned."""
+    m = _build_model(gpu_device).train()
+    video = T(detgen.det_normalish("real:video", (1, 3, 8, 224, 224)))
+    audio = T(detgen.det_normalish("real:audio", (1, 1, 200, 257)))
+    video = torch.cat([video, video.flip(4)]); audio = torch.cat([audio, audio.flip(2)])     # 2 clips
+    masks, remove = capture_relu_masks(m)
+    e1, e2 = m(video.to(gpu_device), audio.to(gpu_device))
+    remove()
+    gv = T(detgen.det_uniform("real:gv", (2, 128))).to(gpu_device)
+    ga = T(detgen.det_uniform("real:ga", (2, 128))).to(gpu_device)
+    ((e1 * gv).sum() + (e2 * ga).sum()).backward()
+    P = O.det_state(O.av_wrapper_spec(18), "w")
+    for n in P:
+        if not ("running" in n or "num_batches" in n):
+            P[n].requires_grad_(True)
+    O.RELU_MASKS = masks
+    try:
+        ve, ae = O.av_forward(video, audio, P, 18, True)
+        ((ve * gv.cpu()).sum() + (ae * ga.cpu()).sum()).backward()
+    finally:
+        O.RELU_MASKS = None
+    assert float((e1.detach().cpu() - ve.detach()).abs().max() / ve.detach().abs().max()) < 2e-4
+    assert float((e2.detach().cpu() - ae.detach()).abs().max() / ae.detach().abs().max()) < 2e-4
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        a, r = p.grad.contiguous().cpu().double(), P[n].grad.double()
+        worst = max(worst, (n, float((a - r).abs().max() / (r.abs().max() + 1e-30))), key=lambda t: t[1])
+    assert worst[1] < 1e-3, worst

@@ -80,3 +80,37 @@ def test_nce_checkpoint_shape_quirk():
     assert c.avg_exp_score.shape == ()
     c.load_state_dict({"avg_exp_score": torch.tensor([3.5])})     # reference stores shape (1,) after step 1
     assert c.avg_exp_score.shape == () and float(c.avg_exp_score) == 3.5
+
+
+def test_reference_factories_resolve_build_classes():
+    """The drop-in claim end to end on the host: with avid-cma_amd ahead of the reference checkout on
+    sys.path, the reference's OWN factories (utils/main_utils.py:74-94, :231-238) build this repo's
+    classes from the reference's own YAML config.  Skipped where the reference is absent (GPU box)."""
+    import importlib
+    import os
+    import sys
+    import pytest
+    import yaml
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkout not present")
+    sys.path.append(ref)                                   # AFTER ours (conftest put avid-cma_amd first)
+    try:
+        for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+            del sys.modules[k]
+        main_utils = importlib.import_module("utils.main_utils")          # the reference's file
+        assert main_utils.__file__.startswith(ref)
+        cfg = yaml.safe_load(open(os.path.join(ref, "configs/main/avid/kinetics/Cross-N1024.yaml")))
+        model = main_utils.build_model(cfg["model"])
+        import models
+        assert type(model).__module__ == "models.av_wrapper" and models.__file__.startswith(os.path.dirname(ref) + "/repo") \
+            or "avid-cma_amd" in models.__file__
+        assert model.out_dim == 128 and len(model.state_dict()) == 267
+        from utils.alias_method import AliasMethod
+        assert "avid-cma_amd" in sys.modules["utils.alias_method"].__file__ and AliasMethod(torch.ones(5)).uniform
+        import criterions
+        assert "avid-cma_amd" in criterions.__file__ and cfg["loss"]["name"] in criterions.__dict__
+    finally:
+        sys.path.remove(ref)
+        for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+            del sys.modules[k]
