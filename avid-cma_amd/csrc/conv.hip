@@ -20,6 +20,7 @@
 //
 // Reference ops replaced: nn.Conv3d/Conv2d/Linear fwd+bwd — models/video.py:20,
 // models/network_blocks.py:18,20,35,37,40,42,49, models/audio.py:22, models/av_wrapper.py:25.
+#include <math.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -45,6 +46,8 @@ struct ConvArgs {
   int relu;
   int epi_op;  // how `addend` combines: 0 add, 1 min, 2 max (CMA agreement scores)
   int nsplit, ksteps_per_split;
+  int mt2_begin, mt2_count;           // window of M pair-tiles this launch covers (tail launches split K)
+  int part_row_begin;                 // first destination row of the partial slabs
   long long ssB, ssT, ssH, ssW, ssC;  // gather-path source strides (elements)
   // Strided dgrad only: destination pixels are processed per stride-parity class (only taps of matching
   // parity contribute), each class a dense sub-problem with its own tap subset.
@@ -101,10 +104,10 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
   const int lrow = tid >> 3, lcol = (tid & 7) * 4;
 
   // XCD-aware tile order: consecutive M-tiles (which share input halos) stay on one XCD's L2.
-  const unsigned ntm = (p.M + BM - 1) / BM, ntn = p.Cd / BN;
-  const unsigned ntm2 = STRIDED ? (unsigned)p.cls_ptiles_total : (ntm + 1) / 2, ntiles = ntm2 * ntn;
+  const unsigned ntn = p.Cd / BN;
+  const unsigned ntm2 = STRIDED ? (unsigned)p.cls_ptiles_total : (unsigned)p.mt2_count, ntiles = ntm2 * ntn;
   const unsigned lin = xcd_remap(blockIdx.x, ntiles * p.nsplit);
-  const unsigned split = lin / ntiles, tile = lin - split * ntiles;
+  const unsigned split = lin / ntiles, tile = lin - split * ntiles + (STRIDED ? 0u : (unsigned)p.mt2_begin * ntn);
   const int n0 = (tile % ntn) * BN;
   int m0 = ((tile / ntn) * 2 + grp) * BM;     // first row of this group's tile (class-local row when STRIDED)
 
@@ -251,21 +254,33 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
   if (grp == 1) __syncthreads();   // shift group 1 by one phase
 
   for (int ks = ks0; ks < ks1; ++ks) {
-    // ---- phase A: matrix pipe
+    // ---- phase A: matrix pipe.  Fragments of k-group g+1 are fetched BEFORE the MFMAs of group g are
+    // issued (order pinned with sched_barrier: the compiler otherwise sinks the ds_reads to just before
+    // their use and exposes the LDS latency four times per phase).
+    floatx4 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const floatx4*>(Bb + j * 32 * LDK);
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
-      floatx4 af[TM], bf[TN];
+      if (g + 1 < BK / 8) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK + g * 8);
+        for (int i = 0; i < TM; ++i)
+          af[(g + 1) & 1][i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK + (g + 1) * 8);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const floatx4*>(Bb + j * 32 * LDK + g * 8);
+        for (int j = 0; j < TN; ++j)
+          bf[(g + 1) & 1][j] = *reinterpret_cast<const floatx4*>(Bb + j * 32 * LDK + (g + 1) * 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][s], bf[g & 1][j][s], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     // ---- phase B: stage (the partner group is in its phase A)
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const bool direct = p.nsplit == 1;
-  float* outp = direct ? p.dst : p.part + (long long)split * p.M * p.Cd;
+  float* outp = direct ? p.dst : p.part + ((long long)split * (p.M - p.part_row_begin) - p.part_row_begin) * p.Cd;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -974,6 +989,17 @@ static void fill_src_strides(const avid_conv_desc* d, long long& sB, long long& 
   }
 }
 
+static int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
 // ---- tile / split-K plan (shared by the launcher, the workspace query and the name query)
 struct IgemmPlan {
   int tile;    // 0: 128x128, 1: 128x64, 3: 64x64
@@ -1016,17 +1042,44 @@ static int launch_igemm(const ConvArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  const unsigned ntm = (a.M + BM - 1) / BM, ntn = a.Cd / BN;
+  const unsigned ntn = a.Cd / BN;
   static char name[64] = "";
   if (!name[0]) snprintf(name, sizeof(name), "igemm_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, MODE, STRIDED ? "s2" : "");
   const double K = (double)a.kt * a.kh * a.kw * a.Cs;
   // algorithmic work: 2*M*N*K flops; bytes = one read of src + weights, one write of dst (+ addend)
   const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
-  ScopedTimer t(s, name, 2.0 * a.M * a.Cd * K,
-                4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (a.addend ? 2 : 1)));
-  const unsigned ptiles = STRIDED ? (unsigned)a.cls_ptiles_total : (ntm + 1) / 2;
+  const double frac = STRIDED ? 1.0 : fmin(1.0, (double)a.mt2_count * 2 * BM / (double)a.M) *
+                                          (a.mt2_begin > 0 ? ((double)a.M - a.part_row_begin) / ((double)a.mt2_count * 2 * BM) : 1.0);
+  ScopedTimer t(s, name, frac * 2.0 * a.M * a.Cd * K,
+                frac * 4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (a.addend ? 2 : 1)));
+  const unsigned ptiles = STRIDED ? (unsigned)a.cls_ptiles_total : (unsigned)a.mt2_count;
   hipLaunchKernelGGL(kern, dim3(ptiles * ntn * a.nsplit), dim3(512), lds, s, a);
   return check_launch("igemm");
+}
+
+// Tail split of a launch with more workgroups than resident slots (see dispatch_igemm).
+struct TailPlan {
+  int tail_m, f;
+  long long tail_rows;
+};
+static TailPlan plan_tail(const IgemmPlan& pl, long long M, int Cd, int nk_total) {
+  TailPlan t{0, 1, 0};
+  if (pl.nsplit > 1) return t;
+  const int ntn = Cd / pl.BN;
+  const int mt2 = (int)(((M + pl.BM - 1) / pl.BM + 1) / 2);
+  const long long slots = (pl.tile == 0 ? 1 : 2) * device_cus();
+  const long long wgs = (long long)mt2 * ntn;
+  const int slots_m = (int)(slots / ntn);
+  if (wgs <= slots || slots_m <= 0) return t;
+  const int tail_m = mt2 % slots_m;
+  if (tail_m == 0) return t;
+  int f = (int)(slots / ((long long)tail_m * ntn));
+  if (f > nk_total / 3) f = nk_total / 3;
+  if (f < 2 || nk_total < 12) return t;   // short K loops: the extra prologue + slab pass costs more than the idle round
+  t.tail_m = tail_m;
+  t.f = f;
+  t.tail_rows = M - (long long)(mt2 - tail_m) * 2 * pl.BM;
+  return t;
 }
 
 // Parity-class table of a strided dgrad (strides are 1 or 2 per axis).
@@ -1079,23 +1132,52 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
   if (pl.nsplit > 1 && (ws == nullptr || ws_bytes < sizeof(float) * (size_t)pl.nsplit * a.M * a.Cd)) {
     pl = plan_igemm(a.M, a.Cd, nk_total, false);  // no scratch: single pass
   }
+  auto launch = [&](ConvArgs& x) {
+    switch (pl.tile) {
+      case 0: return launch_igemm<2, 2, 2, 2, MODE>(x, s);
+      case 1: return launch_igemm<4, 1, 1, 2, MODE>(x, s);
+      default: return launch_igemm<2, 2, 1, 1, MODE>(x, s);
+    }
+  };
+  auto reduce = [&](const ConvArgs& x, int nsplit) {
+    const long long rows = x.M - x.part_row_begin, n4 = rows * x.Cd / 4;
+    long long grid = ceil_div(n4, 256);
+    if (grid > 2048) grid = 2048;
+    const long long off = (long long)x.part_row_begin * x.Cd;
+    ScopedTimer t(s, "splitk_reduce_kernel", 0.0, 4.0 * rows * x.Cd * (nsplit + 1 + (x.addend ? 1 : 0)));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, x.part, x.dst + off,
+                       x.addend ? x.addend + off : nullptr, x.bias, n4, x.Cd / 4, nsplit, x.relu);
+    return check_launch("splitk_reduce");
+  };
+  const int ntn = a.Cd / pl.BN;
+  const int mt2 = (int)((((long long)a.M + pl.BM - 1) / pl.BM + 1) / 2);   // M pair-tiles
+  a.mt2_begin = 0;
+  a.mt2_count = mt2;
+  a.part_row_begin = 0;
   a.nsplit = pl.nsplit;
   a.ksteps_per_split = pl.ksteps_per_split;
   a.part = static_cast<float*>(ws);
-  int rc;
-  switch (pl.tile) {
-    case 0: rc = launch_igemm<2, 2, 2, 2, MODE>(a, s); break;
-    case 1: rc = launch_igemm<4, 1, 1, 2, MODE>(a, s); break;
-    default: rc = launch_igemm<2, 2, 1, 1, MODE>(a, s); break;
+  if (pl.nsplit > 1) {   // small-M layer: the whole launch is split-K
+    int rc = launch(a);
+    return rc ? rc : reduce(a, pl.nsplit);
   }
-  if (rc || pl.nsplit == 1) return rc;
-  const long long n4 = (long long)a.M * a.Cd / 4;
-  long long grid = ceil_div(n4, 256);
-  if (grid > 2048) grid = 2048;
-  ScopedTimer t(s, "splitk_reduce_kernel", 0.0, 4.0 * a.M * a.Cd * (pl.nsplit + 1 + (a.addend ? 1 : 0)));
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, a.part, a.dst, a.addend, a.bias, n4,
-                     a.Cd / 4, pl.nsplit, a.relu);
-  return check_launch("splitk_reduce");
+  // Tail split: whole rounds of workgroups run as is; a nearly empty last round (<= half the slots) is cut
+  // in K so that it fills the chip for a fraction of a tile time instead of idling it for a full one.
+  const TailPlan tp = plan_tail(pl, a.M, a.Cd, nk_total);
+  const int tail_m = tp.tail_m, f = tp.f;
+  const bool tail_split = tail_m > 0 && ws != nullptr && ws_bytes >= sizeof(float) * (size_t)f * tp.tail_rows * a.Cd;
+  if (!tail_split) return launch(a);
+  a.mt2_count = mt2 - tail_m;
+  int rc = launch(a);
+  if (rc) return rc;
+  ConvArgs t = a;
+  t.mt2_begin = mt2 - tail_m;
+  t.mt2_count = tail_m;
+  t.part_row_begin = (mt2 - tail_m) * 2 * pl.BM;
+  t.ksteps_per_split = (nk_total + f - 1) / f;
+  t.nsplit = (nk_total + t.ksteps_per_split - 1) / t.ksteps_per_split;
+  rc = launch(t);
+  return rc ? rc : reduce(t, t.nsplit);
 }
 
 static int launch_gather(const ConvArgs& a, hipStream_t s) {
@@ -1130,6 +1212,9 @@ static void fill_common(ConvArgs& a, const avid_conv_desc* d) {
   a.epi_op = 0;
   a.ncls = 1;
   a.cls_ptiles_total = 0;
+  a.mt2_begin = 0;
+  a.mt2_count = 0;
+  a.part_row_begin = 0;
 }
 
 // C[M][N] = A[M][K] . Bq[N][K]^T, optionally combined with Cin by min / max — the similarity GEMMs of
@@ -1146,6 +1231,7 @@ int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin,
   a.src = A; a.wk = Bq; a.addend = Cin; a.bias = nullptr; a.dst = Cout_;
   a.mode = 0; a.relu = 0; a.epi_op = op;
   a.nsplit = 1; a.ksteps_per_split = 1 << 30; a.part = nullptr; a.ncls = 1; a.cls_ptiles_total = 0;
+  a.mt2_begin = 0; a.mt2_count = (int)((((long long)M + 127) / 128 + 1) / 2); a.part_row_begin = 0;
   a.ssB = a.ssT = a.ssH = a.ssW = a.ssC = 0;
   return launch_igemm<4, 1, 1, 2, 0>(a, s);
 }
@@ -1159,8 +1245,11 @@ extern "C" size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d) {
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
   if (!vec) return stem_fwd_supported(d) ? stem_fwd_ws_bytes(d) : 0;
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
-  IgemmPlan pl = plan_igemm(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK), true);
-  return pl.nsplit > 1 ? sizeof(float) * (size_t)pl.nsplit * M * d->Cout : 0;
+  const int nk = d->kt * d->kh * d->kw * (d->Cin / BK);
+  IgemmPlan pl = plan_igemm(M, d->Cout, nk, true);
+  if (pl.nsplit > 1) return sizeof(float) * (size_t)pl.nsplit * M * d->Cout;
+  const TailPlan tp = plan_tail(pl, M, d->Cout, nk);
+  return sizeof(float) * (size_t)tp.f * tp.tail_rows * d->Cout;
 }
 
 extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* addend,
@@ -1191,8 +1280,11 @@ static size_t dgrad_wt_bytes(const avid_conv_desc* d) {
 extern "C" size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
-  IgemmPlan pl = plan_igemm(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK), true);
-  return dgrad_wt_bytes(d) + (pl.nsplit > 1 ? sizeof(float) * (size_t)pl.nsplit * M * d->Cin : 0);
+  const int nk = d->kt * d->kh * d->kw * (d->Cout / BK);
+  IgemmPlan pl = plan_igemm(M, d->Cin, nk, true);
+  if (pl.nsplit > 1) return dgrad_wt_bytes(d) + sizeof(float) * (size_t)pl.nsplit * M * d->Cin;
+  const TailPlan tp = plan_tail(pl, M, d->Cin, nk);
+  return dgrad_wt_bytes(d) + sizeof(float) * (size_t)tp.f * tp.tail_rows * d->Cin;
 }
 
 extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* addend,
