@@ -23,7 +23,12 @@ import torch.distributed as dist
 
 
 def _dist_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """Collectives are in play: more than one rank (or AVID_FORCE_DIST=1, which drives the RCCL path on a
+    single-rank group so it can be exercised on a one-GPU box)."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("AVID_FORCE_DIST", "0") == "1"
 
 
 class FlatParams:
@@ -61,6 +66,7 @@ class GradBuckets:
     def __init__(self, flat: FlatParams, bucket_bytes: int = 16 << 20):
         self.flat = flat
         self.world = dist.get_world_size() if _dist_on() else 1
+        self.comm = _dist_on()
         self.bounds, self.bucket_of = [], []
         start, cur = 0, 0
         for i, (p, o) in enumerate(zip(flat.params, flat.offsets)):
@@ -75,7 +81,7 @@ class GradBuckets:
         self.pending = list(self.counts)
         self.works = []
         self.hooks = []
-        if self.world > 1:
+        if self.comm:
             for i, p in enumerate(flat.params):
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
@@ -86,15 +92,28 @@ class GradBuckets:
             self.pending[b] -= 1
             if self.pending[b] == 0:
                 s, e = self.bounds[b]
+                self._join_producers()
                 self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
         return hook
 
+    def _join_producers(self):
+        """The two towers' backward passes run on two streams (models/av_wrapper.py) and a bucket may hold
+        gradients from both: the stream the collective is issued from must first wait for the other one."""
+        if not self.flat.grad.is_cuda:
+            return
+        from . import ops
+        cur = torch.cuda.current_stream()
+        for st in (torch.cuda.default_stream(self.flat.grad.device), ops.side_stream(self.flat.grad.device, 1)):
+            if st != cur:
+                cur.wait_stream(st)
+
     def finish(self):
         """Launch whatever did not fire (unused parameters) and make the current stream wait for all buckets."""
-        if self.world > 1:
+        if self.comm:
             for b, left in enumerate(self.pending):
                 if left > 0:
                     s, e = self.bounds[b]
+                    self._join_producers()
                     self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
             for w in self.works:
                 w.wait()

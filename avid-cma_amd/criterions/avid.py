@@ -51,6 +51,7 @@ class AVIDSimilarityMemoryBank(nn.Module):
 
         self.distributed = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank() if self.distributed else 0
+        self.multinomial.seed = (self.multinomial.seed + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF  # per-rank negatives
 
         self.init_memory(memory_size, embedding_dim)
 

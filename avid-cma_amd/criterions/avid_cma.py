@@ -59,6 +59,7 @@ class AVIDSimilarityPositiveExpansion(AVIDSimilarityMemoryBank):
                          num_negatives=num_negatives, momentum=momentum, device=device)
         self.num_negatives_within = num_negatives_within
         self.multinomial = AliasMethod(torch.ones(memory_size - sampling_args['pos_k']))
+        self.multinomial.seed = (self.multinomial.seed + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF
         self.multinomial.to(_device_of(device))
         self.sampling_args = sampling_args
 

@@ -435,3 +435,40 @@ def test_real_dataset_shapes_vs_oracle(gpu_device):
         a, r = p.grad.contiguous().cpu().double(), P[n].grad.double()
         worst = max(worst, (n, float((a - r).abs().max() / (r.abs().max() + 1e-30))), key=lambda t: t[1])
     assert worst[1] < 1e-3, worst
+
+
+def test_rccl_path_single_rank(gpu_device):
+    """Drive the multi-GPU code path on the one GPU we have: a 1-rank RCCL group with AVID_FORCE_DIST=1 makes
+    TrainStep broadcast parameters, all-reduce the gradient buckets from the backward hooks (issued from both
+    tower streams) and fold 1/world into Adam.  With world == 1 the result must equal the plain run exactly."""
+    import os
+    import torch.distributed as dist
+    import criterions
+    from avid_hip.parallel import TrainStep
+    bs, N, K = 4, 4000, 128
+    g = torch.Generator().manual_seed(9)
+    video = torch.randn(bs, 3, 8, 64, 64, generator=g).to(gpu_device)
+    audio = torch.randn(bs, 1, 40, 100, generator=g).to(gpu_device)
+    ids = torch.stack([torch.randperm(N, generator=g)[:bs] for _ in range(3)]).to(gpu_device)
+
+    def run():
+        torch.manual_seed(0)
+        m = _build_model(gpu_device).train()
+        crit = criterions.AVID(num_data=N, embedding_dim=128, num_negatives=K, momentum=0.5, device=gpu_device.index)
+        gg = torch.Generator().manual_seed(3)
+        crit.nce_average.view1_mem.copy_(torch.nn.functional.normalize(torch.randn(N, 128, generator=gg), dim=1))
+        crit.nce_average.view2_mem.copy_(torch.nn.functional.normalize(torch.randn(N, 128, generator=gg), dim=1))
+        crit.nce_average.multinomial.reseed(11, 0)
+        e = TrainStep(m, crit, bucket_bytes=4 << 20)
+        return [float(e.step(video, audio, ids[i])) for i in range(3)], e
+
+    plain, _ = run()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", AVID_FORCE_DIST="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+    try:
+        forced, eng = run()
+        assert eng.buckets.comm and len(eng.buckets.bounds) >= 4
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("AVID_FORCE_DIST")
+    assert forced == plain, (forced, plain)
