@@ -23,6 +23,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace avid {
@@ -55,6 +57,12 @@ struct ConvArgs {
   int cls_begin[9];                     // first pair-tile of class c (prefix sums)
   int cls_p0[8][3], cls_n[8][3];        // first position / position count per (t,h,w)
   int cls_d0[8][3], cls_nd[8][3];       // first tap / tap count per (t,h,w) (tap step = stride)
+  unsigned mgW, mgH, mgT;               // multiply-shift division by Wd, Hd, Td (igemm_pk_kernel)
+  int shW, shH, shT;
+  // igemm_pk_kernel work list: tiles [0, pk_full) go round-robin to the workgroups as whole tiles; the
+  // pk_tail_units = tail_tiles * pk_f units after them are (tile, K-range) pieces, one per workgroup, that
+  // write partial slabs to `part` (rows [part_row_begin, M))
+  int pk_full, pk_tail_units, pk_f, pk_kps;
 };
 
 constexpr int BK = 32;
@@ -316,6 +324,341 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
             if (p.relu) v = fmaxf(v, 0.f);
           }
           outp[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent, K-pipelined variant for the big-M layers (conv2x / conv3x forward + unit-stride dgrad).
+//
+// What the hardware rewards (tools/mfma_peak.hip, tools/gemm_lab.hip): an MFMA blocks its own wave's
+// instruction stream for its 64 cycles, so everything that is not an MFMA (address math, LDS and VMEM
+// issue) is paid once per wave and only overlaps with the MFMAs of OTHER waves on the SIMD.  A plain GEMM
+// staged exactly like this kernel reaches 122-134 TFLOP/s; the convolution gets there by making its
+// loader as cheap as the GEMM's:
+//   * per-row voffsets are recomputed only when the filter tap changes (every Cs/32 k-tiles); the channel
+//     block and the weight tap ride in the scalar soffset, so a k-tile issues PA+PB loads and no VALU;
+//   * row decode uses multiply-shift division (magic numbers from the host), once per tile;
+//   * the epilogue is buffer stores whose row step rides in soffset and whose bound is num_records.
+// The workgroup is persistent: it walks tiles slot, slot+G, ... as one flattened (tile, k-tile) stream
+// whose loader runs two k-tiles ahead ACROSS tile boundaries (LDS double-buffered, one barrier per k-tile),
+// so a tile's row decode and first loads hide under the previous tile's last MFMAs and its stores drain
+// under the next tile's.  The host hands it whole rounds of tiles; the remaining rows go to igemm_kernel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned magic_div(unsigned n, unsigned magic, int shift) {
+  return (unsigned)(((unsigned long long)n * magic) >> shift);
+}
+
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArgs p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int RPP = NT / 8;                   // rows staged per pass: 8 lanes x 16 B cover a 32-float row
+  constexpr int PA = BM / RPP, PB = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
+  constexpr int STAGE = (BM + BN) * LDK;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int ntn = p.Cd / BN;
+  const int G = gridDim.x;
+  const int slot = __builtin_amdgcn_readfirstlane((int)xcd_remap(blockIdx.x, G));
+  const int ntaps = p.kt * p.kh * p.kw;
+  const int cpt = p.Cs / BK;
+  const int nk = ntaps * cpt;
+  const int cs4 = p.Cs * 4;
+  const int pix_per_b = p.Ts * p.Hs * p.Ws;
+  const int pix_d = p.Td * p.Hd * p.Wd;
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.wk, 0, (int)((long long)p.Cd * ntaps * p.Cs * 4), 0x00020000);
+
+  // ---- this workgroup's segments: whole tiles slot, slot+G, ... below pk_full, then at most one
+  // (tile, K-range) piece of the split tail
+  const int n_full = slot < p.pk_full ? (p.pk_full - slot + G - 1) / G : 0;
+  const int nseg = n_full + (slot < p.pk_tail_units ? 1 : 0);
+  if (nseg == 0) return;
+  auto seg_info = [&](int j, int& tile, int& k0, int& k1, int& split) {
+    if (j < n_full) {
+      tile = slot + j * G; k0 = 0; k1 = nk; split = -1;
+    } else {
+      tile = p.pk_full + slot / p.pk_f;
+      split = slot % p.pk_f;
+      k0 = split * p.pk_kps;
+      k1 = k0 + p.pk_kps < nk ? k0 + p.pk_kps : nk;
+    }
+  };
+
+  // ---- loader state (two k-tiles ahead of the MFMAs, possibly already in the next segment)
+  int ld_seg = 0, ld_ks = 0, ld_kend = 0;
+  int ld_dt = 0, ld_dh = 0, ld_dw = 0, ld_c0 = 0, ld_tap = 0;   // position in the K loop (tap, channel block)
+  long long ld_base = 0;                                       // element offset of the loader tile's batch span
+  unsigned a_base[PA], a_mask[PA], a_cur[PA];                  // tap-(0,0,0) offset, tap validity, current voffset
+  unsigned b_off[PB];
+  floatx4 va[PA], vb[PB];
+
+  auto range_mask = [](int lo, int hi, int k) -> unsigned {    // bits lo..hi clipped to [0, k)
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > k - 1 ? k - 1 : hi;
+    return hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+  };
+  auto retap = [&]() {   // voffset of every staged row for the loader's current tap (OOB: tap outside the source)
+    const int pixoff = ((ld_dt * p.Hs + ld_dh) * p.Ws + ld_dw) * cs4;
+    const unsigned tap_off = (unsigned)(MODE == 0 ? pixoff : -pixoff);
+    const unsigned sh_t = ld_dt, sh_h = 8 + ld_dh, sh_w = 16 + ld_dw;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const unsigned okb = (a_mask[i] >> sh_t) & (a_mask[i] >> sh_h) & (a_mask[i] >> sh_w) & 1u;
+      a_cur[i] = okb ? a_base[i] + tap_off : OOB;
+    }
+  };
+  auto setup_tile = [&](int tile) {
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    int b_lo = m0 / pix_d;
+    if (b_lo >= p.B) b_lo = p.B - 1;
+    b_lo = __builtin_amdgcn_readfirstlane(b_lo);
+    const long long base = (long long)b_lo * pix_per_b * p.Cs;
+    ld_base = ((long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+              (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const unsigned m = m0 + lrow + RPP * i;
+      const bool ok = m < (unsigned)p.M;
+      const unsigned mm = ok ? m : 0u;
+      const unsigned q1 = magic_div(mm, p.mgW, p.shW);
+      const int wd = mm - q1 * p.Wd;
+      const unsigned q2 = magic_div(q1, p.mgH, p.shH);
+      const int hd = q1 - q2 * p.Hd;
+      const int b = magic_div(q2, p.mgT, p.shT);
+      const int td = q2 - b * p.Td;
+      int t0, h0, w0;
+      unsigned mt_, mh, mw;
+      if (MODE == 0) {   // source coordinate of tap d: t0 + d
+        t0 = td * p.st - p.pt; h0 = hd * p.sh - p.ph; w0 = wd * p.sw - p.pw;
+        mt_ = range_mask(-t0, p.Ts - 1 - t0, p.kt);
+        mh = range_mask(-h0, p.Hs - 1 - h0, p.kh);
+        mw = range_mask(-w0, p.Ws - 1 - w0, p.kw);
+      } else {           // unit-stride dgrad: t0 - d
+        t0 = td + p.pt; h0 = hd + p.ph; w0 = wd + p.pw;
+        mt_ = range_mask(t0 - p.Ts + 1, t0, p.kt);
+        mh = range_mask(h0 - p.Hs + 1, h0, p.kh);
+        mw = range_mask(w0 - p.Ws + 1, w0, p.kw);
+      }
+      a_mask[i] = ok ? (mt_ | (mh << 8) | (mw << 16)) : 0u;
+      a_base[i] = (unsigned)((((b - b_lo) * p.Ts + t0) * p.Hs + h0) * p.Ws + w0) * cs4 + lcol * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + RPP * i) * ntaps * p.Cs + lcol) * 4;
+    retap();
+  };
+  auto issue_loads = [&]() {   // k-tile (ld_tile; tap, channel block) -> registers: PA + PB loads, no VALU
+    // the descriptor and the scalar offsets are pinned to SGPRs here: the compiler's divergence analysis
+    // gives up on this loop-carried state and would wrap every load in a readfirstlane waterfall loop
+    const int base_lo = __builtin_amdgcn_readfirstlane((int)ld_base);
+    const int base_hi = __builtin_amdgcn_readfirstlane((int)(ld_base >> 32));
+    const int soff_a = __builtin_amdgcn_readfirstlane(ld_c0 * 4);
+    const int soff_b = __builtin_amdgcn_readfirstlane((ld_tap * p.Cs + ld_c0) * 4);
+    const long long base = ((long long)base_hi << 32) | (unsigned)base_lo;
+    long long a_bytes = ((long long)p.B * pix_per_b * p.Cs - base) * 4;
+    if (a_bytes > 0x7fffffffll) a_bytes = 0x7fffffffll;
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + base), 0, (int)a_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      va[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_cur[i], soff_a, 0));
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      vb[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], soff_b, 0));
+  };
+  const auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto setup_seg = [&](int j) {
+    int tile, k0, k1, split;
+    seg_info(j, tile, k0, k1, split);
+    ld_ks = sgpr(k0);
+    ld_kend = sgpr(k1);
+    const int tapi = k0 / cpt;
+    ld_c0 = sgpr((k0 - tapi * cpt) * BK);
+    ld_tap = sgpr(tapi);
+    ld_dw = sgpr(tapi % p.kw);
+    const int r = tapi / p.kw;
+    ld_dh = sgpr(r % p.kh);
+    ld_dt = sgpr(r / p.kh);
+    setup_tile(tile);
+  };
+  auto advance = [&]() {
+    ld_ks = sgpr(ld_ks + 1);
+    ld_c0 = sgpr(ld_c0 + BK);
+    if (ld_ks == ld_kend) {          // next segment of this workgroup
+      ld_seg = sgpr(ld_seg + 1);
+      if (ld_seg < nseg) setup_seg(ld_seg);
+    } else if (ld_c0 == p.Cs) {      // next tap
+      ld_c0 = 0;
+      int dw = ld_dw + 1, dh = ld_dh, dt = ld_dt;
+      if (dw == p.kw) { dw = 0; ++dh; }
+      if (dh == p.kh) { dh = 0; ++dt; }
+      ld_dw = sgpr(dw);
+      ld_dh = sgpr(dh);
+      ld_dt = sgpr(dt);
+      ld_tap = sgpr(ld_tap + 1);
+      retap();
+    }
+  };
+  auto store_stage = [&](float* st) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<floatx4*>(&st[(lrow + RPP * i) * LDK + lcol]) = va[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) *reinterpret_cast<floatx4*>(&st[(BM + lrow + RPP * i) * LDK + lcol]) = vb[i];
+  };
+
+  // ---- prologue: k-tile 0 -> LDS stage 0, k-tile 1 -> registers
+  setup_seg(0);
+  issue_loads();
+  advance();
+  store_stage(smem);
+  if (ld_seg < nseg) {              // registers hold the k-tile after the one in LDS
+    issue_loads();
+    advance();
+  }
+  __syncthreads();
+
+  const int a_frag = (wm * TM * 32 + l31) * LDK + h * 4;
+  const int b_frag = (BM + wn * TN * 32 + l31) * LDK + h * 4;
+  int left = n_full * nk;   // k-tiles still to be multiplied, including the one in LDS
+  if (nseg > n_full) {
+    int tile, k0, k1, split;
+    seg_info(n_full, tile, k0, k1, split);
+    left += k1 - k0;
+  }
+  int u = 0;
+  floatx16 acc[TM][TN];
+
+  // One k-tile: 4 k-groups of (fragment prefetch | staging work in the shadow of the group's MFMAs).
+  // ST: the registers hold the next k-tile (write it to the other LDS stage); LD: one more exists (load it).
+  auto ktile = [&](auto ST, auto LD) {
+    const float* cur = smem + u * STAGE;
+    float* nxt = smem + (u ^ 1) * STAGE;
+    const float* Ab = cur + a_frag;
+    const float* Bb = cur + b_frag;
+    floatx4 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const floatx4*>(Bb + j * 32 * LDK);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      if (g + 1 < BK / 8) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[(g + 1) & 1][i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK + (g + 1) * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bf[(g + 1) & 1][j] = *reinterpret_cast<const floatx4*>(Bb + j * 32 * LDK + (g + 1) * 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (decltype(ST)::value && g == 0) store_stage(nxt);
+      if (decltype(LD)::value && g == 1) issue_loads();
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][s], bf[g & 1][j][s], acc[i][j], 0, 0, 0);
+      // issue order inside the group: one staging instruction per MFMA, never a burst
+      if (decltype(ST)::value && g == 0) {
+#pragma unroll
+        for (int q = 0; q < PA + PB; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+        }
+      }
+      if (decltype(LD)::value && g == 1) {
+#pragma unroll
+        for (int q = 0; q < PA + PB; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int row_bytes = p.Cd * 4;
+  for (int j = 0; j < nseg; ++j) {
+    int tile, k0, k1, split;
+    seg_info(j, tile, k0, k1, split);
+    const int nkj = k1 - k0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    // steady state: a k-tile is pending in registers and another one exists beyond it — one straight-line
+    // body; only the last two k-tiles of the workgroup's whole stream take the drain variants.
+    int nst = left - 2 < nkj ? left - 2 : nkj;
+    if (nst < 0) nst = 0;
+    for (int ks = 0; ks < nst; ++ks, u ^= 1) {
+      ktile(std::true_type{}, std::true_type{});
+      advance();
+      __syncthreads();
+    }
+    left -= nst;
+    if (nst < nkj) {
+      if (left == 2) {
+        ktile(std::true_type{}, std::false_type{});
+        __syncthreads();
+        u ^= 1;
+        --left;
+        ++nst;
+      }
+      if (nst < nkj) {
+        ktile(std::false_type{}, std::false_type{});
+        __syncthreads();
+        u ^= 1;
+        --left;
+      }
+    }
+
+    // ---- epilogue of this segment: buffer stores bounded by num_records (rows past M are dropped by the
+    // hardware), the row step in soffset; they drain under the next tile's MFMAs.  A K-split piece writes
+    // its raw partial sums to the slab of its split; splitk_reduce_kernel applies the epilogue.
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    int rows = p.M - m0;
+    rows = rows > BM ? BM : rows;
+    const bool direct = split < 0;
+    const long long d_base = (long long)m0 * p.Cd;
+    const long long s_base = ((long long)split * (p.M - p.part_row_begin) + (m0 - p.part_row_begin)) * p.Cd;
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(direct ? p.dst + d_base : p.part + s_base), 0, rows * row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.addend ? p.addend + d_base : p.dst + d_base), 0, rows * row_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int jj = 0; jj < TN; ++jj) {
+        const int col = n0 + (wn * TN + jj) * 32 + l31;
+        const unsigned voff = (unsigned)(((wm * TM + i) * 32 + 4 * h) * p.Cd + col) * 4;
+        const float bv = (direct && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int soff = ((r & 3) + 8 * (r >> 2)) * row_bytes;
+          float v = acc[i][jj][r] + bv;
+          if (direct) {
+            if (p.addend) {
+              const float ad = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, voff, soff, 0));
+              v = p.epi_op == 0 ? v + ad : (p.epi_op == 1 ? fminf(v, ad) : fmaxf(v, ad));
+            }
+            if (p.relu) v = fmaxf(v, 0.f);
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff, soff, 0);
         }
       }
     }
@@ -1048,13 +1391,106 @@ static int launch_igemm(const ConvArgs& a, hipStream_t s) {
   const double K = (double)a.kt * a.kh * a.kw * a.Cs;
   // algorithmic work: 2*M*N*K flops; bytes = one read of src + weights, one write of dst (+ addend)
   const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
-  const double frac = STRIDED ? 1.0 : fmin(1.0, (double)a.mt2_count * 2 * BM / (double)a.M) *
-                                          (a.mt2_begin > 0 ? ((double)a.M - a.part_row_begin) / ((double)a.mt2_count * 2 * BM) : 1.0);
+  const double row_lo = (double)a.mt2_begin * 2 * BM, row_hi = fmin((double)a.M, row_lo + (double)a.mt2_count * 2 * BM);
+  const double frac = STRIDED ? 1.0 : (row_hi - row_lo) / (double)a.M;
   ScopedTimer t(s, name, frac * 2.0 * a.M * a.Cd * K,
                 frac * 4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (a.addend ? 2 : 1)));
   const unsigned ptiles = STRIDED ? (unsigned)a.cls_ptiles_total : (unsigned)a.mt2_count;
   hipLaunchKernelGGL(kern, dim3(ptiles * ntn * a.nsplit), dim3(512), lds, s, a);
   return check_launch("igemm");
+}
+
+// ---- persistent K-pipelined kernel: whole rounds of tiles + a K-split tail, one launch
+struct PkPlan {
+  int tile;          // 0: 128x128, 1: 128x64 (4 waves, 2 workgroups / CU); 2: 256x128, 3: 256x64 (8 waves, 1 / CU)
+  int BM, BN, grid;
+  int full;          // tiles [0, full) run whole, round-robin over the workgroups
+  int tail_units;    // then tail_tiles * f (tile, K-range) pieces, at most one per workgroup
+  int f, kps;        // K splits per tail tile, k-tiles per split
+  long long tail_row0;   // rows [tail_row0, M) are produced by splitk_reduce_kernel from f slabs
+  size_t ws_floats;
+};
+static bool pk_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("AVID_PK");
+    on = e ? atoi(e) != 0 : 1;
+  }
+  return on != 0;
+}
+static int pk_alt() {
+  static int alt = -1;
+  if (alt < 0) {
+    const char* e = getenv("AVID_PK_ALT");
+    alt = e ? atoi(e) : 0;
+  }
+  return alt;
+}
+static PkPlan plan_pk(long long M, int Cd, int nk) {
+  PkPlan k{};
+  const int cus = device_cus();
+  if (Cd % 128 == 0) {
+    if (pk_alt()) { k.tile = 2; k.BM = 256; k.BN = 128; k.grid = cus; }
+    else          { k.tile = 0; k.BM = 128; k.BN = 128; k.grid = 2 * cus; }
+  } else {
+    if (pk_alt()) { k.tile = 3; k.BM = 256; k.BN = 64; k.grid = cus; }
+    else          { k.tile = 1; k.BM = 128; k.BN = 64; k.grid = 2 * cus; }
+  }
+  const int ntn = Cd / k.BN;
+  const int S = k.grid / ntn * ntn;                 // resident workgroups, a whole number of M-tiles
+  const long long mt_all = (M + k.BM - 1) / k.BM;
+  const long long T = mt_all * ntn;
+  const long long rounds = T / S;
+  const long long tail = T - rounds * S;
+  k.f = 1; k.kps = nk;
+  k.full = (int)T; k.tail_units = 0; k.tail_row0 = M;
+  if (tail > 0) {
+    // a last round that is >= 60 % full runs unbalanced; otherwise its tiles are cut in K so that every
+    // workgroup gets one piece and the chip stays full for a fraction of a tile time
+    int f = (int)(S / tail);
+    if (f > nk / 3) f = nk / 3;                     // >= 3 k-tiles per piece
+    if (f > 64) f = 64;
+    const bool split = f >= 2 && (rounds == 0 || tail * 10 < 6ll * S);
+    if (split) {
+      k.kps = (nk + f - 1) / f;
+      k.f = (nk + k.kps - 1) / k.kps;
+      k.full = (int)(rounds * S);
+      k.tail_units = (int)tail * k.f;
+      k.tail_row0 = (long long)(k.full / ntn) * k.BM;
+      k.ws_floats = (size_t)k.f * (size_t)(M - k.tail_row0) * Cd;
+    }
+  }
+  k.grid = k.full >= S ? S : (k.full > k.tail_units ? k.full : k.tail_units);
+  return k;
+}
+
+// n / d == (n * magic) >> shift for every n < 2^31 (d >= 1)
+static void magic_for(int d, unsigned& magic, int& shift) {
+  int l = 0;
+  while ((1ll << l) < d) ++l;
+  shift = 31 + l;
+  magic = (unsigned)(((1ull << shift) + (unsigned)d - 1) / (unsigned)d);
+}
+
+template <int WM, int WN, int TM, int TN, int MODE>
+static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;
+  static bool attr_set = false;
+  auto kern = igemm_pk_kernel<WM, WN, TM, TN, MODE>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  static char name[64] = "";
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_pk_kernel<%d,%d,%d,%d,%d>", WM, WN, TM, TN, MODE);
+  const double K = (double)a.kt * a.kh * a.kw * a.Cs;
+  const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
+  // algorithmic work: 2*M*N*K flops; bytes = one read of src + weights, one write of dst (+ addend)
+  ScopedTimer t(s, name, 2.0 * a.M * a.Cd * K,
+                4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (a.addend ? 2 : 1)));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
+  return check_launch("igemm_pk");
 }
 
 // Tail split of a launch with more workgroups than resident slots (see dispatch_igemm).
@@ -1128,9 +1564,51 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     return launch_igemm<4, 1, 1, 2, 1, true>(a, s);
   }
   const int nk_total = a.kt * a.kh * a.kw * (a.Cs / BK);
-  IgemmPlan pl = plan_igemm(a.M, a.Cd, nk_total, true);
-  if (pl.nsplit > 1 && (ws == nullptr || ws_bytes < sizeof(float) * (size_t)pl.nsplit * a.M * a.Cd)) {
-    pl = plan_igemm(a.M, a.Cd, nk_total, false);  // no scratch: single pass
+  // Everything dense goes to the persistent kernel (whole rounds + K-split tail in one launch).
+  if (pk_enabled()) {
+    PkPlan pk = plan_pk(a.M, a.Cd, nk_total);
+    if (pk.tail_units > 0 && (ws == nullptr || ws_bytes < sizeof(float) * pk.ws_floats)) {   // no scratch: unsplit
+      pk.full += pk.tail_units / pk.f;
+      pk.tail_units = 0;
+      pk.f = 1;
+      pk.tail_row0 = a.M;
+      const int S = (pk.tile < 2 ? 2 : 1) * device_cus();
+      pk.grid = pk.full < S ? pk.full : S;
+    }
+    ConvArgs k = a;
+    k.mt2_begin = 0;
+    k.mt2_count = 0;
+    k.nsplit = 1;
+    k.pk_full = pk.full;
+    k.pk_tail_units = pk.tail_units;
+    k.pk_f = pk.f;
+    k.pk_kps = pk.kps;
+    k.part = static_cast<float*>(ws);
+    k.part_row_begin = (int)pk.tail_row0;
+    magic_for(k.Wd, k.mgW, k.shW);
+    magic_for(k.Hd, k.mgH, k.shH);
+    magic_for(k.Td, k.mgT, k.shT);
+    int rc;
+    switch (pk.tile) {
+      case 0: rc = launch_pk<2, 2, 2, 2, MODE>(k, pk.grid, s); break;
+      case 1: rc = launch_pk<4, 1, 1, 2, MODE>(k, pk.grid, s); break;
+      case 2: rc = launch_pk<4, 2, 2, 2, MODE>(k, pk.grid, s); break;
+      default: rc = launch_pk<4, 2, 2, 1, MODE>(k, pk.grid, s); break;
+    }
+    if (rc || pk.tail_units == 0) return rc;
+    const long long rows = a.M - pk.tail_row0, n4 = rows * a.Cd / 4, off = pk.tail_row0 * a.Cd;
+    long long grid = ceil_div(n4, 256);
+    if (grid > 2048) grid = 2048;
+    ScopedTimer t(s, "splitk_reduce_kernel", 0.0, 4.0 * rows * a.Cd * (pk.f + 1 + (a.addend ? 1 : 0)));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, k.part, a.dst + off,
+                       a.addend ? a.addend + off : nullptr, a.bias, n4, a.Cd / 4, pk.f, a.relu);
+    return check_launch("splitk_reduce");
+  }
+  const long long row0 = 0;
+  const long long Mr = a.M - row0;
+  IgemmPlan pl = plan_igemm(Mr, a.Cd, nk_total, true);
+  if (pl.nsplit > 1 && (ws == nullptr || ws_bytes < sizeof(float) * (size_t)pl.nsplit * Mr * a.Cd)) {
+    pl = plan_igemm(Mr, a.Cd, nk_total, false);  // no scratch: single pass
   }
   auto launch = [&](ConvArgs& x) {
     switch (pl.tile) {
@@ -1149,21 +1627,22 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
                        x.addend ? x.addend + off : nullptr, x.bias, n4, x.Cd / 4, nsplit, x.relu);
     return check_launch("splitk_reduce");
   };
-  const int ntn = a.Cd / pl.BN;
-  const int mt2 = (int)((((long long)a.M + pl.BM - 1) / pl.BM + 1) / 2);   // M pair-tiles
-  a.mt2_begin = 0;
+  const int pair = 2 * pl.BM;                                       // rows per workgroup of igemm_kernel
+  const int mt2_0 = (int)(row0 / pair);                             // row0 is a multiple of 256
+  const int mt2 = (int)((Mr + pair - 1) / pair);                    // M pair-tiles of the remainder
+  a.mt2_begin = mt2_0;
   a.mt2_count = mt2;
-  a.part_row_begin = 0;
+  a.part_row_begin = (int)row0;
   a.nsplit = pl.nsplit;
   a.ksteps_per_split = pl.ksteps_per_split;
   a.part = static_cast<float*>(ws);
-  if (pl.nsplit > 1) {   // small-M layer: the whole launch is split-K
+  if (pl.nsplit > 1) {   // small-M problem: the whole launch is split-K
     int rc = launch(a);
     return rc ? rc : reduce(a, pl.nsplit);
   }
   // Tail split: whole rounds of workgroups run as is; a nearly empty last round (<= half the slots) is cut
   // in K so that it fills the chip for a fraction of a tile time instead of idling it for a full one.
-  const TailPlan tp = plan_tail(pl, a.M, a.Cd, nk_total);
+  const TailPlan tp = plan_tail(pl, Mr, a.Cd, nk_total);
   const int tail_m = tp.tail_m, f = tp.f;
   const bool tail_split = tail_m > 0 && ws != nullptr && ws_bytes >= sizeof(float) * (size_t)f * tp.tail_rows * a.Cd;
   if (!tail_split) return launch(a);
@@ -1171,13 +1650,23 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
   int rc = launch(a);
   if (rc) return rc;
   ConvArgs t = a;
-  t.mt2_begin = mt2 - tail_m;
+  t.mt2_begin = mt2_0 + mt2 - tail_m;
   t.mt2_count = tail_m;
-  t.part_row_begin = (mt2 - tail_m) * 2 * pl.BM;
+  t.part_row_begin = (int)row0 + (mt2 - tail_m) * pair;
   t.ksteps_per_split = (nk_total + f - 1) / f;
   t.nsplit = (nk_total + t.ksteps_per_split - 1) / t.ksteps_per_split;
   rc = launch(t);
   return rc ? rc : reduce(t, t.nsplit);
+}
+
+// scratch floats the non-strided igemm dispatch wants for an M x Cd problem (mirrors dispatch_igemm)
+static size_t igemm_ws_floats(long long M, int Cd, int nk) {
+  if (pk_enabled()) return plan_pk(M, Cd, nk).ws_floats;
+  const long long Mr = M;
+  const IgemmPlan pl = plan_igemm(Mr, Cd, nk, true);
+  if (pl.nsplit > 1) return (size_t)pl.nsplit * Mr * Cd;
+  const TailPlan tp = plan_tail(pl, Mr, Cd, nk);
+  return (size_t)tp.f * tp.tail_rows * Cd;
 }
 
 static int launch_gather(const ConvArgs& a, hipStream_t s) {
@@ -1211,6 +1700,7 @@ static void fill_common(ConvArgs& a, const avid_conv_desc* d) {
   a.part = nullptr;
   a.epi_op = 0;
   a.ncls = 1;
+  a.mgW = a.mgH = a.mgT = 0; a.shW = a.shH = a.shT = 0;
   a.cls_ptiles_total = 0;
   a.mt2_begin = 0;
   a.mt2_count = 0;
@@ -1246,10 +1736,7 @@ extern "C" size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d) {
   if (!vec) return stem_fwd_supported(d) ? stem_fwd_ws_bytes(d) : 0;
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
   const int nk = d->kt * d->kh * d->kw * (d->Cin / BK);
-  IgemmPlan pl = plan_igemm(M, d->Cout, nk, true);
-  if (pl.nsplit > 1) return sizeof(float) * (size_t)pl.nsplit * M * d->Cout;
-  const TailPlan tp = plan_tail(pl, M, d->Cout, nk);
-  return sizeof(float) * (size_t)tp.f * tp.tail_rows * d->Cout;
+  return sizeof(float) * igemm_ws_floats(M, d->Cout, nk);
 }
 
 extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* addend,
@@ -1281,10 +1768,7 @@ extern "C" size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
   const int nk = d->kt * d->kh * d->kw * (d->Cout / BK);
-  IgemmPlan pl = plan_igemm(M, d->Cin, nk, true);
-  if (pl.nsplit > 1) return dgrad_wt_bytes(d) + sizeof(float) * (size_t)pl.nsplit * M * d->Cin;
-  const TailPlan tp = plan_tail(pl, M, d->Cin, nk);
-  return dgrad_wt_bytes(d) + sizeof(float) * (size_t)tp.f * tp.tail_rows * d->Cin;
+  return dgrad_wt_bytes(d) + sizeof(float) * igemm_ws_floats(M, d->Cin, nk);
 }
 
 extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* addend,

@@ -42,6 +42,10 @@ CONV_CASES = [
     ("late_64x64", 256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (3, 2, 14, 14)),
     ("big_128x64", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 8, 48, 48)),
     ("big_128x128", 64, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 8, 48, 48)),
+    # persistent kernel: whole rounds + split-K remainder with a ragged last tile; 27 taps crossing batch items
+    ("big_ragged_333", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (5, 7, 45, 47)),
+    # persistent kernel alone, last round 80 % full and ragged (run unbalanced)
+    ("big_unbalanced", 64, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (7, 8, 45, 47)),
 ]
 
 

@@ -49,18 +49,23 @@ for name, cin, cout, k, st, pd, (T, H, W) in L:
         torch.cuda.synchronize()
         res[which] = lib.timing_report()
         lib.timing_enable(False)
+    if os.environ.get('AVID_DBG') == '8':
+        v = y.flatten()[:2].tolist(); print(f'   clock: {v[0]:.0f} shader ticks / {v[1]:.0f} x10ns = {v[0]/(v[1]/100):.0f} MHz')
+    if os.environ.get('CB_VERBOSE'):
+        for which in ('fwd','bwd'):
+            for n, v in res[which].items(): print(f'      {which} {n:34s} {v["ms"]/reps*1e3:8.1f} us  x{v["launches"]/reps:.0f}')
     M = y.numel() // cout
     K = cin * k[0] * k[1] * k[2]
     fl = 2.0 * M * cout * K
     def pick(rep, pref, mode=None):
         t = 0.0; names = []
         for n, v in rep.items():
-            if n.startswith(pref) and (mode is None or n.endswith(f",{mode}>")):
+            if n.startswith(pref) and (mode is None or n.endswith(f",{mode}>") or n.endswith(f",{mode}>s2")):
                 t += v["ms"]; names.append(n)
         return t / reps * 1e3, names
-    f_us, fn = pick(res["fwd"], "igemm_kernel", 0)
+    f_us, fn = pick(res["fwd"], "igemm_", 0)
     fr_us, _ = pick(res["fwd"], "splitk")
-    d_us, dn = pick(res["bwd"], "igemm_kernel", 1)
+    d_us, dn = pick(res["bwd"], "igemm_", 1)
     dr_us, _ = pick(res["bwd"], "splitk"); dt_us, _ = pick(res["bwd"], "weight_tr")
     w_us, wn = pick(res["bwd"], "wgrad_kernel")
     wr_us, _ = pick(res["bwd"], "wgrad_reduce")
