@@ -113,6 +113,67 @@ def _desc(xs, cin, cout, k, stride, pad, channel_first):
     return d
 
 
+class TransposedWeights:
+    """[Cin][taps][Cout] copies of every conv / linear weight that can need an input gradient, repacked by ONE
+    launch (avid_weight_transpose_batched) instead of one small launch inside every avid_conv_dgrad call.
+
+    The copies are only trusted while ``armed()`` is active: ``TrainStep`` refreshes them right before
+    ``loss.backward()`` and arms them for its duration, so weights changed in any way between steps
+    (optimizer, load_state_dict, manual edits) are always picked up."""
+
+    def __init__(self, params):
+        import struct
+        ws = [p for p in params
+              if p.is_cuda and p.dtype == torch.float32 and p.dim() in (2, 4, 5) and weight_layout_ok(p)
+              and p.shape[1] % 64 == 0 and p.shape[0] % 32 == 0]
+        self.n = len(ws)
+        self.map = {}
+        if not ws:
+            return
+        dev = ws[0].device
+        self.buf = torch.empty(sum(p.numel() for p in ws), dtype=torch.float32, device=dev)
+        recs, off, self.max_elems = [], 0, 0
+        for p in ws:
+            k = _kdims(p)
+            wt = self.buf[off:off + p.numel()]
+            off += p.numel()
+            recs.append(struct.pack("<QQiiii", p.data_ptr(), wt.data_ptr(), p.shape[0], k[0] * k[1] * k[2], p.shape[1], 0))
+            self.map[p.data_ptr()] = wt
+            self.max_elems = max(self.max_elems, p.numel())
+        self.table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+
+    def refresh(self):
+        if self.n:
+            lib.call("avid_weight_transpose_batched", self.n, _p(self.table), self.max_elems, _stream())
+
+    def armed(self):
+        return _ArmTransposed(self)
+
+
+class _ArmTransposed:
+    def __init__(self, tw):
+        self.tw = tw
+
+    def __enter__(self):
+        global _TRANSPOSED
+        self.prev, _TRANSPOSED = _TRANSPOSED, self.tw
+        return self.tw
+
+    def __exit__(self, *exc):
+        global _TRANSPOSED
+        _TRANSPOSED = self.prev
+        return False
+
+
+_TRANSPOSED = None
+
+
+def _wt_for(w):
+    if _TRANSPOSED is None:
+        return None
+    return _TRANSPOSED.map.get(w.data_ptr())
+
+
 class _ConvCL(Function):
     """y = conv(x, w) [+ addend] [+ bias] [relu]  — avid_conv_fwd / avid_conv_dgrad / avid_conv_wgrad."""
 
@@ -180,7 +241,7 @@ class _ConvCL(Function):
         if need_dx:
             ws = workspace(x.device, ctx.nb_dgrad)
             dx = torch.empty_like(x)
-            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), None, _p(dx), _p(ws), ws.numel(), st)
+            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_wt_for(w)), None, _p(dx), _p(ws), ws.numel(), st)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():

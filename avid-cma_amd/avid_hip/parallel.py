@@ -145,12 +145,21 @@ class TrainStep:
         self.t_dev = torch.zeros((), dtype=torch.int64, device=self.flat.flat.device) \
             if self.flat.flat.is_cuda else None
         self.graph = None
+        self.twt = None
+        if self.flat.flat.is_cuda:
+            from . import ops
+            self.twt = ops.TransposedWeights(self.flat.params)   # dgrad weight repack: one launch per step
 
     def forward_backward(self, video, audio, index):
         self.flat.zero_grad()
         video_emb, audio_emb = self.model(video, audio)
         loss, _ = self.criterion(video_emb, audio_emb, index)
-        loss.backward()
+        if self.twt is not None:
+            self.twt.refresh()                       # after the forward: whatever the weights are now
+            with self.twt.armed():
+                loss.backward()
+        else:
+            loss.backward()
         self.buckets.finish()
         return loss
 

@@ -63,6 +63,8 @@ struct ConvArgs {
   // pk_tail_units = tail_tiles * pk_f units after them are (tile, K-range) pieces, one per workgroup, that
   // write partial slabs to `part` (rows [part_row_begin, M))
   int pk_full, pk_tail_units, pk_f, pk_kps;
+  int pk_rot;      // tail unit u runs on workgroup (u + pk_rot) mod G: the ones that got one full tile less
+  int pk_paired;   // grid = 2 workgroups per CU: number them so that v and v + G/2 share a CU
 };
 
 constexpr int BK = 32;
@@ -367,7 +369,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
 
   const int ntn = p.Cd / BN;
   const int G = gridDim.x;
-  const int slot = __builtin_amdgcn_readfirstlane((int)xcd_remap(blockIdx.x, G));
+  // Workgroup numbering.  Hardware deals consecutive ids round-robin to the 8 XCDs and, inside an XCD, one
+  // per CU before doubling up.  Logical slots keep 32 consecutive tiles on one XCD (shared L2 halos) and,
+  // for a 2-per-CU grid, put the CU-mates at v and v + G/2 — the planner balances work per CU with that.
+  int slot_;
+  if (p.pk_paired) {
+    const int per = G >> 4;                               // CUs per XCD
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    const int second = pos >= per ? 1 : 0;
+    slot_ = second * (G >> 1) + xcd * per + (pos - second * per);
+  } else {
+    slot_ = (int)xcd_remap(blockIdx.x, G);
+  }
+  const int slot = __builtin_amdgcn_readfirstlane(slot_);
   const int ntaps = p.kt * p.kh * p.kw;
   const int cpt = p.Cs / BK;
   const int nk = ntaps * cpt;
@@ -380,15 +394,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   // ---- this workgroup's segments: whole tiles slot, slot+G, ... below pk_full, then at most one
   // (tile, K-range) piece of the split tail
   const int n_full = slot < p.pk_full ? (p.pk_full - slot + G - 1) / G : 0;
-  const int nseg = n_full + (slot < p.pk_tail_units ? 1 : 0);
+  int tslot = slot - p.pk_rot;
+  tslot += tslot < 0 ? G : 0;
+  const int nseg = n_full + (tslot < p.pk_tail_units ? 1 : 0);
   if (nseg == 0) return;
   auto seg_info = [&](int j, int& tile, int& k0, int& k1, int& split) {
     if (j < n_full) {
       tile = slot + j * G; k0 = 0; k1 = nk; split = -1;
     } else {
-      tile = p.pk_full + slot / p.pk_f;
-      split = slot % p.pk_f;
-      k0 = split * p.pk_kps;
+      tile = p.pk_full + tslot / p.pk_f;
+      const int piece = tslot % p.pk_f;
+      split = p.pk_f > 1 ? piece : -1;          // unsplit tail tiles take the direct epilogue
+      k0 = piece * p.pk_kps;
       k1 = k0 + p.pk_kps < nk ? k0 + p.pk_kps : nk;
     }
   };
@@ -1278,6 +1295,19 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
   wt[i] = w[((long long)co * ntaps + tap) * Ci + ci];
 }
 
+// all weights of a model in one launch: blockIdx.y picks the descriptor
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const avid_wt_desc* __restrict__ descs) {
+  const avid_wt_desc d = descs[blockIdx.y];
+  const long long n = (long long)d.Cout * d.ntaps * d.Cin;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int co = (int)(i % d.Cout);
+  const long long r = i / d.Cout;
+  const int tap = (int)(r % d.ntaps);
+  const int ci = (int)(r / d.ntaps);
+  d.wt[i] = d.w[((long long)co * d.ntaps + tap) * d.Cin + ci];
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1407,6 +1437,8 @@ struct PkPlan {
   int full;          // tiles [0, full) run whole, round-robin over the workgroups
   int tail_units;    // then tail_tiles * f (tile, K-range) pieces, at most one per workgroup
   int f, kps;        // K splits per tail tile, k-tiles per split
+  int rot;           // first workgroup that takes a tail unit
+  bool paired;       // 2-per-CU grid numbered so that v and v + G/2 share a CU
   long long tail_row0;   // rows [tail_row0, M) are produced by splitk_reduce_kernel from f slabs
   size_t ws_floats;
 };
@@ -1429,38 +1461,51 @@ static int pk_alt() {
 static PkPlan plan_pk(long long M, int Cd, int nk) {
   PkPlan k{};
   const int cus = device_cus();
+  int per_cu = 2;
   if (Cd % 128 == 0) {
-    if (pk_alt()) { k.tile = 2; k.BM = 256; k.BN = 128; k.grid = cus; }
-    else          { k.tile = 0; k.BM = 128; k.BN = 128; k.grid = 2 * cus; }
+    if (pk_alt()) { k.tile = 2; k.BM = 256; k.BN = 128; per_cu = 1; }
+    else          { k.tile = 0; k.BM = 128; k.BN = 128; }
   } else {
-    if (pk_alt()) { k.tile = 3; k.BM = 256; k.BN = 64; k.grid = cus; }
-    else          { k.tile = 1; k.BM = 128; k.BN = 64; k.grid = 2 * cus; }
+    if (pk_alt()) { k.tile = 3; k.BM = 256; k.BN = 64; per_cu = 1; }
+    else          { k.tile = 1; k.BM = 128; k.BN = 64; }
   }
   const int ntn = Cd / k.BN;
-  const int S = k.grid / ntn * ntn;                 // resident workgroups, a whole number of M-tiles
+  const int C = cus / ntn * ntn;                    // CUs, a whole number of M-tiles
+  const int G = per_cu * C;
   const long long mt_all = (M + k.BM - 1) / k.BM;
   const long long T = mt_all * ntn;
-  const long long rounds = T / S;
-  const long long tail = T - rounds * S;
-  k.f = 1; k.kps = nk;
-  k.full = (int)T; k.tail_units = 0; k.tail_row0 = M;
-  if (tail > 0) {
-    // a last round that is >= 60 % full runs unbalanced; otherwise its tiles are cut in K so that every
-    // workgroup gets one piece and the chip stays full for a fraction of a tile time
-    int f = (int)(S / tail);
-    if (f > nk / 3) f = nk / 3;                     // >= 3 k-tiles per piece
-    if (f > 64) f = 64;
-    const bool split = f >= 2 && (rounds == 0 || tail * 10 < 6ll * S);
-    if (split) {
-      k.kps = (nk + f - 1) / f;
-      k.f = (nk + k.kps - 1) / k.kps;
-      k.full = (int)(rounds * S);
-      k.tail_units = (int)tail * k.f;
-      k.tail_row0 = (long long)(k.full / ntn) * k.BM;
-      k.ws_floats = (size_t)k.f * (size_t)(M - k.tail_row0) * Cd;
+  // Work is balanced per CU.  `full` tiles (a multiple of C) are dealt whole, tile i to workgroup i mod G, so
+  // every CU gets the same number; the remaining tail tiles are cut into f K-ranges ("units", at most one
+  // per workgroup, handed out starting with the workgroups that got one full tile less).  Cost model in
+  // k-tiles per CU: a started tile or unit pays ~2 k-tiles of prologue/epilogue, a split adds the slab pass.
+  const double ovh = 2.0, red = 4.0;
+  double best = 1e300;
+  const int fmax = nk / 3 < 64 ? (nk / 3 < 1 ? 1 : nk / 3) : 64;
+  for (long long m = T / C; m >= 0 && m >= T / C - 1; --m) {
+    const long long full = m * C, tail = T - full;
+    if (tail > G) continue;
+    for (int f0 = 1; f0 <= (tail ? fmax : 1); ++f0) {
+      const int kps = (nk + f0 - 1) / f0, f = (nk + kps - 1) / kps;
+      const long long units = tail * f;
+      if (units > G) break;
+      const int maxu = units == 0 ? 0 : (int)((units + C - 1) / C);       // units on the busiest CU
+      const double cost = (double)m * (nk + ovh) + maxu * (kps + ovh) + (f > 1 ? red : 0.0);
+      if (cost < best - 1e-9) {
+        best = cost;
+        k.full = (int)full; k.tail_units = (int)units; k.f = f; k.kps = kps;
+      }
     }
   }
-  k.grid = k.full >= S ? S : (k.full > k.tail_units ? k.full : k.tail_units);
+  k.rot = per_cu == 2 ? (int)((k.full / C) % 2) * C : 0;
+  k.tail_row0 = k.f > 1 ? (long long)(k.full / ntn) * k.BM : M;
+  k.ws_floats = k.f > 1 ? (size_t)k.f * (size_t)(M - k.tail_row0) * Cd : 0;
+  k.grid = G;
+  k.paired = per_cu == 2 && G % 16 == 0;
+  if ((long long)k.full + k.tail_units <= C / 2) {   // small problem: a compact grid, plain numbering
+    k.grid = k.full + k.tail_units;
+    k.rot = 0;
+    k.paired = false;
+  }
   return k;
 }
 
@@ -1567,13 +1612,11 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
   // Everything dense goes to the persistent kernel (whole rounds + K-split tail in one launch).
   if (pk_enabled()) {
     PkPlan pk = plan_pk(a.M, a.Cd, nk_total);
-    if (pk.tail_units > 0 && (ws == nullptr || ws_bytes < sizeof(float) * pk.ws_floats)) {   // no scratch: unsplit
-      pk.full += pk.tail_units / pk.f;
-      pk.tail_units = 0;
+    if (pk.f > 1 && (ws == nullptr || ws_bytes < sizeof(float) * pk.ws_floats)) {   // no scratch: unsplit
+      pk.tail_units /= pk.f;
       pk.f = 1;
+      pk.kps = nk_total;
       pk.tail_row0 = a.M;
-      const int S = (pk.tile < 2 ? 2 : 1) * device_cus();
-      pk.grid = pk.full < S ? pk.full : S;
     }
     ConvArgs k = a;
     k.mt2_begin = 0;
@@ -1583,6 +1626,8 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     k.pk_tail_units = pk.tail_units;
     k.pk_f = pk.f;
     k.pk_kps = pk.kps;
+    k.pk_rot = pk.rot;
+    k.pk_paired = pk.paired ? 1 : 0;
     k.part = static_cast<float*>(ws);
     k.part_row_begin = (int)pk.tail_row0;
     magic_for(k.Wd, k.mgW, k.shW);
@@ -1595,7 +1640,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
       case 2: rc = launch_pk<4, 2, 2, 2, MODE>(k, pk.grid, s); break;
       default: rc = launch_pk<4, 2, 2, 1, MODE>(k, pk.grid, s); break;
     }
-    if (rc || pk.tail_units == 0) return rc;
+    if (rc || pk.f == 1) return rc;
     const long long rows = a.M - pk.tail_row0, n4 = rows * a.Cd / 4, off = pk.tail_row0 * a.Cd;
     long long grid = ceil_div(n4, 256);
     if (grid > 2048) grid = 2048;
@@ -1771,8 +1816,18 @@ extern "C" size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d) {
   return dgrad_wt_bytes(d) + sizeof(float) * igemm_ws_floats(M, d->Cin, nk);
 }
 
-extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* addend,
-                               float* dx, void* ws, size_t ws_bytes, avid_stream_t stream) {
+extern "C" int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_dev, int64_t max_elems,
+                                             avid_stream_t stream) {
+  AVID_REQUIRE(n > 0 && descs_dev && max_elems > 0, AVID_E_BADARG, "weight_transpose_batched: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ScopedTimer t(s, "weight_transpose_batched_kernel", 0.0, 0.0);
+  hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)ceil_div(max_elems, 256), (unsigned)n), dim3(256), 0,
+                     s, descs_dev);
+  return check_launch("weight_transpose_batched");
+}
+
+extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* wt_in,
+                               const float* addend, float* dx, void* ws, size_t ws_bytes, avid_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
   AVID_REQUIRE(dy && w && dx && ws, AVID_E_BADARG, "conv_dgrad: null pointer");
@@ -1783,15 +1838,19 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
   AVID_REQUIRE(ws_bytes >= dgrad_wt_bytes(d), AVID_E_BADARG, "conv_dgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int ntaps = d->kt * d->kh * d->kw;
-  float* wt = static_cast<float*>(ws);
-  const long long nw = (long long)d->Cout * ntaps * d->Cin;
-  {
-    ScopedTimer t(s, "weight_transpose_kernel", 0.0, 8.0 * nw);
-    hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, s, w, wt, d->Cout,
-                       ntaps, d->Cin);
+  const float* wt = wt_in;
+  if (!wt) {
+    float* wt_ws = static_cast<float*>(ws);
+    const long long nw = (long long)d->Cout * ntaps * d->Cin;
+    {
+      ScopedTimer t(s, "weight_transpose_kernel", 0.0, 8.0 * nw);
+      hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, s, w, wt_ws, d->Cout,
+                         ntaps, d->Cin);
+    }
+    rc = check_launch("weight_transpose");
+    if (rc) return rc;
+    wt = wt_ws;
   }
-  rc = check_launch("weight_transpose");
-  if (rc) return rc;
   ConvArgs a;
   fill_common(a, d);
   a.src = dy; a.wk = wt; a.addend = addend; a.bias = nullptr; a.dst = dx;

@@ -72,10 +72,23 @@ int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const
                   const float* bias, int relu, float* y, void* ws, size_t ws_bytes,
                   avid_stream_t stream);
 
-/* dx = conv_transpose(dy, w) [+ addend].  ws: scratch for the transposed weights (+ split-K slabs). */
+/* dx = conv_transpose(dy, w) [+ addend].  ws: scratch for the transposed weights (+ split-K slabs).
+ * wt: the weights already repacked as [Cin][taps][Cout] by avid_weight_transpose_batched (current for
+ * this w), or NULL to repack inside the call (one extra small launch per layer). */
 size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d);
-int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* addend,
-                    float* dx, void* ws, size_t ws_bytes, avid_stream_t stream);
+int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* wt,
+                    const float* addend, float* dx, void* ws, size_t ws_bytes, avid_stream_t stream);
+
+/* One launch that repacks every conv / linear weight of a model for its input-gradient pass:
+ * w[Cout][taps][Cin] -> wt[Cin][taps][Cout] for each descriptor.  descs_dev: n descriptors in DEVICE
+ * memory (they do not change between steps); max_elems = max over descriptors of Cout*taps*Cin.
+ * Call it once after each optimizer step (the autograd.Function of torch's conv does this per call). */
+typedef struct avid_wt_desc {
+  const float* w;
+  float* wt;
+  int32_t Cout, ntaps, Cin, reserved;
+} avid_wt_desc;
+int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_dev, int64_t max_elems, avid_stream_t stream);
 
 /* Which kernel instantiation a descriptor dispatches to (which: 0 fwd, 1 dgrad, 2 wgrad), e.g.
  * "igemm_kernel<4,1,1,2,1>" — lets bench.py attribute HIP-event timings to rocprofv3 kernel names. */
