@@ -113,6 +113,63 @@ def _desc(xs, cin, cout, k, stride, pad, channel_first):
     return d
 
 
+class GradSlots:
+    """Parameter gradients written straight into their slice of a flat gradient buffer.
+
+    While ``armed()``, a backward kernel that produces a parameter gradient gets the parameter's slice of the
+    flat buffer as its output (``dst``) and the autograd.Function returns ``None`` for that input — no
+    AccumulateGrad add kernel per parameter (141 tiny launches per step otherwise).  A parameter that is hit a
+    second time in the same backward (shared weights) falls back to a fresh tensor and normal accumulation
+    into ``p.grad`` (which is the same slice).  ``on_ready(i)`` is called for parameter i when its gradient
+    has been issued (gradient-bucket all-reduce)."""
+
+    def __init__(self, params, grad_views, on_ready=None):
+        self.index = {p.data_ptr(): i for i, p in enumerate(params)}
+        self.views = grad_views
+        self.on_ready = on_ready
+        self.used = set()
+
+    def armed(self):
+        return _ArmSlots(self)
+
+
+class _ArmSlots:
+    def __init__(self, gs):
+        self.gs = gs
+
+    def __enter__(self):
+        global _SLOTS
+        self.prev, _SLOTS = _SLOTS, self.gs
+        self.gs.used.clear()
+        return self.gs
+
+    def __exit__(self, *exc):
+        global _SLOTS
+        _SLOTS = self.prev
+        return False
+
+
+_SLOTS = None
+
+
+def _grad_dst(param_ptr, like=None, shape=None, device=None):
+    """(tensor to write the gradient of the parameter at ``param_ptr`` into, slot index or None)."""
+    gs = _SLOTS
+    if gs is not None:
+        i = gs.index.get(param_ptr)
+        if i is not None and i not in gs.used:
+            gs.used.add(i)
+            return gs.views[i], i
+    if like is not None:
+        return torch.empty_like(like), None
+    return torch.empty(shape, dtype=torch.float32, device=device), None
+
+
+def _grad_done(i):
+    if i is not None and _SLOTS is not None and _SLOTS.on_ready is not None:
+        _SLOTS.on_ready(i)
+
+
 class TransposedWeights:
     """[Cin][taps][Cout] copies of every conv / linear weight that can need an input gradient, repacked by ONE
     launch (avid_weight_transpose_batched) instead of one small launch inside every avid_conv_dgrad call.
@@ -204,6 +261,7 @@ class _ConvCL(Function):
                  ws.numel() if ws is not None else 0, _stream())
         ctx.d, ctx.relu, ctx.channel_first = d, relu, channel_first
         ctx.has_addend, ctx.has_bias = addend is not None, bias is not None
+        ctx.bias_ptr = bias.data_ptr() if bias is not None else 0
         ctx.save_for_backward(x, w, y if relu else None)
         return y
 
@@ -224,10 +282,13 @@ class _ConvCL(Function):
 
         def run_wgrad():
             ws = workspace(x.device, ctx.nb_wgrad)
-            g = torch.empty_like(w)          # preserve_format keeps the [Cout][k][Cin] memory
+            g, slot = _grad_dst(w.data_ptr(), like=w)   # the flat-buffer slice, or preserve_format empty_like
             if g.stride() != w.stride() and not weight_layout_ok(g):
-                raise AvidHipError("conv: empty_like did not preserve the weight layout")
+                raise AvidHipError("conv: the weight-gradient tensor does not have the [Cout][k][Cin] layout")
             lib.call("avid_conv_wgrad", C.byref(d), _p(x), _p(dy), _p(g), _p(ws), ws.numel(), _stream())
+            if slot is not None:
+                _grad_done(slot)
+                return None
             return g
 
         side = None
@@ -245,15 +306,19 @@ class _ConvCL(Function):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
-                dw.record_stream(torch.cuda.current_stream())
+                if dw is not None:
+                    dw.record_stream(torch.cuda.current_stream())
                 dy.record_stream(side)
         elif need_dw:
             dw = run_wgrad()
         if ctx.has_addend and ctx.needs_input_grad[2]:
             dadd = dy
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            dbias = torch.empty(d.Cout, dtype=torch.float32, device=dy.device)
+            dbias, slot = _grad_dst(ctx.bias_ptr, shape=(d.Cout,), device=dy.device)
             lib.call("avid_colsum", dy.numel() // d.Cout, d.Cout, _p(dy), _p(dbias), st)
+            if slot is not None:
+                _grad_done(slot)
+                dbias = None
         return dx, dw, dadd, dbias, None, None, None, None
 
 
@@ -273,7 +338,7 @@ def linear(x, w, bias=None, relu=False):
 # ------------------------------------------------------------------------------------------------
 class _BatchNormCL(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, stats, training, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, stats, training, momentum, eps, relu, counter=None):
         _need_cuda(x, gamma, beta)
         if not x.is_contiguous():
             raise AvidHipError("bn: x must be contiguous channels-last")
@@ -286,9 +351,10 @@ class _BatchNormCL(Function):
             stats4 = torch.empty((4, Cc), dtype=torch.float32, device=x.device)   # mean, invstd, scale, shift
             ws = workspace(x.device, _bn_ws_bytes(M, Cc))
             lib.call("avid_bn_fwd_train", M, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv), float(momentum),
-                     float(eps), int(relu), _p(y), _p(stats4[0]), _p(stats4[1]), _p(stats4[2]), _p(stats4[3]), _p(ws),
-                     ws.numel(), st)
+                     float(eps), int(relu), _p(y), _p(stats4[0]), _p(stats4[1]), _p(stats4[2]), _p(stats4[3]),
+                     _p(counter), _p(ws), ws.numel(), st)
             ctx.save_for_backward(x, gamma, stats4)
+            ctx.beta_ptr = beta.data_ptr()
         else:
             lib.call("avid_bn_fwd_eval", M, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv), float(eps), int(relu),
                      _p(y), st)
@@ -303,16 +369,25 @@ class _BatchNormCL(Function):
         x, gamma, stats4 = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dgamma = torch.empty(ctx.C, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(ctx.C, dtype=torch.float32, device=x.device)
+        dgamma, sg = _grad_dst(gamma.data_ptr(), shape=(ctx.C,), device=x.device)
+        dbeta, sb = _grad_dst(ctx.beta_ptr, shape=(ctx.C,), device=x.device)
         ws = workspace(x.device, _bn_ws_bytes(ctx.M, ctx.C))
         lib.call("avid_bn_bwd", ctx.M, ctx.C, _p(x), _p(dy), _p(gamma), _p(stats4[0]), _p(stats4[1]), _p(stats4[2]),
                  _p(stats4[3]), int(ctx.relu), _p(dx), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream())
-        return dx, dgamma, dbeta, None, None, None, None, None
+        if sg is not None:
+            _grad_done(sg)
+            dgamma = None
+        if sb is not None:
+            _grad_done(sb)
+            dbeta = None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
-def batch_norm_cl(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False):
-    return _BatchNormCL.apply(x, gamma, beta, (running_mean, running_var), bool(training), momentum, eps, bool(relu))
+def batch_norm_cl(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False,
+                  num_batches_tracked=None):
+    """``num_batches_tracked`` (0-d int64 device tensor or None) is bumped by the kernel in training mode."""
+    return _BatchNormCL.apply(x, gamma, beta, (running_mean, running_var), bool(training), momentum, eps, bool(relu),
+                              num_batches_tracked)
 
 
 # ------------------------------------------------------------------------------------------------

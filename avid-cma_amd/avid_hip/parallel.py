@@ -47,17 +47,19 @@ class FlatParams:
         self.numel = off
         self.flat = torch.zeros(off, dtype=dt, device=dev)
         self.grad = torch.zeros(off, dtype=dt, device=dev)
+        self.grad_views = []
         for p, o in zip(self.params, self.offsets):
             view = self.flat[o:o + p.numel()].as_strided(p.shape, p.stride())
             view.copy_(p.data)
             p.data = view
             p.grad = self.grad[o:o + p.numel()].as_strided(p.shape, p.stride())
+            self.grad_views.append(p.grad)
 
     def zero_grad(self):
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):     # re-seat if something replaced .grad (set_to_none)
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + p.numel()].as_strided(p.shape, p.stride())
+                p.grad = self.grad_views[self.offsets.index(o)]
 
 
 class GradBuckets:
@@ -85,15 +87,21 @@ class GradBuckets:
             for i, p in enumerate(flat.params):
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
-    def _make_hook(self, i):
+    def ready(self, i):
+        """Gradient of parameter i has been issued (autograd hook, or ops.GradSlots for kernels that write the
+        flat buffer directly): launch its bucket's all-reduce once the bucket is complete."""
+        if not self.comm:
+            return
         b = self.bucket_of[i]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            s, e = self.bounds[b]
+            self._join_producers()
+            self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
 
+    def _make_hook(self, i):
         def hook(param):
-            self.pending[b] -= 1
-            if self.pending[b] == 0:
-                s, e = self.bounds[b]
-                self._join_producers()
-                self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
+            self.ready(i)
         return hook
 
     def _join_producers(self):
@@ -145,10 +153,12 @@ class TrainStep:
         self.t_dev = torch.zeros((), dtype=torch.int64, device=self.flat.flat.device) \
             if self.flat.flat.is_cuda else None
         self.graph = None
-        self.twt = None
+        self.twt = self.slots = None
         if self.flat.flat.is_cuda:
             from . import ops
             self.twt = ops.TransposedWeights(self.flat.params)   # dgrad weight repack: one launch per step
+            # backward kernels write parameter gradients straight into the flat buffer (no per-parameter add)
+            self.slots = ops.GradSlots(self.flat.params, self.flat.grad_views, on_ready=self.buckets.ready)
 
     def forward_backward(self, video, audio, index):
         self.flat.zero_grad()
@@ -156,7 +166,7 @@ class TrainStep:
         loss, _ = self.criterion(video_emb, audio_emb, index)
         if self.twt is not None:
             self.twt.refresh()                       # after the forward: whatever the weights are now
-            with self.twt.armed():
+            with self.twt.armed(), self.slots.armed():
                 loss.backward()
         else:
             loss.backward()

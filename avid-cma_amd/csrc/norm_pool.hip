@@ -107,9 +107,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ running_var, float momentum, float eps,
                                                            float* __restrict__ save_mean,
                                                            float* __restrict__ save_invstd, float* __restrict__ scale,
-                                                           float* __restrict__ shift) {
+                                                           float* __restrict__ shift,
+                                                           long long* __restrict__ num_batches_tracked) {
   __shared__ double sh[FIN_SLICES][2][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   double s, ss;
   finalize_sums(part, nblk, C, c, slice, sh, s, ss);
   if (slice != 0 || c >= C) return;
@@ -451,7 +453,8 @@ static int bn_check(int64_t M, int C, const char* who) {
 extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, int relu,
                                  float* y, float* save_mean, float* save_invstd, float* save_scale,
-                                 float* save_shift, void* ws, size_t ws_bytes, avid_stream_t stream) {
+                                 float* save_shift, int64_t* num_batches_tracked, void* ws, size_t ws_bytes,
+                                 avid_stream_t stream) {
   int rc = bn_check(M, C, "bn_fwd_train");
   if (rc) return rc;
   AVID_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && save_scale && save_shift && ws, AVID_E_BADARG,
@@ -468,7 +471,8 @@ extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* 
                        p.rows_per_pass, p.rows_per_block);
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64 * FIN_SLICES), 0, s, part, p.nblk, (long long)M,
-                     C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+                     C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift,
+                     reinterpret_cast<long long*>(num_batches_tracked));
   const long long n4 = (long long)M * p.G;
   {
     ScopedTimer t(s, "bn_apply_kernel", 0.0, 8.0 * M * C);

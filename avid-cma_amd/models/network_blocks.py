@@ -59,10 +59,9 @@ class BatchNormCL(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
     def forward(self, x, relu=False):
-        if self.training:
-            self.num_batches_tracked.add_(1)
         return ops.batch_norm_cl(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                 self.momentum, self.eps, relu)
+                                 self.momentum, self.eps, relu,
+                                 self.num_batches_tracked if self.training else None)   # bumped inside the kernel
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"

@@ -107,11 +107,13 @@ int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const float* dy, fl
 size_t avid_bn_workspace_bytes(int64_t M, int C);
 /* Train: batch mean / biased var -> save_mean, save_invstd [C]; running stats updated in place
  * (momentum, unbiased var); y = [relu](fma(x, scale, shift)) with scale = gamma * invstd,
- * shift = beta - mean * scale, both also saved ([C]) so backward can recompute the ReLU mask bit-exactly. */
+ * shift = beta - mean * scale, both also saved ([C]) so backward can recompute the ReLU mask bit-exactly.
+ * num_batches_tracked: device int64 counter bumped by one (nn.BatchNorm's buffer), or NULL. */
 int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps, int relu,
                       float* y, float* save_mean, float* save_invstd, float* save_scale,
-                      float* save_shift, void* ws, size_t ws_bytes, avid_stream_t stream);
+                      float* save_shift, int64_t* num_batches_tracked, void* ws, size_t ws_bytes,
+                      avid_stream_t stream);
 /* Eval: uses running stats. */
 int avid_bn_fwd_eval(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                      const float* running_mean, const float* running_var, float eps, int relu,
