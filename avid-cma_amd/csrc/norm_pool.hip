@@ -76,27 +76,49 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// Combine the per-block partials in fp64.  Block = 64 channels x 16 slices of the partial list (a single
-// thread per channel walking <= 1024 partials serially cost ~100 us per BN layer); LDS tree over slices.
-constexpr int FIN_SLICES = 16;
+// Combine the per-block partials in fp64.  Block = 16 channels x 64 slices of the partial list, every
+// thread keeping 4 independent row streams in flight (the first version, 64 channels x 16 slices with one
+// dependent chain of <= 64 loads per thread, took 11-13 us per BatchNorm layer — 1 ms per training step);
+// the 4 slices that share a wave are folded with lane shuffles, the 16 waves through LDS.
+constexpr int FIN_CH = 16, FIN_SLICES = 64;
 
 __device__ __forceinline__ void finalize_sums(const float* __restrict__ part, int nblk, int C, int c, int slice,
-                                              double (*sh)[2][64], double& s0, double& s1) {
-  double a = 0, b = 0;
-  if (c < C)
-    for (int k = slice; k < nblk; k += FIN_SLICES) {
-      a += (double)part[(long long)k * 2 * C + c];
-      b += (double)part[(long long)k * 2 * C + C + c];
+                                              double (*sh)[2][FIN_CH], double& s0, double& s1) {
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  if (c < C) {
+    const long long st = 2ll * C;
+    int k = slice;
+    for (; k + 3 * FIN_SLICES < nblk; k += 4 * FIN_SLICES) {
+      const float* q = part + (long long)k * st + c;
+      const float x0 = q[0], y0 = q[C];
+      const float x1 = q[FIN_SLICES * st], y1 = q[FIN_SLICES * st + C];
+      const float x2 = q[2 * FIN_SLICES * st], y2 = q[2 * FIN_SLICES * st + C];
+      const float x3 = q[3 * FIN_SLICES * st], y3 = q[3 * FIN_SLICES * st + C];
+      a0 += (double)x0; b0 += (double)y0;
+      a1 += (double)x1; b1 += (double)y1;
+      a2 += (double)x2; b2 += (double)y2;
+      a3 += (double)x3; b3 += (double)y3;
     }
-  sh[slice][0][threadIdx.x & 63] = a;
-  sh[slice][1][threadIdx.x & 63] = b;
+    for (; k < nblk; k += FIN_SLICES) {
+      a0 += (double)part[(long long)k * st + c];
+      b0 += (double)part[(long long)k * st + C + c];
+    }
+  }
+  double a = (a0 + a1) + (a2 + a3), b = (b0 + b1) + (b2 + b3);
+  a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+  a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 48) == 0) {
+    sh[wave][0][threadIdx.x & 15] = a;
+    sh[wave][1][threadIdx.x & 15] = b;
+  }
   __syncthreads();
   s0 = 0;
   s1 = 0;
-  if (slice == 0)
-    for (int k = 0; k < FIN_SLICES; ++k) {
-      s0 += sh[k][0][threadIdx.x & 63];
-      s1 += sh[k][1][threadIdx.x & 63];
+  if (threadIdx.x < FIN_CH)
+    for (int k = 0; k < 16; ++k) {
+      s0 += sh[k][0][threadIdx.x];
+      s1 += sh[k][1][threadIdx.x];
     }
 }
 
@@ -109,12 +131,12 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ save_invstd, float* __restrict__ scale,
                                                            float* __restrict__ shift,
                                                            long long* __restrict__ num_batches_tracked) {
-  __shared__ double sh[FIN_SLICES][2][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  __shared__ double sh[16][2][FIN_CH];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), slice = threadIdx.x / FIN_CH;
   if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   double s, ss;
   finalize_sums(part, nblk, C, c, slice, sh, s, ss);
-  if (slice != 0 || c >= C) return;
+  if (threadIdx.x >= FIN_CH || c >= C) return;
   const double mean = s / (double)M;
   double var = ss / (double)M - mean * mean;
   if (var < 0) var = 0;
@@ -248,11 +270,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                                int C, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ k1,
                                                                float* __restrict__ k2) {
-  __shared__ double sh[FIN_SLICES][2][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  __shared__ double sh[16][2][FIN_CH];
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), slice = threadIdx.x / FIN_CH;
   double s, sx;
   finalize_sums(part, nblk, C, c, slice, sh, s, sx);
-  if (slice != 0 || c >= C) return;
+  if (threadIdx.x >= FIN_CH || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)sx;
   k1[c] = (float)(s / (double)M);
@@ -470,7 +492,7 @@ extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* 
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
                        p.rows_per_pass, p.rows_per_block);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64 * FIN_SLICES), 0, s, part, p.nblk, (long long)M,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SLICES), 0, s, part, p.nblk, (long long)M,
                      C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift,
                      reinterpret_cast<long long*>(num_batches_tracked));
   const long long n4 = (long long)M * p.G;
@@ -514,7 +536,7 @@ extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, co
                        save_invstd, part,
                        (long long)M, C, p.G, p.rows_per_pass, p.rows_per_block, relu);
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64 * FIN_SLICES), 0, s, part, p.nblk,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SLICES), 0, s, part, p.nblk,
                      (long long)M, C, dgamma, dbeta, k1, k2);
   const long long n4 = (long long)M * p.G;
   {
