@@ -870,6 +870,8 @@ struct WgradArgs {
   int nsplit, chunks_per_split;  // chunks of 32 rows
   int kt_tiles;                  // k tiles per n tile
   long long ssB, ssT, ssH, ssW, ssC;
+  unsigned mgW, mgH, mgT;        // multiply-shift division by Wd, Hd, Td
+  int shW, shH, shT;
 };
 
 constexpr int WG_LD = 64 + 4;
@@ -895,6 +897,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradArgs p) {
   const int n0 = ntile * 64 * NB;
   // the KC (tap, c0) chunks of this k tile (uniform)
   int q_tap[KC], q_c0[KC], q_dt[KC], q_dh[KC], q_dw[KC];
+  unsigned q_off[KC];
   bool q_ok[KC];
 #pragma unroll
   for (int j = 0; j < KC; ++j) {
@@ -907,6 +910,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradArgs p) {
     const int r = q_tap[j] / p.kw;
     q_dh[j] = r % p.kh;
     q_dt[j] = r / p.kh;
+    q_off[j] = (unsigned)(((q_dt[j] * p.Hs + q_dh[j]) * p.Ws + q_dw[j]) * p.Cs + q_c0[j]) * 4;
   }
 
   const int split = blockIdx.y * 2 + grp;
@@ -940,21 +944,26 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradArgs p) {
     for (int i = 0; i < 2; ++i) {
       const int mrel = it * 32 + lrow + 16 * i;   // row relative to the split base
       const int m = chunk0 * 32 + mrel;
-      int b, td, hd, wd;
-      bool ok;
-      decode_row(m, p.M, p.Wd, p.Hd, p.Td, b, td, hd, wd, ok);
+      // row decode by multiply-shift division (the generic integer divisions cost ~100 VALU per row, per chunk)
+      const bool ok = m < p.M;
+      const unsigned mm = ok ? (unsigned)m : 0u;
+      const unsigned q1 = magic_div(mm, p.mgW, p.shW);
+      const int wd = mm - q1 * p.Wd;
+      const unsigned q2 = magic_div(q1, p.mgH, p.shH);
+      const int hd = q1 - q2 * p.Hd;
+      const int b = magic_div(q2, p.mgT, p.shT);
+      const int td = q2 - b * p.Td;
       const unsigned doff = (unsigned)(mrel * p.Cd + n0 + lcol) * 4;
 #pragma unroll
       for (int t = 0; t < NB; ++t) vd[i][t] = buf_load4(rsD, ok ? doff + t * 256 : OOB);
       const int t0 = td * p.st - p.pt, h0 = hd * p.sh - p.ph, w0 = wd * p.sw - p.pw;
+      // byte offset of tap (0,0,0), channel 0; a tap adds a uniform offset (q_off)
+      const unsigned base = (unsigned)((((b - b_lo) * p.Ts + t0) * p.Hs + h0) * p.Ws + w0) * cs4 + lcol * 4;
 #pragma unroll
       for (int j = 0; j < KC; ++j) {
-        const int ts = t0 + q_dt[j], hs = h0 + q_dh[j], ws = w0 + q_dw[j];
-        const bool okx = ok & q_ok[j] & ((unsigned)ts < (unsigned)p.Ts) & ((unsigned)hs < (unsigned)p.Hs) &
-                         ((unsigned)ws < (unsigned)p.Ws);
-        const unsigned off = (unsigned)((((b - b_lo) * p.Ts + ts) * p.Hs + hs) * p.Ws + ws) * cs4 +
-                             (q_c0[j] + lcol) * 4;
-        vx[i][j] = buf_load4(rsX, okx ? off : OOB);
+        const bool okx = ok & q_ok[j] & ((unsigned)(t0 + q_dt[j]) < (unsigned)p.Ts) &
+                         ((unsigned)(h0 + q_dh[j]) < (unsigned)p.Hs) & ((unsigned)(w0 + q_dw[j]) < (unsigned)p.Ws);
+        vx[i][j] = buf_load4(rsX, okx ? base + q_off[j] : OOB);
       }
     }
   };
@@ -1043,6 +1052,7 @@ __global__ __launch_bounds__(256) void wgrad_db_kernel(const WgradArgs p) {
   const int n0 = ntile * 64 * NB;
   // the KC (tap, c0) chunks of this k tile (uniform)
   int q_tap[KC], q_c0[KC], q_dt[KC], q_dh[KC], q_dw[KC];
+  unsigned q_off[KC];
   bool q_ok[KC];
 #pragma unroll
   for (int j = 0; j < KC; ++j) {
@@ -1055,6 +1065,7 @@ __global__ __launch_bounds__(256) void wgrad_db_kernel(const WgradArgs p) {
     const int r = q_tap[j] / p.kw;
     q_dh[j] = r % p.kh;
     q_dt[j] = r / p.kh;
+    q_off[j] = (unsigned)(((q_dt[j] * p.Hs + q_dh[j]) * p.Ws + q_dw[j]) * p.Cs + q_c0[j]) * 4;
   }
 
   const int total_chunks = (p.M + 31) / 32;
@@ -1086,21 +1097,26 @@ __global__ __launch_bounds__(256) void wgrad_db_kernel(const WgradArgs p) {
     for (int i = 0; i < 2; ++i) {
       const int mrel = (ch - chunk0) * 32 + lrow + 16 * i;   // row relative to the split base
       const int m = chunk0 * 32 + mrel;
-      int b, td, hd, wd;
-      bool ok;
-      decode_row(m, p.M, p.Wd, p.Hd, p.Td, b, td, hd, wd, ok);
-      const unsigned doff = ok ? (unsigned)(mrel * p.Cd + n0 + lcol) * 4 : OOB;
+      // row decode by multiply-shift division (the generic integer divisions cost ~100 VALU per row, per chunk)
+      const bool ok = m < p.M;
+      const unsigned mm = ok ? (unsigned)m : 0u;
+      const unsigned q1 = magic_div(mm, p.mgW, p.shW);
+      const int wd = mm - q1 * p.Wd;
+      const unsigned q2 = magic_div(q1, p.mgH, p.shH);
+      const int hd = q1 - q2 * p.Hd;
+      const int b = magic_div(q2, p.mgT, p.shT);
+      const int td = q2 - b * p.Td;
+      const unsigned doff = (unsigned)(mrel * p.Cd + n0 + lcol) * 4;
 #pragma unroll
       for (int t = 0; t < NB; ++t) vd[i][t] = buf_load4(rsD, ok ? doff + t * 256 : OOB);
       const int t0 = td * p.st - p.pt, h0 = hd * p.sh - p.ph, w0 = wd * p.sw - p.pw;
+      // byte offset of tap (0,0,0), channel 0; a tap adds a uniform offset (q_off)
+      const unsigned base = (unsigned)((((b - b_lo) * p.Ts + t0) * p.Hs + h0) * p.Ws + w0) * cs4 + lcol * 4;
 #pragma unroll
       for (int j = 0; j < KC; ++j) {
-        const int ts = t0 + q_dt[j], hs = h0 + q_dh[j], ws = w0 + q_dw[j];
-        const bool okx = ok & q_ok[j] & ((unsigned)ts < (unsigned)p.Ts) & ((unsigned)hs < (unsigned)p.Hs) &
-                         ((unsigned)ws < (unsigned)p.Ws);
-        const unsigned off = (unsigned)((((b - b_lo) * p.Ts + ts) * p.Hs + hs) * p.Ws + ws) * cs4 +
-                             (q_c0[j] + lcol) * 4;
-        vx[i][j] = buf_load4(rsX, okx ? off : OOB);
+        const bool okx = ok & q_ok[j] & ((unsigned)(t0 + q_dt[j]) < (unsigned)p.Ts) &
+                         ((unsigned)(h0 + q_dh[j]) < (unsigned)p.Hs) & ((unsigned)(w0 + q_dw[j]) < (unsigned)p.Ws);
+        vx[i][j] = buf_load4(rsX, okx ? base + q_off[j] : OOB);
       }
     }
   };
@@ -1942,6 +1958,9 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
   a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
   a.M = d->B * d->To * d->Ho * d->Wo;
   a.nsplit = pl.nsplit; a.chunks_per_split = pl.cps; a.kt_tiles = pl.kt_tiles;
+  magic_for(a.Wd, a.mgW, a.shW);
+  magic_for(a.Hd, a.mgH, a.shH);
+  magic_for(a.Td, a.mgT, a.shT);
   fill_src_strides(d, a.ssB, a.ssT, a.ssH, a.ssW, a.ssC);
   dim3 grid((unsigned)(pl.kt_tiles * pl.n_tiles), (unsigned)pl.nsplit);
   dim3 grid_pp((unsigned)(pl.kt_tiles * pl.n_tiles), (unsigned)((pl.nsplit + 1) / 2));   // two splits per workgroup
