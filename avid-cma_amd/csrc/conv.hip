@@ -877,7 +877,7 @@ struct WgradArgs {
 constexpr int WG_LD = 64 + 4;
 
 template <int NB, int KC>
-__global__ __launch_bounds__(512) void wgrad_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(512, 4) void wgrad_kernel(const WgradArgs p) {
   // Ping-pong like igemm_kernel: two groups of 4 waves, each reducing its own pixel range (split
   // 2*blockIdx.y + grp) of the same dw tile through a private single-buffered LDS stage, shifted by one
   // phase so one wave per SIMD is always in its MFMA phase.
@@ -997,17 +997,33 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradArgs p) {
   if (grp == 1) __syncthreads();
   for (int it = 0; it < nloop; ++it) {
     // phase A: matrix pipe
+    // fragments of k-step pair kp+1 are fetched before the MFMAs of pair kp issue (pinned with
+    // sched_barrier: left alone the compiler sinks each ds_read next to its use and exposes the LDS latency
+    // sixteen times per chunk); a pair per fetch keeps the ds_read2_b32 merging
+    float a[2][2][NB], b[2][2][KC];
+    auto frag = [&](int kp, int buf) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float a[NB], b[KC];
+      for (int q = 0; q < 2; ++q) {
+        const int kk = 2 * kp + q;
 #pragma unroll
-      for (int t = 0; t < NB; ++t) a[t] = Db[(2 * kk + h) * DW + t * 32];             // A[i = n][k = m]
+        for (int t = 0; t < NB; ++t) a[buf][q][t] = Db[(2 * kk + h) * DW + t * 32];             // A[i = n][k = m]
 #pragma unroll
-      for (int j = 0; j < KC; ++j) b[j] = Xb[j * 32 * WG_LD + (2 * kk + h) * WG_LD];  // B[k = m][j = c]
+        for (int j = 0; j < KC; ++j) b[buf][q][j] = Xb[j * 32 * WG_LD + (2 * kk + h) * WG_LD];  // B[k = m][j = c]
+      }
+    };
+    frag(0, 0);
 #pragma unroll
-      for (int t = 0; t < NB; ++t)
+    for (int kp = 0; kp < 8; ++kp) {
+      if (kp + 1 < 8) frag(kp + 1, (kp + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < KC; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[j], acc[t][j], 0, 0, 0);
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+          for (int j = 0; j < KC; ++j)
+            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][q][t], b[kp & 1][q][j], acc[t][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     // phase B: stage
@@ -1153,17 +1169,30 @@ __global__ __launch_bounds__(256) void wgrad_db_kernel(const WgradArgs p) {
     if (ch + 1 < chunk1) load_chunk(ch + 1);
     const float* Db = smem + cur * BUF + wm * 32 * NB + l31;
     const float* Xb = smem + cur * BUF + 32 * DW + wn * 32 + l31;
+    float a[2][2][NB], b[2][2][KC];   // fragment prefetch one k-step pair ahead (see wgrad_kernel)
+    auto frag = [&](int kp, int buf) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float a[NB], b[KC];
+      for (int q = 0; q < 2; ++q) {
+        const int kk = 2 * kp + q;
 #pragma unroll
-      for (int t = 0; t < NB; ++t) a[t] = Db[(2 * kk + h) * DW + t * 32];             // A[i = n][k = m]
+        for (int t = 0; t < NB; ++t) a[buf][q][t] = Db[(2 * kk + h) * DW + t * 32];             // A[i = n][k = m]
 #pragma unroll
-      for (int j = 0; j < KC; ++j) b[j] = Xb[j * 32 * WG_LD + (2 * kk + h) * WG_LD];  // B[k = m][j = c]
+        for (int j = 0; j < KC; ++j) b[buf][q][j] = Xb[j * 32 * WG_LD + (2 * kk + h) * WG_LD];  // B[k = m][j = c]
+      }
+    };
+    frag(0, 0);
 #pragma unroll
-      for (int t = 0; t < NB; ++t)
+    for (int kp = 0; kp < 8; ++kp) {
+      if (kp + 1 < 8) frag(kp + 1, (kp + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < KC; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[j], acc[t][j], 0, 0, 0);
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+          for (int j = 0; j < KC; ++j)
+            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][q][t], b[kp & 1][q][j], acc[t][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (ch + 1 < chunk1) store_chunk(cur ^ 1);
     __syncthreads();
