@@ -1996,7 +1996,7 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
   {
     const double K = (double)a.kt * a.kh * a.kw * a.Cs;
     const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
-    const char* name = !pl.vec ? "wgrad_gather_kernel" : (pl.NB == 1 ? "wgrad_kernel<1,3>" : "wgrad_kernel<2,2>");
+    const char* name = !pl.vec ? "wgrad_gather_kernel" : (pl.NB == 1 ? "wgrad_kernel<1,3>" : "wgrad_db_kernel<2,2>");
     ScopedTimer t(s, name, 2.0 * a.M * a.Cd * K, 4.0 * (srcpix * a.Cs + (double)a.M * a.Cd + (double)a.Cd * K));
     if (!pl.vec) {
       const size_t lds = sizeof(float) * 4 * 32 * WG_LD + sizeof(int2) * 64;

@@ -154,7 +154,7 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         clips = bs * world * args.steps / dt
-        mfma = {k: v for k, v in kern.items() if v["flops"] > 0 and ("igemm" in k or "wgrad_kernel" in k)}
+        mfma = {k: v for k, v in kern.items() if v["flops"] > 0 and ("igemm" in k or "wgrad" in k)}
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         d = mfma[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
