@@ -1224,6 +1224,213 @@ __global__ __launch_bounds__(256) void wgrad_db_kernel(const WgradArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-table variant: the weight-gradient kernel of every vector-path layer.
+//
+// A GEMM of this shape with a GEMM's loader (tools/gemm_tn_lab.hip: reduction-major operands, 4-byte
+// fragment reads, 4 waves, double-buffered) runs at 113-119 TFLOP/s; the two kernels above reach 80-98
+// because every one of the 16 threads that share a pixel row re-derives that row's coordinates, tap
+// validity and offset for every 32-pixel chunk (~130 VALU per thread per chunk — and an MFMA only overlaps
+// with OTHER waves' instructions).  Here the workgroup decodes each of its rows ONCE into an LDS table
+// (byte offset of tap (0,0,0), 3x8 validity bits); per chunk a thread reads its two entries and spends
+// 4 VALU per tap; the dy row step rides in the scalar soffset and rows past M fall off num_records.
+// Loads of chunk c+2 and the LDS stores of chunk c+1 are issued inside the MFMA stream of chunk c.
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_TABC = 32;   // chunks (of 32 pixel rows) covered by one fill of the row table: 1024 rows, 8 KB
+
+template <int NB, int KC>
+__global__ __launch_bounds__(256, 2) void wgrad_tab_kernel(const WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int DW = 64 * NB + 4;                 // dy tile row (floats)
+  constexpr int BUF = 32 * (DW + KC * WG_LD);     // one stage
+  uint2* tab = reinterpret_cast<uint2*>(smem + 2 * BUF);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ntaps = p.kt * p.kh * p.kw;
+  const int K = ntaps * p.Cs;
+  const int cpt = p.Cs / 64, nchunks = ntaps * cpt;
+
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);   // dw tiles of one pixel range stay on one XCD
+  const int bx = (int)(lid % (unsigned)p.tiles), by = (int)(lid / (unsigned)p.tiles);
+  const int ktile = bx % p.kt_tiles, ntile = bx / p.kt_tiles;
+  const int n0 = ntile * 64 * NB;
+  const int lrow = tid >> 4;         // 0..15 (+16)
+  const int lcol = (tid & 15) * 4;   // 0..60
+  // the KC (tap, c0) chunks of this k tile (uniform): offset from tap (0,0,0), required validity bits
+  int q_tap[KC], q_c0[KC];
+  unsigned q_off[KC], q_need[KC];
+  bool q_ok[KC];
+#pragma unroll
+  for (int j = 0; j < KC; ++j) {
+    const int q = ktile * KC + j;
+    q_ok[j] = q < nchunks;
+    const int qq = q_ok[j] ? q : 0;
+    q_tap[j] = qq / cpt;
+    q_c0[j] = (qq - q_tap[j] * cpt) * 64;
+    const int dw = q_tap[j] % p.kw, r = q_tap[j] / p.kw;
+    const int dh = r % p.kh, dt = r / p.kh;
+    q_off[j] = (unsigned)(((dt * p.Hs + dh) * p.Ws + dw) * p.Cs + q_c0[j] + lcol) * 4;
+    q_need[j] = q_ok[j] ? (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw)) : 0xffffffffu;
+  }
+
+  const int total_chunks = (p.M + 31) / 32;
+  const int chunk0 = by * p.chunks_per_split;
+  const int chunk1 = min(chunk0 + p.chunks_per_split, total_chunks);
+
+  // buffer descriptors (dy and x based at the first batch item / row this split touches)
+  const int pix_out = p.Td * p.Hd * p.Wd, pix_in = p.Ts * p.Hs * p.Ws;
+  int b_lo = (chunk0 * 32) / pix_out;
+  if (b_lo >= p.B) b_lo = p.B - 1;
+  const long long x_base = (long long)b_lo * pix_in * p.Cs;
+  long long x_bytes = ((long long)p.B * pix_in * p.Cs - x_base) * 4;
+  if (x_bytes > 0x7fffffffll) x_bytes = 0x7fffffffll;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + x_base), 0, (int)x_bytes, 0x00020000);
+  const long long d_base = (long long)min(chunk0 * 32, p.M - 1) * p.Cd;
+  long long d_bytes = ((long long)p.M * p.Cd - d_base) * 4;     // exact: rows >= M read as zeros
+  if (d_bytes > 0x7fffffffll) d_bytes = 0x7fffffffll;
+  const __amdgpu_buffer_rsrc_t rsD =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + d_base), 0, (int)d_bytes, 0x00020000);
+  const int cs4 = p.Cs * 4;
+  unsigned doff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) doff[i] = (unsigned)((lrow + 16 * i) * p.Cd + n0 + lcol) * 4;
+
+  floatx4 vd[2][NB], vx[2][KC];
+  int cb = chunk0;   // first chunk covered by the row table
+
+  auto fill_table = [&]() {
+#pragma unroll
+    for (int r = tid; r < WG_TABC * 32; r += 256) {
+      const int m = cb * 32 + r;
+      const bool ok = m < p.M;
+      const unsigned mm = ok ? (unsigned)m : 0u;
+      const unsigned q1 = magic_div(mm, p.mgW, p.shW);
+      const int wd = mm - q1 * p.Wd;
+      const unsigned q2 = magic_div(q1, p.mgH, p.shH);
+      const int hd = q1 - q2 * p.Hd;
+      const int b = magic_div(q2, p.mgT, p.shT);
+      const int td = q2 - b * p.Td;
+      const int t0 = td * p.st - p.pt, h0 = hd * p.sh - p.ph, w0 = wd * p.sw - p.pw;
+      unsigned mt = 0, mh = 0, mw = 0;
+      for (int d = 0; d < p.kt; ++d) mt |= ((unsigned)(t0 + d) < (unsigned)p.Ts ? 1u : 0u) << d;
+      for (int d = 0; d < p.kh; ++d) mh |= ((unsigned)(h0 + d) < (unsigned)p.Hs ? 1u : 0u) << d;
+      for (int d = 0; d < p.kw; ++d) mw |= ((unsigned)(w0 + d) < (unsigned)p.Ws ? 1u : 0u) << d;
+      uint2 e;
+      e.x = (unsigned)((((b - b_lo) * p.Ts + t0) * p.Hs + h0) * p.Ws + w0) * cs4;
+      e.y = ok ? (mt | (mh << 8) | (mw << 16)) : 0u;
+      tab[r] = e;
+    }
+  };
+  auto load_chunk = [&](int ch) {
+    const int soff = (ch - chunk0) * 32 * p.Cd * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint2 e = tab[(ch - cb) * 32 + lrow + 16 * i];
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+        vd[i][t] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsD, doff[i] + t * 256, soff, 0));
+#pragma unroll
+      for (int j = 0; j < KC; ++j)
+        vx[i][j] = buf_load4(rsX, (e.y & q_need[j]) == q_need[j] ? e.x + q_off[j] : OOB);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* Ds = smem + buf * BUF;
+    float* Xs = Ds + 32 * DW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+        *reinterpret_cast<floatx4*>(&Ds[(lrow + 16 * i) * DW + t * 64 + lcol]) = vd[i][t];
+#pragma unroll
+      for (int j = 0; j < KC; ++j)
+        *reinterpret_cast<floatx4*>(&Xs[j * 32 * WG_LD + (lrow + 16 * i) * WG_LD + lcol]) = vx[i][j];
+    }
+  };
+
+  floatx16 acc[NB][KC];
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+
+  int u = 0;
+  // one chunk: 8 k-step pairs of (fragment prefetch | staging in the shadow of the pair's MFMAs)
+  auto chunk_body = [&](int ch, auto ST, auto LD) {
+    const float* Db = smem + u * BUF + wm * 32 * NB + l31;
+    const float* Xb = smem + u * BUF + 32 * DW + wn * 32 + l31;
+    float a[2][2][NB], b[2][2][KC];
+    auto frag = [&](int kp, int buf) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int kk = 2 * kp + q;
+#pragma unroll
+        for (int t = 0; t < NB; ++t) a[buf][q][t] = Db[(2 * kk + h) * DW + t * 32];             // A[i = n][k = m]
+#pragma unroll
+        for (int j = 0; j < KC; ++j) b[buf][q][j] = Xb[j * 32 * WG_LD + (2 * kk + h) * WG_LD];  // B[k = m][j = c]
+      }
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int kp = 0; kp < 8; ++kp) {
+      if (kp + 1 < 8) frag(kp + 1, (kp + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (decltype(ST)::value && kp == 0) store_chunk(u ^ 1);
+      if (decltype(LD)::value && kp == 2) load_chunk(ch + 2);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+          for (int j = 0; j < KC; ++j)
+            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][q][t], b[kp & 1][q][j], acc[t][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  for (; cb < chunk1; cb += WG_TABC) {
+    const int ce = min(cb + WG_TABC, chunk1);
+    __syncthreads();                 // the previous block's table reads are done
+    fill_table();
+    __syncthreads();
+    load_chunk(cb);
+    store_chunk(u);
+    if (cb + 1 < ce) load_chunk(cb + 1);
+    __syncthreads();
+    int ch = cb;
+    for (; ch + 2 < ce; ++ch, u ^= 1) {          // steady state
+      chunk_body(ch, std::true_type{}, std::true_type{});
+      __syncthreads();
+    }
+    if (ch + 1 < ce) {
+      chunk_body(ch, std::true_type{}, std::false_type{});
+      __syncthreads();
+      ++ch;
+      u ^= 1;
+    }
+    chunk_body(ch, std::false_type{}, std::false_type{});
+    u ^= 1;
+  }
+
+  float* o = p.out + (long long)by * p.Cd * K;
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      if (!q_ok[j]) continue;
+      const int kcol = q_tap[j] * p.Cs + q_c0[j] + wn * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 32 * NB + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        o[(long long)n * K + kcol] = acc[t][j][r];
+      }
+    }
+}
+
 // gather-path wgrad (stems): 64(n) x 64(k) tile, k -> tap table in LDS
 __global__ __launch_bounds__(256) void wgrad_gather_kernel(const WgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1955,7 +2162,7 @@ static WgradPlan wgrad_plan(const avid_conv_desc* d) {
   }
   const long long tiles = (long long)pl.kt_tiles * pl.n_tiles;
   const long long chunks = ceil_div(M, 32);
-  long long want = (pl.vec && pl.NB == 1 ? 2 : 1) * ((2 * 256) / tiles);   // ping-pong workgroups take two splits
+  long long want = (2 * 256) / tiles;   // 4-wave workgroups, two per CU
   long long max_split = chunks / 8 > 0 ? chunks / 8 : 1;  // >= 8 chunks (256 rows) per split
   long long ns = want < 1 ? 1 : (want > max_split ? max_split : want);
   if (ns > 512) ns = 512;
@@ -2008,29 +2215,29 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
   {
     const double K = (double)a.kt * a.kh * a.kw * a.Cs;
     const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
-    const char* name = !pl.vec ? "wgrad_gather_kernel" : (pl.NB == 1 ? "wgrad_kernel<1,3>" : "wgrad_db_kernel<2,2>");
+    const char* name = !pl.vec ? "wgrad_gather_kernel" : (pl.NB == 1 ? "wgrad_tab_kernel<1,3>" : "wgrad_tab_kernel<2,2>");
     ScopedTimer t(s, name, 2.0 * a.M * a.Cd * K, 4.0 * (srcpix * a.Cs + (double)a.M * a.Cd + (double)a.Cd * K));
     if (!pl.vec) {
       const size_t lds = sizeof(float) * 4 * 32 * WG_LD + sizeof(int2) * 64;
       hipLaunchKernelGGL(wgrad_gather_kernel, grid, dim3(256), lds, s, a);
     } else if (pl.NB == 1) {
-      const size_t lds = sizeof(float) * 2 * 32 * (64 * 1 + 4 + 3 * WG_LD);   // two groups, one stage each
+      const size_t lds = sizeof(float) * 2 * 32 * (64 * 1 + 4 + 3 * WG_LD) + sizeof(uint2) * WG_TABC * 32;
       static bool set = false;
       if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1, 3>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tab_kernel<1, 3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         set = true;
       }
-      hipLaunchKernelGGL((wgrad_kernel<1, 3>), dim3(grid_pp.x * grid_pp.y), dim3(512), lds, s, a);
+      hipLaunchKernelGGL((wgrad_tab_kernel<1, 3>), dim3(grid.x * grid.y), dim3(256), lds, s, a);
     } else {
-      const size_t lds = sizeof(float) * 2 * 32 * (64 * 2 + 4 + 2 * WG_LD);
+      const size_t lds = sizeof(float) * 2 * 32 * (64 * 2 + 4 + 2 * WG_LD) + sizeof(uint2) * WG_TABC * 32;
       static bool set = false;
       if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_db_kernel<2, 2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tab_kernel<2, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         set = true;
       }
-      hipLaunchKernelGGL((wgrad_db_kernel<2, 2>), dim3(grid.x * grid.y), dim3(256), lds, s, a);
+      hipLaunchKernelGGL((wgrad_tab_kernel<2, 2>), dim3(grid.x * grid.y), dim3(256), lds, s, a);
     }
   }
   rc = check_launch("wgrad");
