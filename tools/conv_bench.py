@@ -69,7 +69,7 @@ for name, cin, cout, k, st, pd, (T, H, W) in L:
     fr_us, _ = pick(res["fwd"], "splitk")
     d_us, dn = pick(res["bwd"], "igemm_", 1)
     dr_us, _ = pick(res["bwd"], "splitk"); dt_us, _ = pick(res["bwd"], "weight_tr")
-    w_us, wn = pick(res["bwd"], "wgrad_kernel")
+    w_us, wn = pick(res["bwd"], "wgrad_tab")
     wr_us, _ = pick(res["bwd"], "wgrad_reduce")
     print(f"{name:10s} {M:8d} {K:5d} {cout:4d} | {f_us+fr_us:8.1f} {fl/(f_us+fr_us)/1e6:6.1f} | {d_us+dr_us+dt_us:8.1f} {fl/(d_us+dr_us+dt_us)/1e6:6.1f} | "
           f"{w_us+wr_us:8.1f} {fl/(w_us+wr_us)/1e6:6.1f}  {fn+dn+wn} (+red {fr_us:.0f}/{dr_us+dt_us:.0f}/{wr_us:.0f})")
