@@ -63,6 +63,8 @@ struct ConvArgs {
   // pk_tail_units = tail_tiles * pk_f units after them are (tile, K-range) pieces, one per workgroup, that
   // write partial slabs to `part` (rows [part_row_begin, M))
   int pk_full, pk_tail_units, pk_f, pk_kps;
+  unsigned cls_mg[8][3];   // igemm_pk_kernel<STRIDED>: multiply-shift division by a class's (T,H,W) extents
+  int cls_shf[8][3];
   int pk_rot;      // tail unit u runs on workgroup (u + pk_rot) mod G: the ones that got one full tile less
   int pk_paired;   // grid = 2 workgroups per CU: number them so that v and v + G/2 share a CU
 };
@@ -353,8 +355,9 @@ __device__ __forceinline__ unsigned magic_div(unsigned n, unsigned magic, int sh
   return (unsigned)(((unsigned long long)n * magic) >> shift);
 }
 
-template <int WM, int WN, int TM, int TN, int MODE>
+template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArgs p) {
+  static_assert(!STRIDED || MODE == 1, "parity classes are a dgrad construct");
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RPP = NT / 8;                   // rows staged per pass: 8 lanes x 16 B cover a 32-float row
@@ -398,8 +401,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   tslot += tslot < 0 ? G : 0;
   const int nseg = n_full + (tslot < p.pk_tail_units ? 1 : 0);
   if (nseg == 0) return;
+  // Strided dgrad (STRIDED): the tile list is the concatenation of the stride-parity classes' tile lists
+  // (cls_begin, in tiles); a class is a dense unit-stride problem over its own pixel grid and tap subset,
+  // so its K extent differs (and may be empty: those tiles only write zeros / the addend).
+  auto cls_of = [&](int tile) {
+    int c = 0;
+    while (c + 1 < p.ncls && tile >= p.cls_begin[c + 1]) ++c;
+    return c;
+  };
   auto seg_info = [&](int j, int& tile, int& k0, int& k1, int& split) {
-    if (j < n_full) {
+    if (STRIDED) {   // units = (tile, piece of its own K range), all dealt round-robin
+      const int u = slot + j * G;
+      tile = u / p.pk_f;
+      const int piece = u - tile * p.pk_f;
+      const int c = cls_of(tile);
+      const int nkc = p.cls_nd[c][0] * p.cls_nd[c][1] * p.cls_nd[c][2] * cpt;
+      const int kps = (nkc + p.pk_f - 1) / p.pk_f;
+      k0 = piece * kps < nkc ? piece * kps : nkc;
+      k1 = k0 + kps < nkc ? k0 + kps : nkc;
+      split = p.pk_f > 1 ? piece : -1;
+    } else if (j < n_full) {
       tile = slot + j * G; k0 = 0; k1 = nk; split = -1;
     } else {
       tile = p.pk_full + tslot / p.pk_f;
@@ -413,6 +434,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   // ---- loader state (two k-tiles ahead of the MFMAs, possibly already in the next segment)
   int ld_seg = 0, ld_ks = 0, ld_kend = 0;
   int ld_dt = 0, ld_dh = 0, ld_dw = 0, ld_c0 = 0, ld_tap = 0;   // position in the K loop (tap, channel block)
+  int ld_nh = p.kh, ld_nw = p.kw, ld_cls = 0;                  // tap extents of the loader's class (STRIDED)
   long long ld_base = 0;                                       // element offset of the loader tile's batch span
   unsigned a_base[PA], a_mask[PA], a_cur[PA];                  // tap-(0,0,0) offset, tap validity, current voffset
   unsigned b_off[PB];
@@ -434,9 +456,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     }
   };
   auto setup_tile = [&](int tile) {
-    const int mt = tile / ntn, nt = tile - mt * ntn;
+    int c = 0, cT = p.Td, cH = p.Hd, cW = p.Wd, cM = p.M, cpix = pix_d, lt = tile;
+    unsigned mgW = p.mgW, mgH = p.mgH, mgT = p.mgT;
+    int shW = p.shW, shH = p.shH, shT = p.shT;
+    int offt = p.pt, offh = p.ph, offw = p.pw, ndt = p.kt, ndh = p.kh, ndw = p.kw;
+    if (STRIDED) {
+      c = ld_cls;
+      lt = tile - p.cls_begin[c];
+      cT = p.cls_n[c][0]; cH = p.cls_n[c][1]; cW = p.cls_n[c][2];
+      cpix = cT * cH * cW;
+      cM = p.B * cpix;
+      mgT = p.cls_mg[c][0]; mgH = p.cls_mg[c][1]; mgW = p.cls_mg[c][2];
+      shT = p.cls_shf[c][0]; shH = p.cls_shf[c][1]; shW = p.cls_shf[c][2];
+      // source coordinate of class tap j for class-local position q: q + off - j  (off is exact by construction)
+      offt = (p.cls_p0[c][0] + p.pt - p.cls_d0[c][0]) / p.st;
+      offh = (p.cls_p0[c][1] + p.ph - p.cls_d0[c][1]) / p.sh;
+      offw = (p.cls_p0[c][2] + p.pw - p.cls_d0[c][2]) / p.sw;
+      ndt = p.cls_nd[c][0]; ndh = p.cls_nd[c][1]; ndw = p.cls_nd[c][2];
+    }
+    const int mt = lt / ntn, nt = lt - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
-    int b_lo = m0 / pix_d;
+    int b_lo = m0 / cpix;
     if (b_lo >= p.B) b_lo = p.B - 1;
     b_lo = __builtin_amdgcn_readfirstlane(b_lo);
     const long long base = (long long)b_lo * pix_per_b * p.Cs;
@@ -445,14 +485,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const unsigned m = m0 + lrow + RPP * i;
-      const bool ok = m < (unsigned)p.M;
+      const bool ok = m < (unsigned)cM;
       const unsigned mm = ok ? m : 0u;
-      const unsigned q1 = magic_div(mm, p.mgW, p.shW);
-      const int wd = mm - q1 * p.Wd;
-      const unsigned q2 = magic_div(q1, p.mgH, p.shH);
-      const int hd = q1 - q2 * p.Hd;
-      const int b = magic_div(q2, p.mgT, p.shT);
-      const int td = q2 - b * p.Td;
+      const unsigned q1 = magic_div(mm, mgW, shW);
+      const int wd = mm - q1 * cW;
+      const unsigned q2 = magic_div(q1, mgH, shH);
+      const int hd = q1 - q2 * cH;
+      const int b = magic_div(q2, mgT, shT);
+      const int td = q2 - b * cT;
       int t0, h0, w0;
       unsigned mt_, mh, mw;
       if (MODE == 0) {   // source coordinate of tap d: t0 + d
@@ -460,11 +500,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
         mt_ = range_mask(-t0, p.Ts - 1 - t0, p.kt);
         mh = range_mask(-h0, p.Hs - 1 - h0, p.kh);
         mw = range_mask(-w0, p.Ws - 1 - w0, p.kw);
-      } else {           // unit-stride dgrad: t0 - d
-        t0 = td + p.pt; h0 = hd + p.ph; w0 = wd + p.pw;
-        mt_ = range_mask(t0 - p.Ts + 1, t0, p.kt);
-        mh = range_mask(h0 - p.Hs + 1, h0, p.kh);
-        mw = range_mask(w0 - p.Ws + 1, w0, p.kw);
+      } else {           // dgrad: t0 - d (unit stride, or class-local coordinates of a strided one)
+        t0 = td + offt; h0 = hd + offh; w0 = wd + offw;
+        mt_ = range_mask(t0 - p.Ts + 1, t0, ndt);
+        mh = range_mask(h0 - p.Hs + 1, h0, ndh);
+        mw = range_mask(w0 - p.Ws + 1, w0, ndw);
       }
       a_mask[i] = ok ? (mt_ | (mh << 8) | (mw << 16)) : 0u;
       a_base[i] = (unsigned)((((b - b_lo) * p.Ts + t0) * p.Hs + h0) * p.Ws + w0) * cs4 + lcol * 4;
@@ -493,18 +533,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       vb[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], soff_b, 0));
   };
   const auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-  auto setup_seg = [&](int j) {
+  // weight tap index of the loader's current (class-local) tap
+  auto set_tap = [&]() {
+    if (STRIDED) {
+      const int c = ld_cls;
+      ld_tap = sgpr(((p.cls_d0[c][0] + ld_dt * p.st) * p.kh + p.cls_d0[c][1] + ld_dh * p.sh) * p.kw + p.cls_d0[c][2] +
+                    ld_dw * p.sw);
+    } else {
+      ld_tap = sgpr((ld_dt * p.kh + ld_dh) * p.kw + ld_dw);
+    }
+  };
+  auto setup_seg = [&](int j) {   // loader enters segment j (STRIDED: the next segment that has any k-tiles)
     int tile, k0, k1, split;
     seg_info(j, tile, k0, k1, split);
+    if (STRIDED) {
+      while (k1 == k0 && j + 1 < nseg) seg_info(++j, tile, k0, k1, split);
+      ld_seg = sgpr(k1 == k0 ? nseg : j);
+      if (k1 == k0) return;
+      ld_cls = sgpr(cls_of(tile));
+      ld_nh = sgpr(p.cls_nd[ld_cls][1]);
+      ld_nw = sgpr(p.cls_nd[ld_cls][2]);
+    }
     ld_ks = sgpr(k0);
     ld_kend = sgpr(k1);
     const int tapi = k0 / cpt;
     ld_c0 = sgpr((k0 - tapi * cpt) * BK);
-    ld_tap = sgpr(tapi);
-    ld_dw = sgpr(tapi % p.kw);
-    const int r = tapi / p.kw;
-    ld_dh = sgpr(r % p.kh);
-    ld_dt = sgpr(r / p.kh);
+    ld_dw = sgpr(tapi % ld_nw);
+    const int r = tapi / ld_nw;
+    ld_dh = sgpr(r % ld_nh);
+    ld_dt = sgpr(r / ld_nh);
+    set_tap();
     setup_tile(tile);
   };
   auto advance = [&]() {
@@ -516,12 +574,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     } else if (ld_c0 == p.Cs) {      // next tap
       ld_c0 = 0;
       int dw = ld_dw + 1, dh = ld_dh, dt = ld_dt;
-      if (dw == p.kw) { dw = 0; ++dh; }
-      if (dh == p.kh) { dh = 0; ++dt; }
+      if (dw == ld_nw) { dw = 0; ++dh; }
+      if (dh == ld_nh) { dh = 0; ++dt; }
       ld_dw = sgpr(dw);
       ld_dh = sgpr(dh);
       ld_dt = sgpr(dt);
-      ld_tap = sgpr(ld_tap + 1);
+      set_tap();
       retap();
     }
   };
@@ -534,19 +592,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
 
   // ---- prologue: k-tile 0 -> LDS stage 0, k-tile 1 -> registers
   setup_seg(0);
-  issue_loads();
-  advance();
-  store_stage(smem);
-  if (ld_seg < nseg) {              // registers hold the k-tile after the one in LDS
+  if (!STRIDED || ld_seg < nseg) {  // (a strided workgroup may own nothing but empty classes)
     issue_loads();
     advance();
+    store_stage(smem);
+    if (ld_seg < nseg) {            // registers hold the k-tile after the one in LDS
+      issue_loads();
+      advance();
+    }
   }
   __syncthreads();
 
   const int a_frag = (wm * TM * 32 + l31) * LDK + h * 4;
   const int b_frag = (BM + wn * TN * 32 + l31) * LDK + h * 4;
   int left = n_full * nk;   // k-tiles still to be multiplied, including the one in LDS
-  if (nseg > n_full) {
+  if (STRIDED) {
+    left = 0;
+    for (int j = 0; j < nseg; ++j) {
+      int tile, k0, k1, split;
+      seg_info(j, tile, k0, k1, split);
+      left += k1 - k0;
+    }
+  } else if (nseg > n_full) {
     int tile, k0, k1, split;
     seg_info(n_full, tile, k0, k1, split);
     left += k1 - k0;
@@ -646,6 +713,52 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     // ---- epilogue of this segment: buffer stores bounded by num_records (rows past M are dropped by the
     // hardware), the row step in soffset; they drain under the next tile's MFMAs.  A K-split piece writes
     // its raw partial sums to the slab of its split; splitk_reduce_kernel applies the epilogue.
+    if (STRIDED) {
+      // class-local rows -> destination pixels are not an affine map: one decode per tile row into LDS, then
+      // buffer stores through the looked-up row offsets (rows past the class fall off num_records)
+      int* drow = reinterpret_cast<int*>(smem + 2 * STAGE);
+      const int c = cls_of(tile);
+      const int lt = tile - p.cls_begin[c];
+      const int mt = lt / ntn, nt = lt - mt * ntn;
+      const int n0 = nt * BN;
+      const int cT = p.cls_n[c][0], cH = p.cls_n[c][1], cW = p.cls_n[c][2];
+      __syncthreads();
+      if (tid < BM) {
+        const unsigned m = mt * BM + tid;
+        const bool ok = m < (unsigned)(p.B * cT * cH * cW);
+        const unsigned mm = ok ? m : 0u;
+        const unsigned q1 = magic_div(mm, p.cls_mg[c][2], p.cls_shf[c][2]);
+        const int wd = mm - q1 * cW;
+        const unsigned q2 = magic_div(q1, p.cls_mg[c][1], p.cls_shf[c][1]);
+        const int hd = q1 - q2 * cH;
+        const int b = magic_div(q2, p.cls_mg[c][0], p.cls_shf[c][0]);
+        const int td = q2 - b * cT;
+        const int dst = ((b * p.Td + p.cls_p0[c][0] + td * p.st) * p.Hd + p.cls_p0[c][1] + hd * p.sh) * p.Wd +
+                        p.cls_p0[c][2] + wd * p.sw;
+        drow[tid] = ok ? dst * row_bytes : (int)OOB;
+      }
+      __syncthreads();
+      const bool direct = split < 0;   // K-split pieces write raw sums to their slab, in destination row order
+      const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(direct ? p.dst : p.part + (long long)split * p.M * p.Cd), 0, (int)((long long)p.M * row_bytes), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.addend ? p.addend : p.dst), 0, (int)((long long)p.M * row_bytes), 0x00020000);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) {
+          const int col4 = (n0 + (wn * TN + jj) * 32 + l31) * 4;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned voff = (unsigned)drow[(wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] + col4;
+            float v = acc[i][jj][r];
+            if (direct && p.addend) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, voff, 0, 0));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff, 0, 0);
+          }
+        }
+      }
+      continue;
+    }
     const int mt = tile / ntn, nt = tile - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
     int rows = p.M - m0;
@@ -1791,18 +1904,18 @@ static void magic_for(int d, unsigned& magic, int& shift) {
   magic = (unsigned)(((1ull << shift) + (unsigned)d - 1) / (unsigned)d);
 }
 
-template <int WM, int WN, int TM, int TN, int MODE>
+template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
 static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + (STRIDED ? sizeof(int) * BM : 0);
   static bool attr_set = false;
-  auto kern = igemm_pk_kernel<WM, WN, TM, TN, MODE>;
+  auto kern = igemm_pk_kernel<WM, WN, TM, TN, MODE, STRIDED>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   static char name[64] = "";
-  if (!name[0]) snprintf(name, sizeof(name), "igemm_pk_kernel<%d,%d,%d,%d,%d>", WM, WN, TM, TN, MODE);
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_pk_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, MODE, STRIDED ? "s2" : "");
   const double K = (double)a.kt * a.kh * a.kw * a.Cs;
   const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
   // algorithmic work: 2*M*N*K flops; bytes = one read of src + weights, one write of dst (+ addend)
@@ -1871,8 +1984,93 @@ static void build_classes(ConvArgs& a, int BM) {
   a.cls_ptiles_total = begin;
 }
 
+// K pieces per tile of a strided dgrad: few (heavy, uneven) tiles are cut so that ~1000+ units can be dealt
+static int strided_splits(int total_tiles) {
+  if (total_tiles >= 768) return 1;
+  int f = (1024 + total_tiles - 1) / total_tiles;
+  return f > 8 ? 8 : f;
+}
+
+// Parity classes of a strided dgrad for the persistent kernel: tile-unit prefix sums, classes ordered by
+// decreasing tap count (the round-robin deal then gives every workgroup a similar mix), class extents'
+// division magics.  Classes without taps are kept: their pixels still have to be written (zeros / addend).
+static int build_classes_pk(ConvArgs& a, int BM, int ntn) {
+  const int S[3] = {a.st, a.sh, a.sw}, P[3] = {a.pt, a.ph, a.pw}, Kd[3] = {a.kt, a.kh, a.kw}, D[3] = {a.Td, a.Hd, a.Wd};
+  struct Cls { int p0[3], n[3], d0[3], nd[3]; long long pixels; int taps; };
+  Cls cl[8];
+  int nc = 0;
+  for (int ct = 0; ct < S[0]; ++ct)
+    for (int ch = 0; ch < S[1]; ++ch)
+      for (int cw = 0; cw < S[2]; ++cw) {
+        const int c[3] = {ct, ch, cw};
+        Cls k;
+        k.pixels = a.B;
+        k.taps = 1;
+        for (int x = 0; x < 3; ++x) {
+          if (S[x] == 1) {
+            k.p0[x] = 0; k.n[x] = D[x]; k.d0[x] = 0; k.nd[x] = Kd[x];
+          } else {   // positions p with (p + pad) % 2 == c ; taps d with d % 2 == c
+            const int p0 = (c[x] + P[x]) & 1;
+            k.p0[x] = p0;
+            k.n[x] = p0 < D[x] ? (D[x] - p0 + 1) / 2 : 0;
+            k.d0[x] = c[x];
+            k.nd[x] = c[x] < Kd[x] ? (Kd[x] - c[x] + 1) / 2 : 0;
+          }
+          k.pixels *= k.n[x];
+          k.taps *= k.nd[x];
+        }
+        if (k.pixels == 0) continue;
+        if (k.taps == 0) k.nd[0] = k.nd[1] = k.nd[2] = 0;
+        cl[nc++] = k;
+      }
+  for (int i = 1; i < nc; ++i)   // insertion sort, taps descending (stable)
+    for (int j = i; j > 0 && cl[j].taps > cl[j - 1].taps; --j) { Cls t = cl[j]; cl[j] = cl[j - 1]; cl[j - 1] = t; }
+  int begin = 0;
+  for (int k = 0; k < nc; ++k) {
+    for (int x = 0; x < 3; ++x) {
+      a.cls_p0[k][x] = cl[k].p0[x]; a.cls_n[k][x] = cl[k].n[x]; a.cls_d0[k][x] = cl[k].d0[x]; a.cls_nd[k][x] = cl[k].nd[x];
+      magic_for(cl[k].n[x], a.cls_mg[k][x], a.cls_shf[k][x]);
+    }
+    a.cls_begin[k] = begin;
+    begin += (int)((cl[k].pixels + BM - 1) / BM) * ntn;
+  }
+  a.ncls = nc;
+  a.cls_begin[nc] = begin;
+  return begin;
+}
+
 template <int MODE>
 static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (MODE == 1 && (a.st > 1 || a.sh > 1 || a.sw > 1) && pk_enabled() && (long long)a.M * a.Cd * 4 < (1ll << 31) &&
+      a.st <= 2 && a.sh <= 2 && a.sw <= 2) {
+    // strided dgrad on the persistent kernel: every class tile is dealt whole, heavy classes first
+    ConvArgs k = a;
+    const bool wide = a.Cd % 128 == 0;
+    const int BN = wide ? 128 : 64, ntn = a.Cd / BN;
+    const int total = build_classes_pk(k, 128, ntn);
+    const int cus = device_cus();
+    int f = strided_splits(total);
+    if (f > 1 && (ws == nullptr || ws_bytes < sizeof(float) * (size_t)f * a.M * a.Cd)) f = 1;
+    k.nsplit = 1;
+    k.part = static_cast<float*>(ws);
+    k.part_row_begin = 0;
+    k.pk_full = total * f;      // units: (tile, piece of its K range)
+    k.pk_tail_units = 0;
+    k.pk_f = f;
+    k.pk_kps = 0;
+    k.pk_rot = 0;
+    const int grid = k.pk_full < 2 * cus ? k.pk_full : 2 * cus;
+    k.pk_paired = (grid == 2 * cus && grid % 16 == 0) ? 1 : 0;
+    int rc = wide ? launch_pk<2, 2, 2, 2, 1, true>(k, grid, s) : launch_pk<4, 1, 1, 2, 1, true>(k, grid, s);
+    if (rc || f == 1) return rc;
+    const long long n4 = (long long)a.M * a.Cd / 4;
+    long long rgrid = ceil_div(n4, 256);
+    if (rgrid > 2048) rgrid = 2048;
+    ScopedTimer t(s, "splitk_reduce_kernel", 0.0, 4.0 * a.M * a.Cd * (f + 1 + (a.addend ? 1 : 0)));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, k.part, a.dst, a.addend, nullptr, n4,
+                       a.Cd / 4, f, 0);
+    return check_launch("splitk_reduce");
+  }
   if (MODE == 1 && (a.st > 1 || a.sh > 1 || a.sw > 1)) {   // strided dgrad: per-parity-class dense sub-problems
     a.nsplit = 1;
     a.ksteps_per_split = 1 << 30;
@@ -2087,7 +2285,15 @@ extern "C" size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
   const int nk = d->kt * d->kh * d->kw * (d->Cout / BK);
-  return dgrad_wt_bytes(d) + sizeof(float) * igemm_ws_floats(M, d->Cin, nk);
+  size_t fl = igemm_ws_floats(M, d->Cin, nk);
+  if (d->st > 1 || d->sh > 1 || d->sw > 1) {   // strided: K pieces of the parity-class tiles (dispatch_igemm<1>)
+    const int ntn = d->Cin % 128 == 0 ? d->Cin / 128 : d->Cin / 64;
+    // upper bound of the class tile count: every class rounds up separately (<= 8 classes)
+    const long long tiles_lo = (M + 127) / 128 * ntn;
+    const size_t f = (size_t)strided_splits((int)(tiles_lo < (1 << 30) ? tiles_lo : (1 << 30)));
+    if (f > 1 && f * (size_t)M * d->Cin > fl) fl = f * (size_t)M * d->Cin;
+  }
+  return dgrad_wt_bytes(d) + sizeof(float) * fl;
 }
 
 extern "C" int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_dev, int64_t max_elems,
