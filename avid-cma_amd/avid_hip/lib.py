@@ -59,7 +59,8 @@ SIGNATURES = {
     "avid_timing_enable": (_i, [_i]),
     "avid_timing_report": (_i, [C.c_char_p, _sz]),
     "avid_conv_fwd_workspace_bytes": (_sz, [_dp]),
-    "avid_conv_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "avid_conv_fwd_stats_rows": (_i, [_dp]),
+    "avid_conv_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "avid_conv_dgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_weight_transpose_batched": (_i, [_i, _vp, _i64, _vp]),
@@ -67,7 +68,7 @@ SIGNATURES = {
     "avid_conv_wgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_conv_kernel_name": (_i, [_dp, _i, C.c_char_p, _i]),
     "avid_bn_workspace_bytes": (_sz, [_i64, _i]),
-    "avid_bn_fwd_train": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avid_bn_fwd_train": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "avid_bn_fwd_eval": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
     "avid_bn_bwd": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_maxpool_hw3s2_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -78,14 +78,15 @@ _BN_WS_CACHE = {}
 
 
 def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
-    """(ConvDesc, fwd_ws_bytes, dgrad_ws_bytes, wgrad_ws_bytes) — built once per distinct layer geometry."""
+    """(ConvDesc, fwd_ws_bytes, dgrad_ws_bytes, wgrad_ws_bytes, bn_partial_rows) — once per distinct layer geometry."""
     key = (xs, cin, cout, k, stride, pad, channel_first)
     hit = _DESC_CACHE.get(key)
     if hit is None:
         d = _desc(xs, cin, cout, k, stride, pad, channel_first)
         hit = (d, lib.raw("avid_conv_fwd_workspace_bytes")(C.byref(d)),
                0 if channel_first else lib.raw("avid_conv_dgrad_workspace_bytes")(C.byref(d)),
-               lib.raw("avid_conv_wgrad_workspace_bytes")(C.byref(d)))
+               lib.raw("avid_conv_wgrad_workspace_bytes")(C.byref(d)),
+               lib.raw("avid_conv_fwd_stats_rows")(C.byref(d)))
         _DESC_CACHE[key] = hit
     return hit
 
@@ -235,7 +236,7 @@ class _ConvCL(Function):
     """y = conv(x, w) [+ addend] [+ bias] [relu]  — avid_conv_fwd / avid_conv_dgrad / avid_conv_wgrad."""
 
     @staticmethod
-    def forward(ctx, x, w, addend, bias, stride, pad, relu, channel_first):
+    def forward(ctx, x, w, addend, bias, stride, pad, relu, channel_first, want_stats=False):
         _need_cuda(x, w, addend, bias)
         if not x.is_contiguous():
             raise AvidHipError("conv: x must be contiguous (channels-last [B,T,H,W,C])")
@@ -252,21 +253,30 @@ class _ConvCL(Function):
             B, Ti, Hi, Wi, c = x.shape
         if c != cin:
             raise AvidHipError(f"conv: input has {c} channels, weight expects {cin}")
-        d, nb, ctx.nb_dgrad, ctx.nb_wgrad = _desc_cached((B, Ti, Hi, Wi), cin, cout, k, stride, pad, channel_first)
+        d, nb, ctx.nb_dgrad, ctx.nb_wgrad, srows = _desc_cached((B, Ti, Hi, Wi), cin, cout, k, stride, pad, channel_first)
         y = torch.empty((B, d.To, d.Ho, d.Wo, cout), dtype=torch.float32, device=x.device)
         if addend is not None and (addend.shape != y.shape or not addend.is_contiguous()):
             raise AvidHipError("conv: addend must be a contiguous tensor of the output shape")
         ws = workspace(x.device, nb) if nb else None
-        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(addend), _p(bias), int(relu), _p(y), _p(ws),
+        # BatchNorm partial sums of y from the conv epilogue ([rows][2][Cout]; None: this layer cannot)
+        stats = None
+        if want_stats and srows > 0 and bias is None and not relu:
+            stats = torch.empty((srows, 2, cout), dtype=torch.float32, device=x.device)
+        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(addend), _p(bias), int(relu), _p(y), _p(stats), _p(ws),
                  ws.numel() if ws is not None else 0, _stream())
         ctx.d, ctx.relu, ctx.channel_first = d, relu, channel_first
         ctx.has_addend, ctx.has_bias = addend is not None, bias is not None
         ctx.bias_ptr = bias.data_ptr() if bias is not None else 0
         ctx.save_for_backward(x, w, y if relu else None)
+        if want_stats:
+            if stats is None:
+                stats = torch.empty(0, dtype=torch.float32, device=x.device)
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
         x, w, y = ctx.saved_tensors
         d = ctx.d
         dy = dy.contiguous()
@@ -319,10 +329,15 @@ class _ConvCL(Function):
             if slot is not None:
                 _grad_done(slot)
                 dbias = None
-        return dx, dw, dadd, dbias, None, None, None, None
+        return dx, dw, dadd, dbias, None, None, None, None, None
 
 
-def conv_cl(x, w, stride=(1, 1, 1), pad=(0, 0, 0), addend=None, bias=None, relu=False, channel_first=False):
+def conv_cl(x, w, stride=(1, 1, 1), pad=(0, 0, 0), addend=None, bias=None, relu=False, channel_first=False,
+            bn_stats=False):
+    """``bn_stats=True`` returns ``(y, partials)``: ``partials`` are y's BatchNorm partial sums from the conv
+    epilogue (pass them to ``batch_norm_cl``), or an empty tensor when the layer cannot produce them."""
+    if bn_stats:
+        return _ConvCL.apply(x, w, addend, bias, tuple(stride), tuple(pad), bool(relu), bool(channel_first), True)
     return _ConvCL.apply(x, w, addend, bias, tuple(stride), tuple(pad), bool(relu), bool(channel_first))
 
 
@@ -338,7 +353,7 @@ def linear(x, w, bias=None, relu=False):
 # ------------------------------------------------------------------------------------------------
 class _BatchNormCL(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, stats, training, momentum, eps, relu, counter=None):
+    def forward(ctx, x, gamma, beta, stats, training, momentum, eps, relu, counter=None, partials=None):
         _need_cuda(x, gamma, beta)
         if not x.is_contiguous():
             raise AvidHipError("bn: x must be contiguous channels-last")
@@ -352,7 +367,7 @@ class _BatchNormCL(Function):
             ws = workspace(x.device, _bn_ws_bytes(M, Cc))
             lib.call("avid_bn_fwd_train", M, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv), float(momentum),
                      float(eps), int(relu), _p(y), _p(stats4[0]), _p(stats4[1]), _p(stats4[2]), _p(stats4[3]),
-                     _p(counter), _p(ws), ws.numel(), st)
+                     _p(counter), _p(partials), 0 if partials is None else partials.shape[0], _p(ws), ws.numel(), st)
             ctx.save_for_backward(x, gamma, stats4)
             ctx.beta_ptr = beta.data_ptr()
         else:
@@ -380,14 +395,17 @@ class _BatchNormCL(Function):
         if sb is not None:
             _grad_done(sb)
             dbeta = None
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def batch_norm_cl(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False,
-                  num_batches_tracked=None):
-    """``num_batches_tracked`` (0-d int64 device tensor or None) is bumped by the kernel in training mode."""
+                  num_batches_tracked=None, partials=None):
+    """``num_batches_tracked`` (0-d int64 device tensor or None) is bumped by the kernel in training mode;
+    ``partials``: x's partial sums from ``conv_cl(..., bn_stats=True)`` (skips the statistics pass)."""
+    if partials is not None and (partials.numel() == 0 or not training):
+        partials = None
     return _BatchNormCL.apply(x, gamma, beta, (running_mean, running_var), bool(training), momentum, eps, bool(relu),
-                              num_batches_tracked)
+                              num_batches_tracked, partials)
 
 
 # ------------------------------------------------------------------------------------------------

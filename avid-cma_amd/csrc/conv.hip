@@ -65,6 +65,7 @@ struct ConvArgs {
   int pk_full, pk_tail_units, pk_f, pk_kps;
   unsigned cls_mg[8][3];   // igemm_pk_kernel<STRIDED>: multiply-shift division by a class's (T,H,W) extents
   int cls_shf[8][3];
+  float* stats;    // BatchNorm partial sums [rows][2][Cd] of the output (igemm_pk_kernel forward), or null
   int pk_rot;      // tail unit u runs on workgroup (u + pk_rot) mod G: the ones that got one full tile less
   int pk_paired;   // grid = 2 workgroups per CU: number them so that v and v + G/2 share a CU
 };
@@ -400,7 +401,41 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   int tslot = slot - p.pk_rot;
   tslot += tslot < 0 ? G : 0;
   const int nseg = n_full + (tslot < p.pk_tail_units ? 1 : 0);
-  if (nseg == 0) return;
+  float cs[TN], cq[TN];   // running column sum / sum of squares of this wave's outputs (p.stats)
+#pragma unroll
+  for (int jj = 0; jj < TN; ++jj) cs[jj] = cq[jj] = 0.f;
+  // BatchNorm statistics fused into the epilogue: every workgroup owns one partial row [2][Cd] (its tiles
+  // all share one column block — the planner keeps full, rot and the grid multiples of Cd/BN); columns it
+  // does not cover, and the rows of workgroups without direct tiles, are written as zeros.
+  auto write_stats = [&]() {
+    if (!p.stats) return;
+    float* red = smem;                                   // [2][WM][BN] (the stages are dead by now)
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) {
+      const float a = cs[jj] + __shfl_xor(cs[jj], 32, 64), b = cq[jj] + __shfl_xor(cq[jj], 32, 64);
+      if (h == 0) {
+        red[wm * BN + (wn * TN + jj) * 32 + l31] = a;
+        red[WM * BN + wm * BN + (wn * TN + jj) * 32 + l31] = b;
+      }
+    }
+    __syncthreads();
+    const int nb = slot % ntn;                           // this workgroup's column block
+    float* row = p.stats + (long long)slot * 2 * p.Cd;
+    for (int c = tid; c < p.Cd; c += NT) {
+      float a = 0.f, b = 0.f;
+      if (c / BN == nb) {
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { a += red[w * BN + c % BN]; b += red[WM * BN + w * BN + c % BN]; }
+      }
+      row[c] = a;
+      row[p.Cd + c] = b;
+    }
+  };
+  if (nseg == 0) {
+    write_stats();
+    return;
+  }
   // Strided dgrad (STRIDED): the tile list is the concatenation of the stride-parity classes' tile lists
   // (cls_begin, in tiles); a class is a dense unit-stride problem over its own pixel grid and tap subset,
   // so its K extent differs (and may be empty: those tiles only write zeros / the addend).
@@ -787,12 +822,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
               v = p.epi_op == 0 ? v + ad : (p.epi_op == 1 ? fminf(v, ad) : fmaxf(v, ad));
             }
             if (p.relu) v = fmaxf(v, 0.f);
+            if (p.stats) { cs[jj] += v; cq[jj] = fmaf(v, v, cq[jj]); }   // rows past M are exact zeros
           }
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff, soff, 0);
         }
       }
     }
   }
+  write_stats();
 }
 
 // dst = sum_s part[s] (+ bias)(+ addend)(relu) — fixed summation order
@@ -810,6 +847,44 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
     }
     reinterpret_cast<floatx4*>(dst)[i] = s;
+  }
+}
+
+// splitk_reduce_kernel for a forward whose output feeds a BatchNorm: dst = sum_s part[s] (+ addend), and the
+// column sums / sums of squares of the rows this block wrote go to one partial row [2][C] (fixed order).
+// Block = 256 threads = (256 / G) rows x G float4 column groups, `rows_per_block` rows per block.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ part, float* __restrict__ dst,
+                                                                  const float* __restrict__ addend, long long rows, int C,
+                                                                  int nsplit, int rows_per_block,
+                                                                  float* __restrict__ stats) {
+  __shared__ floatx4 sh[2][256];
+  const int G = C >> 2, tid = threadIdx.x;
+  const int g = tid % G, r = tid / G, rpp = 256 / G;
+  const long long n4 = rows * G;
+  const long long row0 = (long long)blockIdx.x * rows_per_block;
+  floatx4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  for (int k = r; k < rows_per_block; k += rpp) {
+    const long long row = row0 + k;
+    if (row >= rows) break;
+    const long long i = row * G + g;
+    floatx4 v = reinterpret_cast<const floatx4*>(part)[i];
+    for (int j = 1; j < nsplit; ++j) v += reinterpret_cast<const floatx4*>(part)[(long long)j * n4 + i];
+    if (addend) v += reinterpret_cast<const floatx4*>(addend)[i];
+    reinterpret_cast<floatx4*>(dst)[i] = v;
+    s += v;
+    q += v * v;
+  }
+  sh[0][tid] = s;
+  sh[1][tid] = q;
+  __syncthreads();
+  if (r == 0) {
+    for (int k = 1; k < rpp; ++k) {
+      s += sh[0][k * G + g];
+      q += sh[1][k * G + g];
+    }
+    float* o = stats + (long long)blockIdx.x * 2 * C;
+    *reinterpret_cast<floatx4*>(o + g * 4) = s;
+    *reinterpret_cast<floatx4*>(o + C + g * 4) = q;
   }
 }
 
@@ -1817,6 +1892,16 @@ static int launch_igemm(const ConvArgs& a, hipStream_t s) {
   return check_launch("igemm");
 }
 
+// rows per block of splitk_reduce_stats_kernel (one BatchNorm partial row each): ~1000 blocks, whole passes
+static int stats_rpb(long long rows, int C) {
+  const int rpp = 256 / (C / 4);
+  long long r = rows / 1024;
+  r = (r + rpp - 1) / rpp * rpp;
+  if (r < rpp) r = rpp;
+  if (r > 256) r = 256;
+  return (int)r;
+}
+
 // ---- persistent K-pipelined kernel: whole rounds of tiles + a K-split tail, one launch
 struct PkPlan {
   int tile;          // 0: 128x128, 1: 128x64 (4 waves, 2 workgroups / CU); 2: 256x128, 3: 256x64 (8 waves, 1 / CU)
@@ -2085,6 +2170,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
   if (pk_enabled()) {
     PkPlan pk = plan_pk(a.M, a.Cd, nk_total);
     if (pk.f > 1 && (ws == nullptr || ws_bytes < sizeof(float) * pk.ws_floats)) {   // no scratch: unsplit
+      AVID_REQUIRE(!a.stats, AVID_E_BADARG, "conv_fwd: BatchNorm partials need the planned workspace");
       pk.tail_units /= pk.f;
       pk.f = 1;
       pk.kps = nk_total;
@@ -2100,6 +2186,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     k.pk_kps = pk.kps;
     k.pk_rot = pk.rot;
     k.pk_paired = pk.paired ? 1 : 0;
+    k.stats = MODE == 0 ? a.stats : nullptr;
     k.part = static_cast<float*>(ws);
     k.part_row_begin = (int)pk.tail_row0;
     magic_for(k.Wd, k.mgW, k.shW);
@@ -2114,6 +2201,14 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     }
     if (rc || pk.f == 1) return rc;
     const long long rows = a.M - pk.tail_row0, n4 = rows * a.Cd / 4, off = pk.tail_row0 * a.Cd;
+    if (MODE == 0 && a.stats) {   // the tail rows' BatchNorm partials come out of the reduce
+      ScopedTimer t(s, "splitk_reduce_stats_kernel", 0.0, 4.0 * rows * a.Cd * (pk.f + 1 + (a.addend ? 1 : 0)));
+      const int rpb = stats_rpb(rows, a.Cd);
+      hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((unsigned)ceil_div(rows, rpb)), dim3(256), 0, s, k.part,
+                         a.dst + off, a.addend ? a.addend + off : nullptr, rows, a.Cd, pk.f, rpb,
+                         a.stats + (long long)pk.grid * 2 * a.Cd);
+      return check_launch("splitk_reduce_stats");
+    }
     long long grid = ceil_div(n4, 256);
     if (grid > 2048) grid = 2048;
     ScopedTimer t(s, "splitk_reduce_kernel", 0.0, 4.0 * rows * a.Cd * (pk.f + 1 + (a.addend ? 1 : 0)));
@@ -2218,6 +2313,7 @@ static void fill_common(ConvArgs& a, const avid_conv_desc* d) {
   a.epi_op = 0;
   a.ncls = 1;
   a.mgW = a.mgH = a.mgT = 0; a.shW = a.shH = a.shT = 0;
+  a.stats = nullptr;
   a.cls_ptiles_total = 0;
   a.mt2_begin = 0;
   a.mt2_count = 0;
@@ -2256,8 +2352,17 @@ extern "C" size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d) {
   return sizeof(float) * igemm_ws_floats(M, d->Cout, nk);
 }
 
+extern "C" int avid_conv_fwd_stats_rows(const avid_conv_desc* d) {
+  if (!d || validate(d)) return 0;
+  const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
+  if (!vec || !pk_enabled() || d->Cout > 1024 || (256 % (d->Cout / 4)) != 0) return 0;
+  const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
+  const PkPlan pk = plan_pk(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK));
+  return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cout)) : 0);
+}
+
 extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* addend,
-                             const float* bias, int relu, float* y, void* ws, size_t ws_bytes,
+                             const float* bias, int relu, float* y, float* bn_partials, void* ws, size_t ws_bytes,
                              avid_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
@@ -2274,6 +2379,11 @@ extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const floa
   a.relu = relu;
   fill_src_strides(d, a.ssB, a.ssT, a.ssH, a.ssW, a.ssC);
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
+  if (bn_partials) {
+    AVID_REQUIRE(!bias && !relu && avid_conv_fwd_stats_rows(d) > 0, AVID_E_UNSUPPORTED,
+                 "conv_fwd: BatchNorm partials need the persistent kernel, no bias and no ReLU");
+    a.stats = bn_partials;
+  }
   return vec ? dispatch_igemm<0>(a, ws, ws_bytes, (hipStream_t)stream) : launch_gather(a, (hipStream_t)stream);
 }
 

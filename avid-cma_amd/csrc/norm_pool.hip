@@ -475,8 +475,8 @@ static int bn_check(int64_t M, int C, const char* who) {
 extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, int relu,
                                  float* y, float* save_mean, float* save_invstd, float* save_scale,
-                                 float* save_shift, int64_t* num_batches_tracked, void* ws, size_t ws_bytes,
-                                 avid_stream_t stream) {
+                                 float* save_shift, int64_t* num_batches_tracked, const float* partials, int nparts,
+                                 void* ws, size_t ws_bytes, avid_stream_t stream) {
   int rc = bn_check(M, C, "bn_fwd_train");
   if (rc) return rc;
   AVID_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && save_scale && save_shift && ws, AVID_E_BADARG,
@@ -487,12 +487,16 @@ extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* 
   float* part = static_cast<float*>(ws);
   float* scale = save_scale;
   float* shift = save_shift;
-  {
+  int nblk = p.nblk;
+  if (partials && nparts > 0) {   // statistics already reduced to partial rows by the producing convolution
+    part = const_cast<float*>(partials);
+    nblk = nparts;
+  } else {
     ScopedTimer t(s, "bn_stats_partial_kernel", 0.0, 4.0 * M * C);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
                        p.rows_per_pass, p.rows_per_block);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SLICES), 0, s, part, p.nblk, (long long)M,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SLICES), 0, s, part, nblk, (long long)M,
                      C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift,
                      reinterpret_cast<long long*>(num_batches_tracked));
   const long long n4 = (long long)M * p.G;

@@ -5,6 +5,7 @@ activations are channels-last ``[B,T,H,W,C]`` and every op is a hand-written HIP
 (avid_hip.ops).  Conv+residual-add and BN+ReLU are fused.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -34,9 +35,10 @@ class ConvCL(nn.Module):
         self.weight = nn.Parameter(ops.make_weight(out_planes, in_planes, *self.kernel_size))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
 
-    def forward(self, x, addend=None):
+    def forward(self, x, addend=None, bn_stats=False):
+        """``bn_stats=True``: also return the BatchNorm partial sums of the output (for the BN that follows)."""
         return ops.conv_cl(x, self.weight, self.stride3, self.padding3, addend=addend,
-                           channel_first=self.channel_first)
+                           channel_first=self.channel_first, bn_stats=bn_stats)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
@@ -58,13 +60,26 @@ class BatchNormCL(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, partials=None):
         return ops.batch_norm_cl(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
                                  self.momentum, self.eps, relu,
-                                 self.num_batches_tracked if self.training else None)   # bumped inside the kernel
+                                 self.num_batches_tracked if self.training else None,   # bumped inside the kernel
+                                 partials)
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"
+
+
+_FUSE_BN_STATS = os.environ.get("AVID_FUSE_BN_STATS", "1") == "1"
+
+
+def _conv_bn(conv, bn, x, addend=None):
+    """ReLU(bn(conv(x) [+ addend])).  In training the conv epilogue hands the BatchNorm its batch statistics
+    as partial sums, so the BN does not re-read the activation for them."""
+    if bn.training and x.is_cuda and _FUSE_BN_STATS:
+        y, partials = conv(x, addend=addend, bn_stats=True)
+        return bn(y, relu=True, partials=partials)
+    return bn(conv(x, addend=addend), relu=True)
 
 
 class Basic2DBlock(nn.Module):
@@ -81,8 +96,8 @@ class Basic2DBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)      # kept for module-tree parity; fused into the BN kernels
 
     def forward(self, x):
-        x = self.bn1(self.conv1(x), relu=True)
-        x = self.bn2(self.conv2(x), relu=True)
+        x = _conv_bn(self.conv1, self.bn1, x)
+        x = _conv_bn(self.conv2, self.bn2, x)
         return x
 
 
@@ -113,12 +128,11 @@ class BasicR2P1DBlock(nn.Module):
             self.res = False
 
     def forward(self, x):
-        h = self.spt_bn1(self.spt_conv1(x), relu=True)
-        h = self.tmp_bn1(self.tmp_conv1(h), relu=True)
-        h = self.spt_bn2(self.spt_conv2(h), relu=True)
+        h = _conv_bn(self.spt_conv1, self.spt_bn1, x)
+        h = _conv_bn(self.tmp_conv1, self.tmp_bn1, h)
+        h = _conv_bn(self.spt_conv2, self.spt_bn2, h)
         x_res = self.res_conv(x) if self.res else x
-        s = self.tmp_conv2(h, addend=x_res)
-        return self.out_bn(s, relu=True)
+        return _conv_bn(self.tmp_conv2, self.out_bn, h, addend=x_res)
 
 
 class MaxPoolHW3S2(nn.Module):

@@ -68,8 +68,12 @@ typedef struct avid_conv_desc {
  * models/network_blocks.py:59 fused into tmp_conv2/res_conv); bias: [Cout] or NULL.
  * ws: scratch for the split-K partial slabs of small-M layers (may be NULL: single pass, slower). */
 size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d);
+/* bn_partials (or NULL): BatchNorm partial sums of the output y, [rows][2][Cout] with rows =
+ * avid_conv_fwd_stats_rows(d) (0 = this layer cannot produce them), written by the conv epilogue so that
+ * avid_bn_fwd_train can skip its statistics pass over y.  Needs bias == NULL and relu == 0. */
+int avid_conv_fwd_stats_rows(const avid_conv_desc* d);
 int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* addend,
-                  const float* bias, int relu, float* y, void* ws, size_t ws_bytes,
+                  const float* bias, int relu, float* y, float* bn_partials, void* ws, size_t ws_bytes,
                   avid_stream_t stream);
 
 /* dx = conv_transpose(dy, w) [+ addend].  ws: scratch for the transposed weights (+ split-K slabs).
@@ -108,12 +112,13 @@ size_t avid_bn_workspace_bytes(int64_t M, int C);
 /* Train: batch mean / biased var -> save_mean, save_invstd [C]; running stats updated in place
  * (momentum, unbiased var); y = [relu](fma(x, scale, shift)) with scale = gamma * invstd,
  * shift = beta - mean * scale, both also saved ([C]) so backward can recompute the ReLU mask bit-exactly.
- * num_batches_tracked: device int64 counter bumped by one (nn.BatchNorm's buffer), or NULL. */
+ * num_batches_tracked: device int64 counter bumped by one (nn.BatchNorm's buffer), or NULL.
+ * partials / nparts: [nparts][2][C] partial sums of x from avid_conv_fwd (skips the statistics pass), or NULL / 0. */
 int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps, int relu,
                       float* y, float* save_mean, float* save_invstd, float* save_scale,
-                      float* save_shift, int64_t* num_batches_tracked, void* ws, size_t ws_bytes,
-                      avid_stream_t stream);
+                      float* save_shift, int64_t* num_batches_tracked, const float* partials, int nparts,
+                      void* ws, size_t ws_bytes, avid_stream_t stream);
 /* Eval: uses running stats. */
 int avid_bn_fwd_eval(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                      const float* running_mean, const float* running_var, float eps, int relu,
