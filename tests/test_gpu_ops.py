@@ -75,6 +75,30 @@ def test_conv_fwd_dgrad_wgrad(case, gpu_device):
     assert wd.grad.stride() == wd.stride()
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 9, 11), (4, 8, 48, 48), (5, 7, 45, 47), (64, 1, 4, 4)])
+@pytest.mark.parametrize("cout", [64, 128])
+def test_conv_bn_partials(shape, cout, gpu_device):
+    """BatchNorm partial sums written by the conv epilogue / the split-K reduce: their column totals must be
+    the column sums and sums of squares of the conv output (fp32 partials, 1e-5 of the scale), for whole
+    tiles, ragged tails and K-split layers alike; with a fused residual add the statistics are of the sum."""
+    from avid_hip import ops
+    B, Ti, Hi, Wi = shape
+    x = T(detgen.det_normalish(f"cbp:{shape}:x", (B, Ti, Hi, Wi, 64))).to(gpu_device)
+    w = ops.make_weight(cout, 64, 1, 3, 3)
+    w.copy_(T(detgen.det_param(f"cbp:{cout}:w.weight", (cout, 64, 1, 3, 3))))
+    w = w.to(gpu_device)
+    add = T(detgen.det_uniform(f"cbp:{shape}:{cout}:add", (B, Ti, Hi, Wi, cout))).to(gpu_device)
+    for addend in (None, add):
+        y, part = ops.conv_cl(x, w, (1, 1, 1), (0, 1, 1), addend=addend, bn_stats=True)
+        y_plain = ops.conv_cl(x, w, (1, 1, 1), (0, 1, 1), addend=addend)
+        assert torch.equal(y, y_plain)                         # the statistics do not perturb the output
+        assert part.dim() == 3 and part.shape[1:] == (2, cout)
+        yd = y.double().reshape(-1, cout)
+        s, q = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+        assert relerr(s, yd.sum(0)) < 1e-5 * max(1.0, float(yd.abs().sum(0).max() / (yd.sum(0).abs().max() + 1e-30)))
+        assert relerr(q, (yd * yd).sum(0)) < 1e-5
+
+
 def test_conv_transpose_detecting(gpu_device):
     """A = identity-like with ASYMMETRIC weights: catches a row<->col swap in the MFMA C-write."""
     from avid_hip import ops
