@@ -408,6 +408,54 @@ def batch_norm_cl(x, gamma, beta, running_mean, running_var, training, momentum=
                               num_batches_tracked, partials)
 
 
+class _BnReluMaxPool(Function):
+    """maxpool_hw3s2(relu(bn_train(x))) in one pass over x (the video stem's tail, models/video.py:21-23)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, stats, momentum, eps, counter):
+        _need_cuda(x, gamma, beta)
+        if not x.is_contiguous():
+            raise AvidHipError("bn_relu_maxpool: x must be contiguous channels-last")
+        B, T, H, W, Cc = x.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        rm, rv = stats
+        y = torch.empty((B, T, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+        am = torch.empty((B, T, Ho, Wo, Cc), dtype=torch.uint8, device=x.device)
+        stats4 = torch.empty((4, Cc), dtype=torch.float32, device=x.device)   # mean, invstd, scale, shift
+        ws = workspace(x.device, _bn_ws_bytes(B * T * H * W, Cc))
+        lib.call("avid_bn_relu_maxpool_fwd", B, T, H, W, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv),
+                 float(momentum), float(eps), _p(y), _p(am), _p(stats4[0]), _p(stats4[1]), _p(stats4[2]), _p(stats4[3]),
+                 _p(counter), _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(x, gamma, stats4, am)
+        ctx.beta_ptr = beta.data_ptr()
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stats4, am = ctx.saved_tensors
+        B, T, H, W, Cc = x.shape
+        dx = torch.empty_like(x)
+        dgamma, sg = _grad_dst(gamma.data_ptr(), shape=(Cc,), device=x.device)
+        dbeta, sb = _grad_dst(ctx.beta_ptr, shape=(Cc,), device=x.device)
+        ws = workspace(x.device, _bn_ws_bytes(B * T * H * W, Cc))
+        lib.call("avid_bn_relu_maxpool_bwd", B, T, H, W, Cc, _p(x), _p(dy.contiguous()), _p(am), _p(gamma),
+                 _p(stats4[0]), _p(stats4[1]), _p(stats4[2]), _p(stats4[3]), _p(dx), _p(dgamma), _p(dbeta), _p(ws),
+                 ws.numel(), _stream())
+        if sg is not None:
+            _grad_done(sg)
+            dgamma = None
+        if sb is not None:
+            _grad_done(sb)
+            dbeta = None
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def bn_relu_maxpool(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, num_batches_tracked=None):
+    """Training-mode BatchNorm + ReLU + MaxPool (1,3,3)/(1,2,2)/(0,1,1) fused (the normalised activation is
+    never written; backward rebuilds the un-pooled gradient from the argmax slots)."""
+    return _BnReluMaxPool.apply(x, gamma, beta, (running_mean, running_var), momentum, eps, num_batches_tracked)
+
+
 # ------------------------------------------------------------------------------------------------
 # pooling
 # ------------------------------------------------------------------------------------------------

@@ -395,6 +395,199 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stem tail fused: BatchNorm(train) + ReLU + MaxPool(1,3,3)/(1,2,2)/(0,1,1)  (models/video.py:21-23).
+// The 411 MB normalised activation is never written: the pooled output is produced straight from the conv
+// output, and the backward kernels rebuild the un-pooled gradient from the pooled one + the argmax slots.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float* __restrict__ y,
+                                                          uint8_t* __restrict__ am, int BT, int H, int W, int Ho, int Wo,
+                                                          int G) {
+  const long long n = (long long)BT * Ho * Wo * G;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int g = (int)(i % G);
+    long long r = i / G;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const long long bt = r / Ho;
+    const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g];
+    const floatx4 sh = reinterpret_cast<const floatx4*>(shift)[g];
+    floatx4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int slot[4] = {0, 0, 0, 0};
+    bool first = true;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = ho * 2 - 1 + dh;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = wo * 2 - 1 + dw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const floatx4 xv = *reinterpret_cast<const floatx4*>(x + (((bt * H + h) * W + w) * (long long)G + g) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = fmaxf(fmaf(xv[j], sc[j], sh[j]), 0.f);   // the same fma the backward recomputes
+          if (first || v > best[j] || v != v) {
+            best[j] = v;
+            slot[j] = dh * 3 + dw;
+          }
+        }
+        first = false;
+      }
+    }
+    reinterpret_cast<floatx4*>(y)[i] = best;
+    reinterpret_cast<uchar4*>(am)[i] = make_uchar4((unsigned char)slot[0], (unsigned char)slot[1],
+                                                   (unsigned char)slot[2], (unsigned char)slot[3]);
+  }
+}
+
+// A thread owns a 2x2 cell of un-pooled positions (h = 2a, 2a+1; w = 2b, 2b+1) of one channel group: the four
+// pooling windows (a|a+1, b|b+1) that can have selected them are loaded once (argmax slots + pooled gradient)
+// and serve all four positions — 3 loads per position instead of 5.5, four positions in flight per thread.
+struct PoolCell {
+  floatx4 d[2][2];   // gradient reaching position (dh2, dw2) of the cell (before the ReLU mask)
+};
+__device__ __forceinline__ PoolCell pool_cell_grad(const float* __restrict__ dy, const uint8_t* __restrict__ am,
+                                                   long long bt, int a, int b, int g, int Ho, int Wo, int G) {
+  uchar4 A[2][2];
+  floatx4 D[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = a + i < Ho && b + j < Wo;
+      const long long o = ((bt * Ho + (ok ? a + i : 0)) * Wo + (ok ? b + j : 0)) * (long long)G + g;
+      A[i][j] = reinterpret_cast<const uchar4*>(am)[o];
+      D[i][j] = reinterpret_cast<const floatx4*>(dy)[o];
+      if (!ok) A[i][j] = make_uchar4(255, 255, 255, 255);
+    }
+  PoolCell c;
+  auto pick = [](uchar4 s, int slot, floatx4 d) {
+    floatx4 r;
+    r.x = s.x == slot ? d.x : 0.f; r.y = s.y == slot ? d.y : 0.f;
+    r.z = s.z == slot ? d.z : 0.f; r.w = s.w == slot ? d.w : 0.f;
+    return r;
+  };
+  // position (2a + dh2, 2b + dw2) sits in window (a + i, b + j) at slot ((dh2 + 1 - 2i), (dw2 + 1 - 2j)):
+  // even coordinate -> only i (j) = 0, slot row (col) 1; odd -> i = 0 slot 2 and i = 1 slot 0
+  c.d[0][0] = pick(A[0][0], 1 * 3 + 1, D[0][0]);
+  c.d[0][1] = pick(A[0][0], 1 * 3 + 2, D[0][0]) + pick(A[0][1], 1 * 3 + 0, D[0][1]);
+  c.d[1][0] = pick(A[0][0], 2 * 3 + 1, D[0][0]) + pick(A[1][0], 0 * 3 + 1, D[1][0]);
+  c.d[1][1] = pick(A[0][0], 2 * 3 + 2, D[0][0]) + pick(A[0][1], 2 * 3 + 0, D[0][1]) + pick(A[1][0], 0 * 3 + 2, D[1][0]) +
+              pick(A[1][1], 0 * 3 + 0, D[1][1]);
+  return c;
+}
+
+// bn_bwd_partial_kernel with dy rebuilt from (pooled dy, argmax); ReLU mask from x.  Rows of the block = cells.
+__global__ __launch_bounds__(256) void bn_pool_bwd_partial_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ dyp, const uint8_t* __restrict__ am, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* __restrict__ part, long long cells, int C, int G, int cells_per_pass,
+    int cells_per_block, int H, int W, int Ho, int Wo) {
+  __shared__ floatx4 shm[2][256];
+  const int tid = threadIdx.x;
+  const int g = tid % G, r = tid / G;
+  const int Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;
+  floatx4 s = {0, 0, 0, 0}, sx = {0, 0, 0, 0};
+  const long long cell0 = (long long)blockIdx.x * cells_per_block;
+  if (r < cells_per_pass) {
+    const floatx4 mu = reinterpret_cast<const floatx4*>(mean)[g];
+    const floatx4 is = reinterpret_cast<const floatx4*>(invstd)[g];
+    const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g];
+    const floatx4 sh = reinterpret_cast<const floatx4*>(shift)[g];
+    for (int k = r; k < cells_per_block; k += cells_per_pass) {
+      const long long cell = cell0 + k;
+      if (cell >= cells) break;
+      const int b = (int)(cell % Wc);
+      const long long q = cell / Wc;
+      const int a = (int)(q % Hc);
+      const long long bt = q / Hc;
+      const PoolCell pc = pool_cell_grad(dyp, am, bt, a, b, g, Ho, Wo, G);
+      floatx4 xv[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool ok = 2 * a + i < H && 2 * b + j < W;
+          xv[i][j] = *reinterpret_cast<const floatx4*>(
+              x + (((bt * H + (ok ? 2 * a + i : 0)) * W + (ok ? 2 * b + j : 0)) * (long long)G + g) * 4);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (2 * a + i >= H || 2 * b + j >= W) continue;
+          floatx4 d = pc.d[i][j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[e] = fmaf(xv[i][j][e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
+          s += d;
+          sx += d * ((xv[i][j] - mu) * is);
+        }
+    }
+  }
+  shm[0][tid] = s;
+  shm[1][tid] = sx;
+  __syncthreads();
+  if (r == 0) {
+    for (int k = 1; k < cells_per_pass; ++k) {
+      s += shm[0][k * G + g];
+      sx += shm[1][k * G + g];
+    }
+    float* o = part + (long long)blockIdx.x * 2 * C;
+    *reinterpret_cast<floatx4*>(o + g * 4) = s;
+    *reinterpret_cast<floatx4*>(o + C + g * 4) = sx;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ dyp, const uint8_t* __restrict__ am, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
+    const float* __restrict__ k2, float* __restrict__ dx, long long ncell4, int G, int H, int W, int Ho, int Wo) {
+  const int Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ncell4; i += stride) {
+    const int g = (int)(i % G);
+    const long long cell = i / G;
+    const int b = (int)(cell % Wc);
+    const long long q = cell / Wc;
+    const int a = (int)(q % Hc);
+    const long long bt = q / Hc;
+    const PoolCell pc = pool_cell_grad(dyp, am, bt, a, b, g, Ho, Wo, G);
+    const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g];
+    const floatx4 sh = reinterpret_cast<const floatx4*>(shift)[g];
+    const floatx4 mu = reinterpret_cast<const floatx4*>(mean)[g];
+    const floatx4 is = reinterpret_cast<const floatx4*>(invstd)[g];
+    const floatx4 ga = reinterpret_cast<const floatx4*>(gamma)[g];
+    const floatx4 ka = reinterpret_cast<const floatx4*>(k1)[g];
+    const floatx4 kb = reinterpret_cast<const floatx4*>(k2)[g];
+    floatx4 xv[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const bool ok = 2 * a + u < H && 2 * b + v < W;
+        xv[u][v] = *reinterpret_cast<const floatx4*>(
+            x + (((bt * H + (ok ? 2 * a + u : 0)) * W + (ok ? 2 * b + v : 0)) * (long long)G + g) * 4);
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        if (2 * a + u >= H || 2 * b + v >= W) continue;
+        floatx4 d = pc.d[u][v];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = fmaf(xv[u][v][e], sc[e], sh[e]) > 0.f ? d[e] : 0.f;
+        const floatx4 xh = (xv[u][v] - mu) * is;
+        *reinterpret_cast<floatx4*>(dx + (((bt * H + 2 * a + u) * W + 2 * b + v) * (long long)G + g) * 4) =
+            ga * is * (d - ka - xh * kb);
+      }
+  }
+}
+
 // global max over S positions: x [B,S,C] -> y [B,C]; first maximum wins
 __global__ void global_maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ am,
                                           int B, int S, int C) {
@@ -550,6 +743,78 @@ extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, co
                        save_invstd, k1, k2, dx, n4, p.G, relu);
   }
   return check_launch("bn_bwd");
+}
+
+extern "C" int avid_bn_relu_maxpool_fwd(int B, int T, int H, int W, int C, const float* x, const float* gamma,
+                                        const float* beta, float* running_mean, float* running_var, float momentum,
+                                        float eps, float* y, uint8_t* argmax, float* save_mean, float* save_invstd,
+                                        float* save_scale, float* save_shift, int64_t* num_batches_tracked, void* ws,
+                                        size_t ws_bytes, avid_stream_t stream) {
+  const int64_t M = (int64_t)B * T * H * W;
+  int rc = bn_check(M, C, "bn_relu_maxpool_fwd");
+  if (rc) return rc;
+  AVID_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0, AVID_E_SHAPE, "bn_relu_maxpool_fwd: bad shape");
+  AVID_REQUIRE(x && gamma && beta && y && argmax && save_mean && save_invstd && save_scale && save_shift && ws,
+               AVID_E_BADARG, "bn_relu_maxpool_fwd: null pointer");
+  AVID_REQUIRE(ws_bytes >= avid_bn_workspace_bytes(M, C), AVID_E_BADARG, "bn_relu_maxpool_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  BnPlan p = bn_plan(M, C);
+  float* part = static_cast<float*>(ws);
+  {
+    ScopedTimer t(s, "bn_stats_partial_kernel", 0.0, 4.0 * M * C);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
+                       p.rows_per_pass, p.rows_per_block);
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SLICES), 0, s, part, p.nblk,
+                     (long long)M, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                     save_scale, save_shift, reinterpret_cast<long long*>(num_batches_tracked));
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long n = (long long)B * T * Ho * Wo * p.G;
+  {
+    ScopedTimer t(s, "bn_pool_fwd_kernel", 0.0, 4.0 * B * T * C * ((double)H * W + 1.25 * Ho * Wo));
+    hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, s, x, save_scale, save_shift, y, argmax, B * T,
+                       H, W, Ho, Wo, p.G);
+  }
+  return check_launch("bn_relu_maxpool_fwd");
+}
+
+extern "C" int avid_bn_relu_maxpool_bwd(int B, int T, int H, int W, int C, const float* x, const float* dy,
+                                        const uint8_t* argmax, const float* gamma, const float* save_mean,
+                                        const float* save_invstd, const float* save_scale, const float* save_shift,
+                                        float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                        avid_stream_t stream) {
+  const int64_t M = (int64_t)B * T * H * W;
+  int rc = bn_check(M, C, "bn_relu_maxpool_bwd");
+  if (rc) return rc;
+  AVID_REQUIRE(x && dy && argmax && gamma && save_mean && save_invstd && save_scale && save_shift && dx && dgamma &&
+                   dbeta && ws,
+               AVID_E_BADARG, "bn_relu_maxpool_bwd: null pointer");
+  AVID_REQUIRE(ws_bytes >= avid_bn_workspace_bytes(M, C), AVID_E_BADARG, "bn_relu_maxpool_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  BnPlan p = bn_plan(M, C);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  float* part = static_cast<float*>(ws);
+  float* k1 = part + (size_t)p.nblk * 2 * C;
+  float* k2 = k1 + C;
+  // blocks over 2x2 cells of positions; at most p.nblk partial rows (the workspace is sized for that)
+  const long long cells = (long long)B * T * ((H + 1) / 2) * ((W + 1) / 2);
+  long long cpb = ceil_div(cells, p.nblk);
+  cpb = ceil_div(cpb, p.rows_per_pass) * p.rows_per_pass;
+  const int nblk = (int)ceil_div(cells, cpb);
+  {
+    ScopedTimer t(s, "bn_pool_bwd_partial_kernel", 0.0, 4.0 * M * C * 1.3);
+    hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3(nblk), dim3(256), 0, s, x, save_scale, save_shift, dy, argmax,
+                       save_mean, save_invstd, part, cells, C, p.G, p.rows_per_pass, (int)cpb, H, W, Ho, Wo);
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SLICES), 0, s, part, nblk,
+                     (long long)M, C, dgamma, dbeta, k1, k2);
+  const long long nc4 = cells * p.G;
+  {
+    ScopedTimer t(s, "bn_pool_bwd_apply_kernel", 0.0, 4.0 * M * C * 2.3);
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(ew_grid(nc4)), dim3(256), 0, s, x, save_scale, save_shift, dy, argmax,
+                       gamma, save_mean, save_invstd, k1, k2, dx, nc4, p.G, H, W, Ho, Wo);
+  }
+  return check_launch("bn_relu_maxpool_bwd");
 }
 
 extern "C" int avid_maxpool_hw3s2_fwd(int B, int T, int H, int W, int C, const float* x, float* y, uint8_t* argmax,

@@ -1,8 +1,11 @@
 """R(2+1)D video encoder on gfx950 kernels (reference: models/video.py:12-54)."""
+import os
 import torch.nn as nn
 
 from avid_hip import ops
 from .network_blocks import BasicR2P1DBlock, BatchNormCL, ConvCL, MaxPoolHW3S2
+
+_FUSE_STEM_TAIL = os.environ.get("AVID_FUSE_STEM_TAIL", "1") == "1"
 
 __all__ = ["R2Plus1D"]
 
@@ -43,7 +46,12 @@ class R2Plus1D(nn.Module):
 
     def forward(self, x, return_embs=False):
         conv, bn = self.conv1[0], self.conv1[1]
-        x_c1 = self.conv1[3](bn(conv(x.contiguous()), relu=True))
+        if self.training and x.is_cuda and _FUSE_STEM_TAIL:
+            # BN + ReLU + max-pool in one pass over the 411 MB stem activation (bs 64)
+            x_c1 = ops.bn_relu_maxpool(conv(x.contiguous()), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       bn.momentum, bn.eps, bn.num_batches_tracked)
+        else:
+            x_c1 = self.conv1[3](bn(conv(x.contiguous()), relu=True))
         x_b1 = self.conv2x(x_c1)
         x_b2 = self.conv3x(x_b1)
         x_b3 = self.conv4x(x_b2)

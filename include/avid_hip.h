@@ -134,6 +134,18 @@ int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, const float* 
  * Pooling.  MaxPool3d((1,3,3),(1,2,2),(0,1,1)) — models/video.py:23;  AdaptiveMaxPool{3,2}d(1) —
  * models/video.py:41, models/audio.py:31.  Ties: first maximum in (t,h,w) scan order (ATen CPU).
  * ---------------------------------------------------------------------------------------------- */
+/* Stem tail fused (models/video.py:21-23): y = maxpool(relu(bn_train(x))) with x [B,T,H,W,C] the stem conv
+ * output, y / argmax [B,T,Ho,Wo,C]; the normalised activation is never materialised.  Backward rebuilds the
+ * un-pooled gradient from (dy, argmax) on the fly.  Same saved tensors / workspace as avid_bn_fwd_train. */
+int avid_bn_relu_maxpool_fwd(int B, int T, int H, int W, int C, const float* x, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                             float* y, uint8_t* argmax, float* save_mean, float* save_invstd, float* save_scale,
+                             float* save_shift, int64_t* num_batches_tracked, void* ws, size_t ws_bytes,
+                             avid_stream_t stream);
+int avid_bn_relu_maxpool_bwd(int B, int T, int H, int W, int C, const float* x, const float* dy,
+                             const uint8_t* argmax, const float* gamma, const float* save_mean,
+                             const float* save_invstd, const float* save_scale, const float* save_shift, float* dx,
+                             float* dgamma, float* dbeta, void* ws, size_t ws_bytes, avid_stream_t stream);
 int avid_maxpool_hw3s2_fwd(int B, int T, int H, int W, int C, const float* x, float* y,
                            uint8_t* argmax, avid_stream_t stream);
 int avid_maxpool_hw3s2_bwd(int B, int T, int H, int W, int C, const float* dy,

@@ -240,6 +240,32 @@ def test_maxpool_hw3s2(gpu_device):
         np.testing.assert_allclose(ncdhw(xd.grad).cpu().numpy(), xr.grad.numpy(), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 10, 12, 64), (1, 2, 7, 9, 64), (3, 2, 56, 56, 64)])
+def test_bn_relu_maxpool_fused(shape, gpu_device):
+    """The fused stem tail against the three separate ops (already checked against torch): identical pooled
+    output, argmax behaviour and running statistics; gradients within 1e-5 (different partial-sum order)."""
+    from avid_hip import ops
+    B, T_, H, W, C = shape
+    x = T(detgen.det_normalish(f"bnpool:{shape}:x", shape)).to(gpu_device)
+    g = T(detgen.det_uniform(f"bnpool:{shape}:g", (C,))).to(gpu_device) + 1.5
+    b = T(detgen.det_uniform(f"bnpool:{shape}:b", (C,))).to(gpu_device)
+    outs = []
+    for fused in (False, True):
+        xx, gg, bb = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=gpu_device), torch.ones(C, device=gpu_device)
+        cnt = torch.zeros((), dtype=torch.int64, device=gpu_device)
+        if fused:
+            y = ops.bn_relu_maxpool(xx, gg, bb, rm, rv, 0.1, 1e-5, cnt)
+        else:
+            y = ops.maxpool_hw3s2(ops.batch_norm_cl(xx, gg, bb, rm, rv, True, 0.1, 1e-5, True, cnt))
+        gy = T(detgen.det_uniform(f"bnpool:{shape}:gy", tuple(y.shape))).to(gpu_device)
+        (y * gy).sum().backward()
+        outs.append((y.detach(), rm, rv, int(cnt), xx.grad, gg.grad, bb.grad))
+    (y0, rm0, rv0, c0, dx0, dg0, db0), (y1, rm1, rv1, c1, dx1, dg1, db1) = outs
+    assert torch.equal(y0, y1) and torch.equal(rm0, rm1) and torch.equal(rv0, rv1) and c0 == c1 == 1
+    assert relerr(dx1, dx0) < 1e-5 and relerr(dg1, dg0) < 1e-5 and relerr(db1, db0) < 1e-5
+
+
 def test_global_maxpool(gpu_device):
     from avid_hip import ops
     for shp in [(3, 512, 1, 4, 4), (2, 512, 1, 3, 7), (2, 64, 2, 5, 5)]:
