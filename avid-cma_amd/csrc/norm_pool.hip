@@ -227,30 +227,33 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     const floatx4 is = reinterpret_cast<const floatx4*>(invstd)[g];
     const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g];
     const floatx4 sh = reinterpret_cast<const floatx4*>(shift)[g];
-    floatx4 s1 = {0, 0, 0, 0}, sx1 = {0, 0, 0, 0};
-    const floatx4 z = {0, 0, 0, 0};
-    for (int k = r; k < rows_per_block; k += 2 * rows_per_pass) {   // two independent row streams per thread
-      const long long ra = row0 + k, rb = ra + rows_per_pass;
-      const bool oa = ra < M, ob = (k + rows_per_pass < rows_per_block) && rb < M;
-      const long long pa = (oa ? ra : 0) * C + g * 4, pb = (ob ? rb : 0) * C + g * 4;
-      floatx4 da = *reinterpret_cast<const floatx4*>(dy + pa), db = *reinterpret_cast<const floatx4*>(dy + pb);
-      const floatx4 xa = *reinterpret_cast<const floatx4*>(x + pa), xb = *reinterpret_cast<const floatx4*>(x + pb);
-      if (relu) {   // ReLU mask recomputed from x with the forward's exact fma (no read of the saved output)
+    floatx4 sA[4], xA[4];   // four independent row streams per thread (latency: x and dy both come from HBM/MALL)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          da[j] = fmaf(xa[j], sc[j], sh[j]) > 0.f ? da[j] : 0.f;
-          db[j] = fmaf(xb[j], sc[j], sh[j]) > 0.f ? db[j] : 0.f;
-        }
+    for (int u = 0; u < 4; ++u) sA[u] = xA[u] = floatx4{0, 0, 0, 0};
+    for (int k = r; k < rows_per_block; k += 4 * rows_per_pass) {
+      floatx4 d[4], xv[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long row = row0 + k + u * rows_per_pass;
+        ok[u] = (k + u * rows_per_pass < rows_per_block) && row < M;
+        const long long pos = (ok[u] ? row : 0) * C + g * 4;
+        d[u] = *reinterpret_cast<const floatx4*>(dy + pos);
+        xv[u] = *reinterpret_cast<const floatx4*>(x + pos);
       }
-      da = oa ? da : z;
-      db = ob ? db : z;
-      s += da;
-      sx += da * ((xa - mu) * is);
-      s1 += db;
-      sx1 += db * ((xb - mu) * is);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (relu) {   // ReLU mask recomputed from x with the forward's exact fma (no read of the saved output)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[u][j] = fmaf(xv[u][j], sc[j], sh[j]) > 0.f ? d[u][j] : 0.f;
+        }
+        if (!ok[u]) d[u] = floatx4{0, 0, 0, 0};
+        sA[u] += d[u];
+        xA[u] += d[u] * ((xv[u] - mu) * is);
+      }
     }
-    s += s1;
-    sx += sx1;
+    s = (sA[0] + sA[1]) + (sA[2] + sA[3]);
+    sx = (xA[0] + xA[1]) + (xA[2] + xA[3]);
   }
   sh[0][tid] = s;
   sh[1][tid] = sx;
