@@ -236,7 +236,7 @@ class _ConvCL(Function):
     """y = conv(x, w) [+ addend] [+ bias] [relu]  — avid_conv_fwd / avid_conv_dgrad / avid_conv_wgrad."""
 
     @staticmethod
-    def forward(ctx, x, w, addend, bias, stride, pad, relu, channel_first, want_stats=False):
+    def forward(ctx, x, w, addend, bias, stride, pad, relu, channel_first, want_stats=False, tap=False):
         _need_cuda(x, w, addend, bias)
         if not x.is_contiguous():
             raise AvidHipError("conv: x must be contiguous (channels-last [B,T,H,W,C])")
@@ -268,18 +268,27 @@ class _ConvCL(Function):
         ctx.has_addend, ctx.has_bias = addend is not None, bias is not None
         ctx.bias_ptr = bias.data_ptr() if bias is not None else 0
         ctx.save_for_backward(x, w, y if relu else None)
+        ctx.want_stats, ctx.tap = want_stats, tap
+        outs = [y]
         if want_stats:
             if stats is None:
                 stats = torch.empty(0, dtype=torch.float32, device=x.device)
             ctx.mark_non_differentiable(stats)
-            return y, stats
-        return y
+            outs.append(stats)
+        if tap:
+            # an alias of the input for a second consumer (the residual branch): its gradient comes back into
+            # THIS backward and rides in the dgrad kernel's addend — no separate accumulate kernel
+            outs.append(x.view(x.shape))
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     @staticmethod
-    def backward(ctx, dy, _dstats=None):
+    def backward(ctx, dy, *more):
         x, w, y = ctx.saved_tensors
         d = ctx.d
         dy = dy.contiguous()
+        d_tap = more[-1] if (ctx.tap and more) else None
+        if d_tap is not None:
+            d_tap = d_tap.contiguous()
         st = _stream()
         if ctx.relu:
             g = torch.empty_like(dy)
@@ -312,7 +321,7 @@ class _ConvCL(Function):
         if need_dx:
             ws = workspace(x.device, ctx.nb_dgrad)
             dx = torch.empty_like(x)
-            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_wt_for(w)), None, _p(dx), _p(ws), ws.numel(), st)
+            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_wt_for(w)), _p(d_tap), _p(dx), _p(ws), ws.numel(), st)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
@@ -329,15 +338,19 @@ class _ConvCL(Function):
             if slot is not None:
                 _grad_done(slot)
                 dbias = None
-        return dx, dw, dadd, dbias, None, None, None, None, None
+        if d_tap is not None and not need_dx:
+            dx = d_tap
+        return dx, dw, dadd, dbias, None, None, None, None, None, None
 
 
 def conv_cl(x, w, stride=(1, 1, 1), pad=(0, 0, 0), addend=None, bias=None, relu=False, channel_first=False,
-            bn_stats=False):
-    """``bn_stats=True`` returns ``(y, partials)``: ``partials`` are y's BatchNorm partial sums from the conv
-    epilogue (pass them to ``batch_norm_cl``), or an empty tensor when the layer cannot produce them."""
-    if bn_stats:
-        return _ConvCL.apply(x, w, addend, bias, tuple(stride), tuple(pad), bool(relu), bool(channel_first), True)
+            bn_stats=False, tap=False):
+    """``bn_stats=True`` adds ``partials`` to the result: y's BatchNorm partial sums from the conv epilogue (pass
+    them to ``batch_norm_cl``), or an empty tensor when the layer cannot produce them.  ``tap=True`` adds an
+    alias of ``x`` for a second consumer whose gradient is then summed inside this op's dgrad kernel."""
+    if bn_stats or tap:
+        return _ConvCL.apply(x, w, addend, bias, tuple(stride), tuple(pad), bool(relu), bool(channel_first),
+                             bool(bn_stats), bool(tap))
     return _ConvCL.apply(x, w, addend, bias, tuple(stride), tuple(pad), bool(relu), bool(channel_first))
 
 

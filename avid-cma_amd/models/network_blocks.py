@@ -35,10 +35,11 @@ class ConvCL(nn.Module):
         self.weight = nn.Parameter(ops.make_weight(out_planes, in_planes, *self.kernel_size))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
 
-    def forward(self, x, addend=None, bn_stats=False):
-        """``bn_stats=True``: also return the BatchNorm partial sums of the output (for the BN that follows)."""
+    def forward(self, x, addend=None, bn_stats=False, tap=False):
+        """``bn_stats=True``: also return the BatchNorm partial sums of the output (for the BN that follows);
+        ``tap=True``: also return an alias of ``x`` for a second consumer (see ``ops.conv_cl``)."""
         return ops.conv_cl(x, self.weight, self.stride3, self.padding3, addend=addend,
-                           channel_first=self.channel_first, bn_stats=bn_stats)
+                           channel_first=self.channel_first, bn_stats=bn_stats, tap=tap)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
@@ -73,13 +74,18 @@ class BatchNormCL(nn.Module):
 _FUSE_BN_STATS = os.environ.get("AVID_FUSE_BN_STATS", "1") == "1"
 
 
-def _conv_bn(conv, bn, x, addend=None):
+def _conv_bn(conv, bn, x, addend=None, tap=False):
     """ReLU(bn(conv(x) [+ addend])).  In training the conv epilogue hands the BatchNorm its batch statistics
-    as partial sums, so the BN does not re-read the activation for them."""
-    if bn.training and x.is_cuda and _FUSE_BN_STATS:
-        y, partials = conv(x, addend=addend, bn_stats=True)
-        return bn(y, relu=True, partials=partials)
-    return bn(conv(x, addend=addend), relu=True)
+    as partial sums, so the BN does not re-read the activation for them.  ``tap``: also return an alias of x
+    whose gradient is folded into this conv's input-gradient kernel (the residual branch)."""
+    fuse = bn.training and x.is_cuda and _FUSE_BN_STATS
+    out = conv(x, addend=addend, bn_stats=fuse, tap=tap)
+    if not (fuse or tap):
+        return bn(out, relu=True)
+    y = out[0]
+    partials = out[1] if fuse else None
+    h = bn(y, relu=True, partials=partials)
+    return (h, out[-1]) if tap else h
 
 
 class Basic2DBlock(nn.Module):
@@ -128,7 +134,11 @@ class BasicR2P1DBlock(nn.Module):
             self.res = False
 
     def forward(self, x):
-        h = _conv_bn(self.spt_conv1, self.spt_bn1, x)
+        tap = x.is_cuda and x.requires_grad and torch.is_grad_enabled()
+        if tap:     # the residual branch reads an alias of x: its gradient is added inside spt_conv1's dgrad
+            h, x = _conv_bn(self.spt_conv1, self.spt_bn1, x, tap=True)
+        else:
+            h = _conv_bn(self.spt_conv1, self.spt_bn1, x)
         h = _conv_bn(self.tmp_conv1, self.tmp_bn1, h)
         h = _conv_bn(self.spt_conv2, self.spt_bn2, h)
         x_res = self.res_conv(x) if self.res else x
