@@ -269,6 +269,7 @@ class _ConvCL(Function):
         ctx.bias_ptr = bias.data_ptr() if bias is not None else 0
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.want_stats, ctx.tap = want_stats, tap
+        ctx.set_materialize_grads(False)   # no zero-fill kernel for the outputs that get no gradient
         outs = [y]
         if want_stats:
             if stats is None:
@@ -285,8 +286,10 @@ class _ConvCL(Function):
     def backward(ctx, dy, *more):
         x, w, y = ctx.saved_tensors
         d = ctx.d
-        dy = dy.contiguous()
         d_tap = more[-1] if (ctx.tap and more) else None
+        if dy is None:                     # only the tap carried a gradient
+            return d_tap, None, None, None, None, None, None, None, None, None
+        dy = dy.contiguous()
         if d_tap is not None:
             d_tap = d_tap.contiguous()
         st = _stream()
