@@ -1488,9 +1488,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tab_kernel(const WgradArgs p) {
   floatx4 vd[2][NB], vx[2][KC];
   int cb = chunk0;   // first chunk covered by the row table
 
-  auto fill_table = [&]() {
-#pragma unroll
-    for (int r = tid; r < WG_TABC * 32; r += 256) {
+  auto fill_table = [&](int nrows) {
+    for (int r = tid; r < nrows; r += 256) {
       const int m = cb * 32 + r;
       const bool ok = m < p.M;
       const unsigned mm = ok ? (unsigned)m : 0u;
@@ -1583,7 +1582,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tab_kernel(const WgradArgs p) {
   for (; cb < chunk1; cb += WG_TABC) {
     const int ce = min(cb + WG_TABC, chunk1);
     __syncthreads();                 // the previous block's table reads are done
-    fill_table();
+    fill_table((ce - cb) * 32);
     __syncthreads();
     load_chunk(cb);
     store_chunk(u);
@@ -1761,13 +1760,14 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const avid_wt_desc* __restrict__ descs) {
   const avid_wt_desc d = descs[blockIdx.y];
   const long long n = (long long)d.Cout * d.ntaps * d.Cin;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int co = (int)(i % d.Cout);
-  const long long r = i / d.Cout;
-  const int tap = (int)(r % d.ntaps);
-  const int ci = (int)(r / d.ntaps);
-  d.wt[i] = d.w[((long long)co * d.ntaps + tap) * d.Cin + ci];
+  const long long stride = (long long)gridDim.x * blockDim.x;    // fixed-width grid: small tensors exit at once
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int co = (int)(i % d.Cout);
+    const long long r = i / d.Cout;
+    const int tap = (int)(r % d.ntaps);
+    const int ci = (int)(r / d.ntaps);
+    d.wt[i] = d.w[((long long)co * d.ntaps + tap) * d.Cin + ci];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2411,8 +2411,9 @@ extern "C" int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_de
   AVID_REQUIRE(n > 0 && descs_dev && max_elems > 0, AVID_E_BADARG, "weight_transpose_batched: bad argument");
   hipStream_t s = (hipStream_t)stream;
   ScopedTimer t(s, "weight_transpose_batched_kernel", 0.0, 0.0);
-  hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)ceil_div(max_elems, 256), (unsigned)n), dim3(256), 0,
-                     s, descs_dev);
+  long long gx = ceil_div(max_elems, 256);
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, s, descs_dev);
   return check_launch("weight_transpose_batched");
 }
 
