@@ -1935,10 +1935,11 @@ static PkPlan plan_pk(long long M, int Cd, int nk) {
   const int cus = device_cus();
   int per_cu = 2;
   if (Cd % 128 == 0) {
-    if (pk_alt()) { k.tile = 2; k.BM = 256; k.BN = 128; per_cu = 1; }
+    if (pk_alt() == 1) { k.tile = 2; k.BM = 256; k.BN = 128; per_cu = 1; }
+    else if (pk_alt() == 2) { k.tile = 1; k.BM = 128; k.BN = 64; }          // experiment: narrow tiles everywhere
     else          { k.tile = 0; k.BM = 128; k.BN = 128; }
   } else {
-    if (pk_alt()) { k.tile = 3; k.BM = 256; k.BN = 64; per_cu = 1; }
+    if (pk_alt() == 1) { k.tile = 3; k.BM = 256; k.BN = 64; per_cu = 1; }
     else          { k.tile = 1; k.BM = 128; k.BN = 64; }
   }
   const int ntn = Cd / k.BN;

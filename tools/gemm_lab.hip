@@ -166,6 +166,9 @@ int main() {
     run<4, 1, 2, 2, 32, 1>("4w 256x64  w64x64 bk32", M, 64, K, 1);
     run<4, 2, 2, 1, 32, 1>("8w 256x64  w64x32 bk32", M, 64, K, 1);
     run<4, 1, 1, 2, 32, 2>("4w 128x64  w32x64 bk32", M, 64, K, 2);
+    run<4, 1, 1, 2, 16, 4>("4w 128x64  w32x64 bk16 x4", M, 64, K, 4);
+    run<4, 1, 1, 2, 16, 3>("4w 128x64  w32x64 bk16 x3", M, 64, K, 3);
+    run<2, 2, 2, 2, 16, 2>("4w 128x128 w64x64 bk16 x2", M, 128, K, 2);
     run<4, 1, 2, 2, 16, 2>("4w 256x64  w64x64 bk16", M, 64, K, 2);
     run<4, 2, 2, 1, 16, 1>("8w 256x64  w64x32 bk16 x2", M, 64, K, 2);
     run<2, 2, 2, 2, 32, 2>("4w 128x128 w64x64 bk32", M, 128, K, 2);
