@@ -92,6 +92,8 @@ def test_conv_bn_partials(shape, cout, gpu_device):
         y, part = ops.conv_cl(x, w, (1, 1, 1), (0, 1, 1), addend=addend, bn_stats=True)
         y_plain = ops.conv_cl(x, w, (1, 1, 1), (0, 1, 1), addend=addend)
         assert torch.equal(y, y_plain)                         # the statistics do not perturb the output
+        if part.numel() == 0:
+            pytest.skip("this configuration (AVID_PK=0) cannot produce conv-side BatchNorm partials")
         assert part.dim() == 3 and part.shape[1:] == (2, cout)
         yd = y.double().reshape(-1, cout)
         s, q = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
