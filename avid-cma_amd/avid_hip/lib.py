@@ -75,6 +75,10 @@ SIGNATURES = {
                                       _vp, _sz, _vp]),
     "avid_bn_relu_maxpool_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                       _vp]),
+    "avid_logspec_basis_floats": (_sz, [_i]),
+    "avid_logspec_basis": (_i, [_i, _vp, _vp]),
+    "avid_logspec_workspace_bytes": (_sz, [_i, _i, _i]),
+    "avid_logspec": (_i, [_i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _sz, _vp]),
     "avid_maxpool_hw3s2_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "avid_maxpool_hw3s2_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "avid_global_maxpool_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),

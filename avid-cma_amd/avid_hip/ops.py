@@ -473,6 +473,35 @@ def bn_relu_maxpool(x, gamma, beta, running_mean, running_var, momentum=0.1, eps
 
 
 # ------------------------------------------------------------------------------------------------
+# audio front end
+# ------------------------------------------------------------------------------------------------
+_LOGSPEC_BASIS = {}
+
+
+def log_spectrogram(sig, n_stft, hop, frames, mean=None, std=None, top_db=100.0):
+    """``sig [B, L]`` mono fp32 on the GPU -> ``[B, 1, frames, n_stft/4 + 1]`` (avid_logspec; reference
+    datasets/preprocessing.py:174-186 with librosa's stft / power_to_db defaults).  No gradient."""
+    _need_cuda(sig, mean, std)
+    if sig.dim() != 2 or sig.dtype != torch.float32 or not sig.is_contiguous():
+        raise AvidHipError("log_spectrogram: sig must be a contiguous fp32 [B, L] tensor")
+    B, L = sig.shape
+    key = (sig.device, int(n_stft))
+    basis = _LOGSPEC_BASIS.get(key)
+    if basis is None:
+        nfl = lib.raw("avid_logspec_basis_floats")(int(n_stft))
+        if nfl == 0:
+            raise AvidHipError(f"log_spectrogram: unsupported STFT size {n_stft}")
+        basis = torch.empty(nfl, dtype=torch.float32, device=sig.device)
+        lib.call("avid_logspec_basis", int(n_stft), _p(basis), _stream())
+        _LOGSPEC_BASIS[key] = basis
+    out = torch.empty((B, 1, int(frames), n_stft // 4 + 1), dtype=torch.float32, device=sig.device)
+    ws = workspace(sig.device, lib.raw("avid_logspec_workspace_bytes")(B, int(n_stft), int(frames)))
+    lib.call("avid_logspec", B, L, _p(sig), int(n_stft), int(hop), int(frames), _p(basis), _p(mean), _p(std),
+             float(top_db), _p(out), _p(ws), ws.numel(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # pooling
 # ------------------------------------------------------------------------------------------------
 class _MaxPoolHW3S2(Function):

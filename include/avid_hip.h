@@ -232,6 +232,21 @@ int avid_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, floa
                    float beta2, float eps, float weight_decay, int64_t step, const int64_t* step_dev,
                    float grad_scale, avid_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Audio front end on the GPU — datasets/preprocessing.py:158-186 LogSpectrogram:
+ * out[b][0][t][f] = z-score( top_db-floored dB( bin-pair mean( |STFT(sig[b])|^2 ) ) ), STFT = librosa.stft
+ * defaults (centred / reflect-padded frames, periodic Hann, n_stft = 2 * n_fft, hop samples).
+ * sig [B][L] mono fp32; out [B][1][T][n_stft/4 + 1], T <= 1 + L/hop (the reference truncates to
+ * int(duration * rate) frames before the dB floor).  basis: avid_logspec_basis_floats(n_stft) floats filled
+ * once by avid_logspec_basis.  mean / std: [n_stft/4 + 1] or both NULL.
+ * ---------------------------------------------------------------------------------------------- */
+size_t avid_logspec_basis_floats(int n_stft);
+int avid_logspec_basis(int n_stft, float* basis, avid_stream_t stream);
+size_t avid_logspec_workspace_bytes(int B, int n_stft, int T);
+int avid_logspec(int B, int L, const float* sig, int n_stft, int hop, int T, const float* basis,
+                 const float* mean, const float* std, float top_db, float* out, void* ws, size_t ws_bytes,
+                 avid_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
