@@ -10,6 +10,11 @@ import ctypes as C
 import os
 import subprocess
 
+# torch must be imported BEFORE libavid_hip.so is dlopen'ed: torch ships its own libamdhip64.so, and a process
+# that loads /opt/rocm's copy first (through this library's DT_NEEDED) ends up with two HIP runtimes — the
+# one this library is bound to then reports "no ROCm-capable device" on its first launch.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libavid_hip.so")
