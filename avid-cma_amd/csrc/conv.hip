@@ -1756,17 +1756,32 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
   wt[i] = w[((long long)co * ntaps + tap) * Ci + ci];
 }
 
-// all weights of a model in one launch: blockIdx.y picks the descriptor
+// all weights of a model in one launch: blockIdx.y picks the descriptor; a block walks 32(co) x 32(ci) tiles of
+// one tap through LDS so that both the read (rows of ci) and the write (rows of co) are contiguous — the
+// element-wise version read with a stride of taps*Cin floats between lanes and took 0.19 ms per step
 __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const avid_wt_desc* __restrict__ descs) {
+  __shared__ float tile[32][33];
   const avid_wt_desc d = descs[blockIdx.y];
-  const long long n = (long long)d.Cout * d.ntaps * d.Cin;
-  const long long stride = (long long)gridDim.x * blockDim.x;    // fixed-width grid: small tensors exit at once
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int co = (int)(i % d.Cout);
-    const long long r = i / d.Cout;
-    const int tap = (int)(r % d.ntaps);
-    const int ci = (int)(r / d.ntaps);
-    d.wt[i] = d.w[((long long)co * d.ntaps + tap) * d.Cin + ci];
+  const int tco = (d.Cout + 31) / 32, tci = (d.Cin + 31) / 32;
+  const long long ntile = (long long)tco * tci * d.ntaps;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  for (long long t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int ci0 = (int)(t % tci) * 32;
+    const long long r = t / tci;
+    const int co0 = (int)(r % tco) * 32;
+    const int tap = (int)(r / tco);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+      tile[ty + 8 * k][tx] = (co < d.Cout && ci < d.Cin) ? d.w[((long long)co * d.ntaps + tap) * d.Cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ci = ci0 + ty + 8 * k, co = co0 + tx;
+      if (ci < d.Cin && co < d.Cout) d.wt[((long long)ci * d.ntaps + tap) * d.Cout + co] = tile[tx][ty + 8 * k];
+    }
+    __syncthreads();
   }
 }
 
@@ -2412,8 +2427,8 @@ extern "C" int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_de
   AVID_REQUIRE(n > 0 && descs_dev && max_elems > 0, AVID_E_BADARG, "weight_transpose_batched: bad argument");
   hipStream_t s = (hipStream_t)stream;
   ScopedTimer t(s, "weight_transpose_batched_kernel", 0.0, 0.0);
-  long long gx = ceil_div(max_elems, 256);
-  if (gx > 128) gx = 128;
+  long long gx = ceil_div(max_elems, 1024);   // 32 x 32 tiles of the largest tensor, capped: blocks stride over tiles
+  if (gx > 256) gx = 256;
   hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, s, descs_dev);
   return check_launch("weight_transpose_batched");
 }
