@@ -85,8 +85,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # AVID_FORCE_DIST=1 drives the multi-GPU code path (RCCL group, bucketed all-reduce, bank all-gather, barrier
+    # + max-over-ranks timing) on a single-rank group: the 1-GPU box check of what the driver runs at N = 2/4/8
+    use_dist = world > 1 or os.environ.get("AVID_FORCE_DIST", "0") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import models
@@ -111,7 +115,7 @@ def main():
     ids = ids[:, rank * bs:(rank + 1) * bs].contiguous().to(dev)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +149,7 @@ def main():
             loss = engine.step(video, audio, ids[args.warmup + i])
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -202,7 +206,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
