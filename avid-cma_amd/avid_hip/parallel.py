@@ -83,7 +83,12 @@ class GradBuckets:
         self.pending = list(self.counts)
         self.works = []
         self.hooks = []
-        if self.comm:
+        self.comm_stream = None
+        self.producers = [set() for _ in self.bounds]     # streams that issued gradients of each bucket
+        # Autograd hooks only where the kernels do not report their gradients themselves (ops.GradSlots, the
+        # CUDA path): 141 tensor hooks cost ~0.4 ms of backward per step on the single-rank check.  A gradient
+        # that arrives through autograd anyway (a parameter used twice) is picked up by finish().
+        if self.comm and not flat.grad.is_cuda:
             for i, p in enumerate(flat.params):
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
@@ -93,40 +98,57 @@ class GradBuckets:
         if not self.comm:
             return
         b = self.bucket_of[i]
+        if self.flat.grad.is_cuda:
+            self.producers[b].add(torch.cuda.current_stream(self.flat.grad.device))
         self.pending[b] -= 1
         if self.pending[b] == 0:
-            s, e = self.bounds[b]
-            self._join_producers()
-            self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
+            self._launch(b)
 
     def _make_hook(self, i):
         def hook(param):
             self.ready(i)
         return hook
 
-    def _join_producers(self):
-        """The two towers' backward passes run on two streams (models/av_wrapper.py) and a bucket may hold
-        gradients from both: the stream the collective is issued from must first wait for the other one."""
+    def _launch(self, b):
+        """Issue bucket b's all-reduce.  The two towers' backward passes run on two streams (models/av_wrapper.py)
+        and a bucket may hold gradients from both, so the collective must wait for every stream that produced
+        them — but the compute streams themselves never wait for each other here (that serialised the audio
+        tower's backward in front of the video tower's): a bucket produced entirely on the current stream is
+        issued from it, a mixed one from a communication-launch stream that waits for its producers only
+        (an event record on a compute stream is not free on this runtime).  ``finish()`` joins the collectives."""
+        s, e = self.bounds[b]
         if not self.flat.grad.is_cuda:
+            self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
             return
         from . import ops
-        cur = torch.cuda.current_stream()
-        for st in (torch.cuda.default_stream(self.flat.grad.device), ops.side_stream(self.flat.grad.device, 1)):
-            if st != cur:
-                cur.wait_stream(st)
+        dev = self.flat.grad.device
+        cur = torch.cuda.current_stream(dev)
+        prod = self.producers[b] or {torch.cuda.default_stream(dev), ops.side_stream(dev, 1)}   # unknown: both towers
+        if prod == {cur}:
+            self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
+            return
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(dev)
+        cs = self.comm_stream
+        for st in prod | {cur}:
+            cs.wait_stream(st)
+        with torch.cuda.stream(cs):
+            self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
 
     def finish(self):
-        """Launch whatever did not fire (unused parameters) and make the current stream wait for all buckets."""
+        """Launch whatever did not fire (unused parameters, gradients that came through autograd) and make the
+        current stream wait for all buckets."""
         if self.comm:
             for b, left in enumerate(self.pending):
                 if left > 0:
-                    s, e = self.bounds[b]
-                    self._join_producers()
-                    self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
+                    self.producers[b].clear()        # not all producers are known: wait for both towers
+                    self._launch(b)
             for w in self.works:
-                w.wait()
+                w.wait()                             # the current (compute) stream waits for the collective
         self.works = []
         self.pending = list(self.counts)
+        for p in self.producers:
+            p.clear()
 
 
 class TrainStep:
