@@ -131,21 +131,32 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs p) {
     const int cur = ch & 1;
     if (ch + 1 < NCH) load_w(ch + 1);
     const float* Wb = Ws + cur * FWD_CH * 8 * WS_LD + l31;
+    // operands of kernel row rr+1 are fetched before the 8 MFMAs of row rr issue (pinned with sched_barrier:
+    // the compiler otherwise puts every ds_read right in front of its MFMA and exposes the LDS latency 16
+    // times per chunk); rows past R read valid LDS and multiply by the zero-filled weight rows
+    float af[2][4], b0f[2][4], b1f[2][4];
+    auto frag = [&](int rr, int buf) {
+      const int row = min(ch * FWD_CH + rr, R - 1);
+      const int dh = row % 7, pl = row / 7;
+      const float* Pr = P + pl * plane + dh * p.PW + base;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        af[buf][q] = Pr[2 * q];
+        b0f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD];
+        b1f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD + 32];
+      }
+    };
+    frag(0, 0);
 #pragma unroll
     for (int rr = 0; rr < FWD_CH; ++rr) {
-      const int row = ch * FWD_CH + rr;
-      if (row < R) {   // uniform
-        const int dh = row % 7, pl = row / 7;
-        const float* Pr = P + pl * plane + dh * p.PW + base;
+      if (rr + 1 < FWD_CH) frag(rr + 1, (rr + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float a = Pr[2 * q];
-          const float b0 = Wb[(rr * 8 + 2 * q + h) * WS_LD];
-          const float b1 = Wb[(rr * 8 + 2 * q + h) * WS_LD + 32];
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-        }
+      for (int q = 0; q < 4; ++q) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rr & 1][q], b0f[rr & 1][q], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rr & 1][q], b1f[rr & 1][q], acc[1], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (ch + 1 < NCH) store_w(cur ^ 1);
     __syncthreads();
@@ -232,16 +243,35 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
       koff[j] = kok[j] ? pl * plane + dh * p.PW + dw : 0;
     }
     __syncthreads();
+    // The patch gather is a dependent LDS chain (pixbase -> patch address): its base is fetched two k-steps
+    // ahead and the operands one k-step ahead of the MFMAs that use them (order pinned with sched_barrier).
+    float a0c, a1c, bvc[NKT], a0n = 0.f, a1n = 0.f, bvn[NKT];
+    int pb1;
+    {
+      const int pb0 = pixbase[h];
+      a0c = Ds[h * WS_LD + l31];
+      a1c = Ds[h * WS_LD + 32 + l31];
+#pragma unroll
+      for (int j = 0; j < NKT; ++j) bvc[j] = kok[j] ? P[pb0 + koff[j]] : 0.f;
+      pb1 = pixbase[2 + h];
+    }
     for (int kk = 0; kk < STEM_TILE / 2; ++kk) {
-      const int px = 2 * kk + h;
-      const float a0 = Ds[px * WS_LD + l31], a1 = Ds[px * WS_LD + 32 + l31];
-      const int pb = pixbase[px];
+      const int pxn = min(2 * (kk + 1) + h, STEM_TILE - 1), pxnn = min(2 * (kk + 2) + h, STEM_TILE - 1);
+      a0n = Ds[pxn * WS_LD + l31];
+      a1n = Ds[pxn * WS_LD + 32 + l31];
+#pragma unroll
+      for (int j = 0; j < NKT; ++j) bvn[j] = kok[j] ? P[pb1 + koff[j]] : 0.f;
+      const int pb2 = pixbase[pxnn];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < NKT; ++j) {
-        const float bv = kok[j] ? P[pb + koff[j]] : 0.f;
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c, bvc[j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c, bvc[j], acc[1][j], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      a0c = a0n; a1c = a1n; pb1 = pb2;
+#pragma unroll
+      for (int j = 0; j < NKT; ++j) bvc[j] = bvn[j];
     }
   }
   // partial slab [blockIdx.x][n][k']
