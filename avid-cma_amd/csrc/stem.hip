@@ -244,34 +244,41 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
     }
     __syncthreads();
     // The patch gather is a dependent LDS chain (pixbase -> patch address): its base is fetched two k-steps
-    // ahead and the operands one k-step ahead of the MFMAs that use them (order pinned with sched_barrier).
-    float a0c, a1c, bvc[NKT], a0n = 0.f, a1n = 0.f, bvn[NKT];
-    int pb1;
+    // ahead and the operands one k-step ahead of the MFMAs that use them (order pinned with sched_barrier;
+    // two k-steps per trip so the register sets ping-pong without copies).  Lanes of the padded / out-of-range
+    // k' columns read patch word pb + 0: their accumulator columns are never read (stem_wgrad_reduce_kernel
+    // skips dw == 7, the slab write skips k' >= KP), so no select is spent on them.
+    float a0[2], a1[2], bv[2][NKT];
+    const float* dsp = Ds + h * WS_LD + l31;        // this lane's dy column, row 2*kk + h
+    const int* pbp = pixbase + h;
+    int pbn;
     {
-      const int pb0 = pixbase[h];
-      a0c = Ds[h * WS_LD + l31];
-      a1c = Ds[h * WS_LD + 32 + l31];
+      const int pb0 = pbp[0];
+      a0[0] = dsp[0];
+      a1[0] = dsp[32];
 #pragma unroll
-      for (int j = 0; j < NKT; ++j) bvc[j] = kok[j] ? P[pb0 + koff[j]] : 0.f;
-      pb1 = pixbase[2 + h];
+      for (int j = 0; j < NKT; ++j) bv[0][j] = P[pb0 + koff[j]];
+      pbn = pbp[2];
     }
-    for (int kk = 0; kk < STEM_TILE / 2; ++kk) {
-      const int pxn = min(2 * (kk + 1) + h, STEM_TILE - 1), pxnn = min(2 * (kk + 2) + h, STEM_TILE - 1);
-      a0n = Ds[pxn * WS_LD + l31];
-      a1n = Ds[pxn * WS_LD + 32 + l31];
+    auto step = [&](int kk, int cur) {   // MFMAs of k-step kk from set `cur`; operands of kk+1 into the other set
+      const int nx = cur ^ 1;
+      const int r1 = 2 * min(kk + 1, STEM_TILE / 2 - 1), r2 = 2 * min(kk + 2, STEM_TILE / 2 - 1);
+      a0[nx] = dsp[r1 * WS_LD];
+      a1[nx] = dsp[r1 * WS_LD + 32];
 #pragma unroll
-      for (int j = 0; j < NKT; ++j) bvn[j] = kok[j] ? P[pb1 + koff[j]] : 0.f;
-      const int pb2 = pixbase[pxnn];
+      for (int j = 0; j < NKT; ++j) bv[nx][j] = P[pbn + koff[j]];
+      pbn = pbp[r2];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < NKT; ++j) {
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0c, bvc[j], acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1c, bvc[j], acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], bv[cur][j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], bv[cur][j], acc[1][j], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      a0c = a0n; a1c = a1n; pb1 = pb2;
-#pragma unroll
-      for (int j = 0; j < NKT; ++j) bvc[j] = bvn[j];
+    };
+    for (int kk = 0; kk < STEM_TILE / 2; kk += 2) {
+      step(kk, 0);
+      step(kk + 1, 1);
     }
   }
   // partial slab [blockIdx.x][n][k']
