@@ -470,7 +470,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   int ld_seg = 0, ld_ks = 0, ld_kend = 0;
   int ld_dt = 0, ld_dh = 0, ld_dw = 0, ld_c0 = 0, ld_tap = 0;   // position in the K loop (tap, channel block)
   int ld_nh = p.kh, ld_nw = p.kw, ld_cls = 0;                  // tap extents of the loader's class (STRIDED)
-  long long ld_base = 0;                                       // element offset of the loader tile's batch span
+  int ld_plo = 0, ld_phi = 0, ld_nrec = 0;                     // A descriptor of the loader tile: base pointer, bytes
+  int ld_soff_a = 0, ld_soff_b = 0;                            // scalar offsets of the current k-tile (A: channel block; B: tap + block)
   unsigned a_base[PA], a_mask[PA], a_cur[PA];                  // tap-(0,0,0) offset, tap validity, current voffset
   unsigned b_off[PB];
   floatx4 va[PA], vb[PB];
@@ -514,9 +515,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     int b_lo = m0 / cpix;
     if (b_lo >= p.B) b_lo = p.B - 1;
     b_lo = __builtin_amdgcn_readfirstlane(b_lo);
-    const long long base = (long long)b_lo * pix_per_b * p.Cs;
-    ld_base = ((long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-              (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    {   // descriptor based at the first batch item the tile touches: 32-bit offsets for any tensor size
+      const long long base = (long long)b_lo * pix_per_b * p.Cs;
+      long long a_bytes = ((long long)p.B * pix_per_b * p.Cs - base) * 4;
+      if (a_bytes > 0x7fffffffll) a_bytes = 0x7fffffffll;
+      const unsigned long long ptr = reinterpret_cast<unsigned long long>(p.src + base);
+      ld_plo = __builtin_amdgcn_readfirstlane((int)(unsigned)ptr);
+      ld_phi = __builtin_amdgcn_readfirstlane((int)(unsigned)(ptr >> 32));
+      ld_nrec = __builtin_amdgcn_readfirstlane((int)a_bytes);
+    }
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const unsigned m = m0 + lrow + RPP * i;
@@ -548,18 +555,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + RPP * i) * ntaps * p.Cs + lcol) * 4;
     retap();
   };
-  auto issue_loads = [&]() {   // k-tile (ld_tile; tap, channel block) -> registers: PA + PB loads, no VALU
-    // the descriptor and the scalar offsets are pinned to SGPRs here: the compiler's divergence analysis
-    // gives up on this loop-carried state and would wrap every load in a readfirstlane waterfall loop
-    const int base_lo = __builtin_amdgcn_readfirstlane((int)ld_base);
-    const int base_hi = __builtin_amdgcn_readfirstlane((int)(ld_base >> 32));
-    const int soff_a = __builtin_amdgcn_readfirstlane(ld_c0 * 4);
-    const int soff_b = __builtin_amdgcn_readfirstlane((ld_tap * p.Cs + ld_c0) * 4);
-    const long long base = ((long long)base_hi << 32) | (unsigned)base_lo;
-    long long a_bytes = ((long long)p.B * pix_per_b * p.Cs - base) * 4;
-    if (a_bytes > 0x7fffffffll) a_bytes = 0x7fffffffll;
-    const __amdgpu_buffer_rsrc_t rsA =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + base), 0, (int)a_bytes, 0x00020000);
+  auto issue_loads = [&]() {   // k-tile (loader tile; tap, channel block) -> registers: PA + PB loads
+    // The descriptor words and scalar offsets were prepared when they last changed (setup_tile / advance); here
+    // they are only pinned to SGPRs — the compiler's divergence analysis gives up on this loop-carried state and
+    // would otherwise wrap every buffer load in a readfirstlane waterfall loop.
+    const unsigned long long ptr = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(ld_phi) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane(ld_plo);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(ptr), 0, __builtin_amdgcn_readfirstlane(ld_nrec), 0x00020000);
+    const int soff_a = __builtin_amdgcn_readfirstlane(ld_soff_a);
+    const int soff_b = __builtin_amdgcn_readfirstlane(ld_soff_b);
 #pragma unroll
     for (int i = 0; i < PA; ++i)
       va[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_cur[i], soff_a, 0));
@@ -577,6 +582,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     } else {
       ld_tap = sgpr((ld_dt * p.kh + ld_dh) * p.kw + ld_dw);
     }
+    ld_soff_a = sgpr(ld_c0 * 4);
+    ld_soff_b = sgpr((ld_tap * p.Cs + ld_c0) * 4);
   };
   auto setup_seg = [&](int j) {   // loader enters segment j (STRIDED: the next segment that has any k-tiles)
     int tile, k0, k1, split;
@@ -606,7 +613,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     if (ld_ks == ld_kend) {          // next segment of this workgroup
       ld_seg = sgpr(ld_seg + 1);
       if (ld_seg < nseg) setup_seg(ld_seg);
-    } else if (ld_c0 == p.Cs) {      // next tap
+    } else if (ld_c0 != p.Cs) {      // next channel block of the same tap
+      ld_soff_a = sgpr(ld_soff_a + BK * 4);
+      ld_soff_b = sgpr(ld_soff_b + BK * 4);
+    } else {                         // next tap
       ld_c0 = 0;
       int dw = ld_dw + 1, dh = ld_dh, dt = ld_dt;
       if (dw == ld_nw) { dw = 0; ++dh; }
