@@ -10,6 +10,8 @@ cases = {
  "c2.spt": (64, 64, (1,3,3), (1,1,1), (0,1,1), (8,28,28)),
  "c3.spt": (128, 128, (1,3,3), (1,1,1), (0,1,1), (4,14,14)),
  "g1152": (1152, 128, (1,1,1), (1,1,1), (0,0,0), (4,14,14)),
+ "c2.spt@224": (64, 64, (1,3,3), (1,1,1), (0,1,1), (8,56,56)),
+ "c2.tmp@224": (64, 64, (3,1,1), (1,1,1), (1,0,0), (8,56,56)),
 }
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 for name, (cin, cout, k, st, pd, (T, H, W)) in cases.items():
