@@ -788,20 +788,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
           (void*)(direct ? p.dst : p.part + (long long)split * p.M * p.Cd), 0, (int)((long long)p.M * row_bytes), 0x00020000);
       const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(p.addend ? p.addend : p.dst), 0, (int)((long long)p.M * row_bytes), 0x00020000);
+      auto emit = [&](auto HAS_ADD) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int jj = 0; jj < TN; ++jj) {
-          const int col4 = (n0 + (wn * TN + jj) * 32 + l31) * 4;
+          for (int jj = 0; jj < TN; ++jj) {
+            const int col4 = (n0 + (wn * TN + jj) * 32 + l31) * 4;
+            unsigned voff[16];
+            float ad[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const unsigned voff = (unsigned)drow[(wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] + col4;
-            float v = acc[i][jj][r];
-            if (direct && p.addend) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, voff, 0, 0));
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff, 0, 0);
+            for (int r = 0; r < 16; ++r) {
+              voff[r] = (unsigned)drow[(wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] + col4;
+              if (HAS_ADD) ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, voff[r], 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[i][jj][r];
+              if (HAS_ADD) v += ad[r];
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff[r], 0, 0);
+            }
           }
         }
-      }
+      };
+      if (direct && p.addend) emit(std::true_type{}); else emit(std::false_type{});
       continue;
     }
     const int mt = tile / ntn, nt = tile - mt * ntn;
@@ -815,29 +824,43 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
         (void*)(direct ? p.dst + d_base : p.part + s_base), 0, rows * row_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.addend ? p.addend + d_base : p.dst + d_base), 0, rows * row_bytes, 0x00020000);
+    // The uniform cases are told apart once per tile, not per element: the element loops below are straight
+    // lines of (load,) VALU, store.
+    auto emit = [&](auto DIRECT, auto HAS_ADD, auto RELU) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int jj = 0; jj < TN; ++jj) {
-        const int col = n0 + (wn * TN + jj) * 32 + l31;
-        const unsigned voff = (unsigned)(((wm * TM + i) * 32 + 4 * h) * p.Cd + col) * 4;
-        const float bv = (direct && p.bias) ? p.bias[col] : 0.f;
+        for (int jj = 0; jj < TN; ++jj) {
+          const int col = n0 + (wn * TN + jj) * 32 + l31;
+          const unsigned voff = (unsigned)(((wm * TM + i) * 32 + 4 * h) * p.Cd + col) * 4;
+          float ad[16];
+          if (HAS_ADD) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int soff = ((r & 3) + 8 * (r >> 2)) * row_bytes;
-          float v = acc[i][jj][r] + bv;
-          if (direct) {
-            if (p.addend) {
-              const float ad = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, voff, soff, 0));
-              v = p.epi_op == 0 ? v + ad : (p.epi_op == 1 ? fminf(v, ad) : fmaxf(v, ad));
-            }
-            if (p.relu) v = fmaxf(v, 0.f);
-            if (p.stats) { cs[jj] += v; cq[jj] = fmaf(v, v, cq[jj]); }   // rows past M are exact zeros
+            for (int r = 0; r < 16; ++r)
+              ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                    rsE, voff, ((r & 3) + 8 * (r >> 2)) * row_bytes, 0));
           }
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff, soff, 0);
+          const float bv = (DIRECT && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int soff = ((r & 3) + 8 * (r >> 2)) * row_bytes;
+            float v = acc[i][jj][r];
+            if (DIRECT) {
+              v += bv;
+              if (HAS_ADD) v += ad[r];
+              if (RELU) v = fmaxf(v, 0.f);
+              if (MODE == 0) { cs[jj] += v; cq[jj] = fmaf(v, v, cq[jj]); }   // rows past M are exact zeros
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff, soff, 0);
+          }
         }
       }
-    }
+    };
+    constexpr std::true_type Y{};
+    constexpr std::false_type N{};
+    if (!direct) emit(N, N, N);
+    else if (p.addend) { if (p.relu) emit(Y, Y, Y); else emit(Y, Y, N); }
+    else { if (p.relu) emit(Y, N, Y); else emit(Y, N, N); }
   }
   write_stats();
 }
@@ -1955,17 +1978,16 @@ static int pk_alt() {
   }
   return alt;
 }
-static PkPlan plan_pk(long long M, int Cd, int nk) {
+static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_out) {
   PkPlan k{};
   const int cus = device_cus();
   int per_cu = 2;
-  if (Cd % 128 == 0) {
-    if (pk_alt() == 1) { k.tile = 2; k.BM = 256; k.BN = 128; per_cu = 1; }
-    else if (pk_alt() == 2) { k.tile = 1; k.BM = 128; k.BN = 64; }          // experiment: narrow tiles everywhere
-    else          { k.tile = 0; k.BM = 128; k.BN = 128; }
-  } else {
-    if (pk_alt() == 1) { k.tile = 3; k.BM = 256; k.BN = 64; per_cu = 1; }
-    else          { k.tile = 1; k.BM = 128; k.BN = 64; }
+  k.tile = tile;
+  switch (tile) {
+    case 0: k.BM = 128; k.BN = 128; break;
+    case 1: k.BM = 128; k.BN = 64; break;
+    case 2: k.BM = 256; k.BN = 128; per_cu = 1; break;
+    default: k.BM = 256; k.BN = 64; per_cu = 1; break;
   }
   const int ntn = Cd / k.BN;
   const int C = cus / ntn * ntn;                    // CUs, a whole number of M-tiles
@@ -1976,7 +1998,7 @@ static PkPlan plan_pk(long long M, int Cd, int nk) {
   // every CU gets the same number; the remaining tail tiles are cut into f K-ranges ("units", at most one
   // per workgroup, handed out starting with the workgroups that got one full tile less).  Cost model in
   // k-tiles per CU: a started tile or unit pays ~2 k-tiles of prologue/epilogue, a split adds the slab pass.
-  const double ovh = 2.0, red = 4.0;
+  const double ovh = 2.0, red = 4.0 * 128 / k.BN;
   double best = 1e300;
   const int fmax = nk / 3 < 64 ? (nk / 3 < 1 ? 1 : nk / 3) : 64;
   for (long long m = T / C; m >= 0 && m >= T / C - 1; --m) {
@@ -2004,7 +2026,23 @@ static PkPlan plan_pk(long long M, int Cd, int nk) {
     k.rot = 0;
     k.paired = false;
   }
+  *cost_out = best * k.BN / 128.0;                  // in k-tiles of a 128-column tile
   return k;
+}
+
+// Tile shape: 128x64 when Cd is not a multiple of 128; otherwise whichever of 128x128 / 128x64 the cost model
+// rates cheaper — the narrow tile quantises M x Cd better (twice the tiles to deal) but reads the activation
+// rows twice and runs a few % below the square tile per flop, so it only wins where whole rounds are lost.
+static PkPlan plan_pk(long long M, int Cd, int nk) {
+  double c0, c1;
+  const int alt = pk_alt();
+  if (Cd % 128 != 0) return plan_pk_tile(M, Cd, nk, alt == 1 ? 3 : 1, &c0);
+  if (alt == 1) return plan_pk_tile(M, Cd, nk, 2, &c0);
+  if (alt == 2) return plan_pk_tile(M, Cd, nk, 1, &c0);
+  const PkPlan wide = plan_pk_tile(M, Cd, nk, 0, &c0);
+  if (alt == 3) return wide;
+  const PkPlan narrow = plan_pk_tile(M, Cd, nk, 1, &c1);
+  return c1 * 1.04 < c0 ? narrow : wide;
 }
 
 // n / d == (n * magic) >> shift for every n < 2^31 (d >= 1)
