@@ -10,6 +10,13 @@ import ctypes as C
 import os
 import subprocess
 
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  An RCCL communicator takes
+# queues of its own; with the default, the audio tower's side stream then shares a queue with the main stream
+# and the towers serialise (measured: +0.5..0.9 ms per step the moment a process group exists, collectives or
+# not; 8 queues: no difference to the single-process step).  Read by the HIP runtime when it initialises, so
+# this has to happen before the first HIP call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # torch must be imported BEFORE libavid_hip.so is dlopen'ed: torch ships its own libamdhip64.so, and a process
 # that loads /opt/rocm's copy first (through this library's DT_NEEDED) ends up with two HIP runtimes — the
 # one this library is bound to then reports "no ROCm-capable device" on its first launch.

@@ -168,6 +168,9 @@ class TrainStep:
             for b in model.buffers():
                 dist.broadcast(b.data, 0)
         self.flat = FlatParams(model)
+        import os
+        if os.environ.get("AVID_BUCKET_MB"):             # tuning knob: gradient all-reduce bucket size
+            bucket_bytes = int(float(os.environ["AVID_BUCKET_MB"]) * (1 << 20))
         self.buckets = GradBuckets(self.flat, bucket_bytes)
         self.m = torch.zeros_like(self.flat.flat)
         self.v = torch.zeros_like(self.flat.flat)

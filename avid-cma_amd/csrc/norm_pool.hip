@@ -164,15 +164,16 @@ __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, con
   shift[c] = beta[c] - rm[c] * sc;
 }
 
+// The grid stride is a multiple of G (= C/4, a divisor of 256 for every width of the two towers) whenever
+// possible: a thread then stays on one channel group, its coefficients are loaded once, and the loop body is
+// load / 4 fma / store — no 64-bit modulo and no coefficient re-reads per element.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        long long n4, int G, int relu) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const int g = (int)(i % G);
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  auto one = [&](long long i, const floatx4& sc, const floatx4& sh) {
     const floatx4 v = reinterpret_cast<const floatx4*>(x)[i];
-    const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g];
-    const floatx4 sh = reinterpret_cast<const floatx4*>(shift)[g];
     floatx4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -180,6 +181,31 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       if (relu) o[j] = fmaxf(o[j], 0.f);
     }
     reinterpret_cast<floatx4*>(y)[i] = o;
+  };
+  if (stride % G == 0) {
+    const int g = (int)(i0 % G);
+    const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g];
+    const floatx4 sh = reinterpret_cast<const floatx4*>(shift)[g];
+    long long i = i0;
+    for (; i + stride < n4; i += 2 * stride) {   // two independent elements in flight
+      const floatx4 v0 = reinterpret_cast<const floatx4*>(x)[i];
+      const floatx4 v1 = reinterpret_cast<const floatx4*>(x)[i + stride];
+      floatx4 o0, o1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o0[j] = fmaf(v0[j], sc[j], sh[j]);
+        o1[j] = fmaf(v1[j], sc[j], sh[j]);
+        if (relu) { o0[j] = fmaxf(o0[j], 0.f); o1[j] = fmaxf(o1[j], 0.f); }
+      }
+      reinterpret_cast<floatx4*>(y)[i] = o0;
+      reinterpret_cast<floatx4*>(y)[i + stride] = o1;
+    }
+    if (i < n4) one(i, sc, sh);
+    return;
+  }
+  for (long long i = i0; i < n4; i += stride) {
+    const int g = (int)(i % G);
+    one(i, reinterpret_cast<const floatx4*>(scale)[g], reinterpret_cast<const floatx4*>(shift)[g]);
   }
 }
 
@@ -294,23 +320,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ k2, float* __restrict__ dx,
                                                            long long n4, int G, int relu) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const int g = (int)(i % G);
-    floatx4 d = reinterpret_cast<const floatx4*>(dy)[i];
-    const floatx4 xv = reinterpret_cast<const floatx4*>(x)[i];
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  struct Coef { floatx4 sc, sh, mu, is, gis, a, b; };
+  auto coef = [&](int g) {
+    Coef c;
+    c.sc = reinterpret_cast<const floatx4*>(scale)[g];
+    c.sh = reinterpret_cast<const floatx4*>(shift)[g];
+    c.mu = reinterpret_cast<const floatx4*>(mean)[g];
+    c.is = reinterpret_cast<const floatx4*>(invstd)[g];
+    c.gis = reinterpret_cast<const floatx4*>(gamma)[g] * c.is;
+    c.a = reinterpret_cast<const floatx4*>(k1)[g];
+    c.b = reinterpret_cast<const floatx4*>(k2)[g];
+    return c;
+  };
+  auto eval = [&](floatx4 d, const floatx4& xv, const Coef& c) {
     if (relu) {
-      const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g];
-      const floatx4 sh = reinterpret_cast<const floatx4*>(shift)[g];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[j] = fmaf(xv[j], sc[j], sh[j]) > 0.f ? d[j] : 0.f;
+      for (int j = 0; j < 4; ++j) d[j] = fmaf(xv[j], c.sc[j], c.sh[j]) > 0.f ? d[j] : 0.f;
     }
-    const floatx4 mu = reinterpret_cast<const floatx4*>(mean)[g];
-    const floatx4 is = reinterpret_cast<const floatx4*>(invstd)[g];
-    const floatx4 ga = reinterpret_cast<const floatx4*>(gamma)[g];
-    const floatx4 a = reinterpret_cast<const floatx4*>(k1)[g];
-    const floatx4 b = reinterpret_cast<const floatx4*>(k2)[g];
-    const floatx4 xh = (xv - mu) * is;
-    reinterpret_cast<floatx4*>(dx)[i] = ga * is * (d - a - xh * b);
+    const floatx4 xh = (xv - c.mu) * c.is;
+    return c.gis * (d - c.a - xh * c.b);
+  };
+  if (stride % G == 0) {   // one channel group per thread: coefficients live in registers (see bn_apply_kernel)
+    const Coef c = coef((int)(i0 % G));
+    long long i = i0;
+    for (; i + stride < n4; i += 2 * stride) {
+      const floatx4 d0 = reinterpret_cast<const floatx4*>(dy)[i], d1 = reinterpret_cast<const floatx4*>(dy)[i + stride];
+      const floatx4 x0 = reinterpret_cast<const floatx4*>(x)[i], x1 = reinterpret_cast<const floatx4*>(x)[i + stride];
+      reinterpret_cast<floatx4*>(dx)[i] = eval(d0, x0, c);
+      reinterpret_cast<floatx4*>(dx)[i + stride] = eval(d1, x1, c);
+    }
+    if (i < n4) reinterpret_cast<floatx4*>(dx)[i] = eval(reinterpret_cast<const floatx4*>(dy)[i], reinterpret_cast<const floatx4*>(x)[i], c);
+    return;
+  }
+  for (long long i = i0; i < n4; i += stride) {
+    const Coef c = coef((int)(i % G));
+    reinterpret_cast<floatx4*>(dx)[i] = eval(reinterpret_cast<const floatx4*>(dy)[i], reinterpret_cast<const floatx4*>(x)[i], c);
   }
 }
 

@@ -26,6 +26,8 @@ for _p in (REPO, os.path.join(REPO, "avid-cma_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see avid_hip/lib.py: must precede HIP runtime initialisation
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -5,10 +5,10 @@ sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "avid-cma_amd"))
 import torch, models, criterions
 from avid_hip.parallel import TrainStep
 dev = torch.device("cuda:0")
-if os.environ.get("AVID_FORCE_DIST") == "1":
+if os.environ.get("AVID_FORCE_DIST") == "1" or os.environ.get("AVID_PG_ONLY"):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29513")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group(os.environ.get("AVID_PG_ONLY") or "nccl", rank=0, world_size=1, **({"device_id": dev} if os.environ.get("AVID_PG_ONLY", "nccl") == "nccl" and not os.environ.get("AVID_PG_LAZY") else {}))
 m = models.av_wrapper("R2Plus1D", {"depth": 18}, "Conv2D", {"depth": 10}, proj_dim=[512, 512, 128]).to(dev).train()
 c = criterions.AVID(num_data=240000, embedding_dim=128, num_negatives=1024, momentum=0.5, device=0)
 e = TrainStep(m, c)
