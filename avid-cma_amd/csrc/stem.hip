@@ -212,24 +212,74 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    const int tf = tile % p.tiles_per_frame, frame = tile / p.tiles_per_frame;
-    const int to = frame % p.Ti, b = frame / p.Ti;
-    const int p0 = tf * STEM_TILE;
-    const int p1 = min(p0 + STEM_TILE, npix);
-    const int ho_lo = p0 / p.Wo, ho_hi = (p1 - 1) / p.Wo;
-    const int nrows_in = 2 * (ho_hi - ho_lo) + 7;
-    const int plane = nrows_in * p.PW;
-    __syncthreads();                               // previous tile fully consumed
-    stem_load_patch<CIN, KT>(p, P, b, to, ho_lo, nrows_in);
-    // dy tile (zero rows past the frame end) + per-pixel patch base
-    for (int e = tid; e < STEM_TILE * 16; e += 512) {
-      const int px = e >> 4, c4 = (e & 15) * 4;
-      const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-      const bool ok = p0 + px < p1;
-      const floatx4 v = *reinterpret_cast<const floatx4*>(p.dy + ((long long)frame * npix + (ok ? p0 + px : p0)) * 64 + c4);
-      *reinterpret_cast<floatx4*>(&Ds[px * WS_LD + c4]) = ok ? v : z;
+  // The next tile's patch and dy rows are fetched into registers while the current tile is multiplied and
+  // written to LDS between the two barriers that separate tiles: the global-load phase (a quarter of this
+  // kernel's time when it ran between the tiles: 0.29 of 1.10 ms) disappears behind the MFMAs.  The patch
+  // row pitch is PW = 4 * q4 floats, so work item e (one float4) lands at LDS float 4 * e.
+  constexpr int PIT = 11;                          // float4 patch items per thread (160 KB of LDS bounds it)
+  floatx4 pre_p[PIT], pre_d[STEM_TILE * 16 / 512];
+  struct TileGeo { int frame, to, b, p0, p1, ho_lo, nrows_in; };
+  auto geo = [&](int tile) {
+    TileGeo g;
+    const int tf = tile % p.tiles_per_frame;
+    g.frame = tile / p.tiles_per_frame;
+    g.to = g.frame % p.Ti;
+    g.b = g.frame / p.Ti;
+    g.p0 = tf * STEM_TILE;
+    g.p1 = min(g.p0 + STEM_TILE, npix);
+    g.ho_lo = g.p0 / p.Wo;
+    g.nrows_in = 2 * ((g.p1 - 1) / p.Wo - g.ho_lo) + 7;
+    return g;
+  };
+  // (Wi % 4 == 0, checked by the host: a patch float4 is then entirely inside or entirely outside its row.)
+  const int q4 = p.PW >> 2;
+  const long long item_floats = (long long)CIN * p.Ti * p.Hi * p.Wi;
+  auto prefetch = [&](const TileGeo& g) {
+    const int total = CIN * KT * g.nrows_in * q4;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (long long)g.b * item_floats), 0, (int)(item_floats * 4), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int e = tid + it * 512;
+      const int r = e / q4, cq = e - r * q4;
+      const int pl = r / g.nrows_in, row = r - pl * g.nrows_in;
+      const int dt = pl % KT, c = pl / KT;
+      const int ti = g.to + dt - KT / 2, hi = 2 * g.ho_lo - 3 + row, wi = cq * 4 - 4;
+      const bool ok = (e < total) & ((unsigned)ti < (unsigned)p.Ti) & ((unsigned)hi < (unsigned)p.Hi) &
+                      ((unsigned)wi < (unsigned)p.Wi);
+      const unsigned off = (unsigned)(((c * p.Ti + ti) * p.Hi + hi) * p.Wi + wi) * 4u;
+      pre_p[it] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? off : 0xfffffff0u, 0, 0));
     }
+    // dy rows of the tile; rows past the frame end fall off num_records and read as zeros
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.dy + ((long long)g.frame * npix + g.p0) * 64), 0, (g.p1 - g.p0) * 256, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < STEM_TILE * 16 / 512; ++it) {
+      const int e = tid + it * 512;
+      pre_d[it] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsD, (unsigned)e * 16u, 0, 0));
+    }
+  };
+  auto commit = [&](const TileGeo& g) {
+    const int total = CIN * KT * g.nrows_in * q4;
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int e = tid + it * 512;
+      if (e < total) *reinterpret_cast<floatx4*>(P + 4 * e) = pre_p[it];
+    }
+#pragma unroll
+    for (int it = 0; it < STEM_TILE * 16 / 512; ++it) {
+      const int e = tid + it * 512;
+      *reinterpret_cast<floatx4*>(&Ds[(e >> 4) * WS_LD + (e & 15) * 4]) = pre_d[it];
+    }
+  };
+
+  if ((int)blockIdx.x < p.ntiles) prefetch(geo(blockIdx.x));
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const TileGeo g = geo(tile);
+    const int p0 = g.p0, p1 = g.p1, ho_lo = g.ho_lo;
+    const int plane = g.nrows_in * p.PW;
+    __syncthreads();                               // previous tile fully consumed
+    commit(g);
     if (tid < STEM_TILE) {
       const int pi = min(p0 + tid, p1 - 1);
       const int ho = pi / p.Wo, wo = pi - ho * p.Wo;
@@ -243,6 +293,7 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
       koff[j] = kok[j] ? pl * plane + dh * p.PW + dw : 0;
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < p.ntiles) prefetch(geo(tile + gridDim.x));
     // The patch gather is a dependent LDS chain (pixbase -> patch address): its base is fetched two k-steps
     // ahead and the operands one k-step ahead of the MFMAs that use them (order pinned with sched_barrier;
     // two k-steps per trip so the register sets ping-pong without copies).  Lanes of the padded / out-of-range
@@ -366,7 +417,11 @@ static size_t stem_wgrad_lds(const avid_conv_desc* d) {
 }
 
 bool stem_fwd_supported(const avid_conv_desc* d) { return stem_match(d) && stem_fwd_lds(d) <= 160 * 1024; }
-bool stem_wgrad_supported(const avid_conv_desc* d) { return stem_match(d) && stem_wgrad_lds(d) <= 160 * 1024; }
+bool stem_wgrad_supported(const avid_conv_desc* d) {
+  // 11 float4 patch items per thread of 512 (the kernel's register prefetch) cover any patch that fits the LDS
+  return stem_match(d) && stem_wgrad_lds(d) <= 160 * 1024 && stem_patch_floats(d, STEM_TILE) <= 11 * 512 * 4 &&
+         d->Wi % 4 == 0 && (long long)d->Cin * d->Ti * d->Hi * d->Wi * 4 < (1ll << 31);
+}
 
 size_t stem_fwd_ws_bytes(const avid_conv_desc* d) { return sizeof(float) * (size_t)d->Cin * d->kt * 7 * 8 * 64; }
 int stem_wgrad_groups() { return 256; }
