@@ -74,24 +74,71 @@ __device__ __forceinline__ void stem_load_patch(const StemArgs& p, float* P, int
 constexpr int FWD_TILE = 128;     // forward: 128 pixels / 4 waves per workgroup -> two workgroups per CU
 constexpr int FWD_CH = 4;         // kernel rows per weight chunk (32 k')
 
+// Persistent: 2 workgroups per CU walk the 128-pixel tiles; the next tile's patch is fetched into registers
+// under the current tile's MFMAs and written to LDS between tiles (with the loads between the tiles the
+// kernel took 1.10 ms, of which 0.28 ms were the loads and only ~0.1 ms of that hidden by the co-resident
+// workgroup).  The weight chunks cycle through their two LDS stages across tile boundaries.
 template <int CIN, int KT>
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs p) {
+__global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const StemArgs p) {
   constexpr int R = CIN * KT * 7;             // kernel rows (c, dt, dh)
   constexpr int NCH = (R + FWD_CH - 1) / FWD_CH;
+  constexpr int PIT = 16;                     // float4 patch items per thread (2 x 80 KB of LDS bound it)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;                           // [2][FWD_CH*8][WS_LD]
   float* P = smem + 2 * FWD_CH * 8 * WS_LD;   // patch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-
-  const int tile = blockIdx.x;
-  const int tf = tile % p.tiles_per_frame, frame = tile / p.tiles_per_frame;
-  const int to = frame % p.Ti, b = frame / p.Ti;
   const int npix = p.Ho * p.Wo;
-  const int p0 = tf * FWD_TILE;
-  const int p1 = min(p0 + FWD_TILE, npix);
-  const int ho_lo = p0 / p.Wo, ho_hi = (p1 - 1) / p.Wo;
-  const int nrows_in = 2 * (ho_hi - ho_lo) + 7;
+  const int q4 = p.PW >> 2;
+  const long long item_floats = (long long)CIN * p.Ti * p.Hi * p.Wi;
+
+  struct TileGeo { int frame, to, b, p0, p1, ho_lo, nrows_in; };
+  auto geo = [&](int tile) {
+    TileGeo g;
+    const int tf = tile % p.tiles_per_frame;
+    g.frame = tile / p.tiles_per_frame;
+    g.to = g.frame % p.Ti;
+    g.b = g.frame / p.Ti;
+    g.p0 = tf * FWD_TILE;
+    g.p1 = min(g.p0 + FWD_TILE, npix);
+    g.ho_lo = g.p0 / p.Wo;
+    g.nrows_in = 2 * ((g.p1 - 1) / p.Wo - g.ho_lo) + 7;
+    return g;
+  };
+  // patch[plane = c*KT+dt][row][col]: row 0 <-> hi = 2*ho_lo - 3, col 0 <-> wi = -4; PW = 4*q4, so work item e
+  // (one float4, entirely inside or outside its row since Wi % 4 == 0) lands at LDS float 4*e
+  floatx4 pre_p[PIT];
+  const unsigned mgq = 0xffffffffu / (unsigned)q4 + 1u;     // e / q4 == mulhi(e, mgq) for the e < 2^12 used here
+  auto prefetch = [&](const TileGeo& g) {
+    const int total = CIN * KT * g.nrows_in * q4;
+    const unsigned mgn = 0xffffffffu / (unsigned)g.nrows_in + 1u;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (long long)g.b * item_floats), 0, (int)(item_floats * 4), 0x00020000);
+    // The item -> (plane, row, column) decode is recomputed per tile from an opaque copy of tid (~20 VALU per
+    // item): left to the compiler its tile-invariant parts are hoisted into 30+ long-lived registers and spill.
+    int t0 = tid;
+    asm volatile("" : "+v"(t0));
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int e = t0 + it * 256;
+      const int r = (int)__umulhi((unsigned)e, mgq), cq = e - r * q4;
+      const int pl = (int)__umulhi((unsigned)r, mgn), row = r - pl * g.nrows_in;
+      const int dt = pl % KT, c = pl / KT;
+      const int ti = g.to + dt - KT / 2, hi = 2 * g.ho_lo - 3 + row, wi = cq * 4 - 4;
+      const bool ok = (e < total) & ((unsigned)ti < (unsigned)p.Ti) & ((unsigned)hi < (unsigned)p.Hi) &
+                      ((unsigned)wi < (unsigned)p.Wi);
+      const unsigned off = (unsigned)(((c * p.Ti + ti) * p.Hi + hi) * p.Wi + wi) * 4u;
+      pre_p[it] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? off : 0xfffffff0u, 0, 0));
+    }
+  };
+  auto commit = [&](const TileGeo& g) {
+    const int total = CIN * KT * g.nrows_in * q4;
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int e = tid + it * 256;
+      if (e < total) *reinterpret_cast<floatx4*>(P + 4 * e) = pre_p[it];
+    }
+  };
 
   // weight chunk: 32 rows x 16 float4 = 512 float4 -> 2 per thread
   const int wrow = tid >> 4, wcol = (tid & 15) * 4;   // 16 rows per pass
@@ -109,68 +156,78 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs p) {
     for (int i = 0; i < 2; ++i)
       *reinterpret_cast<floatx4*>(&Ws[buf * FWD_CH * 8 * WS_LD + (wrow + 16 * i) * WS_LD + wcol]) = wv[i];
   };
+
+  int tile = blockIdx.x;
+  if (tile >= p.ntiles) return;
+  int u = 0;                                  // LDS stage of the weight chunk about to be multiplied
   load_w(0);
-  stem_load_patch<CIN, KT>(p, P, b, to, ho_lo, nrows_in);
+  prefetch(geo(tile));
   store_w(0);
-
-  // this lane's pixel; patch col of tap dw = 2*wo + dw + 1 (4-float left pad, conv pad 3)
-  const int pi = p0 + wave * 32 + l31;
-  const bool pok = pi < p1;
-  const int ho = (pok ? pi : p0) / p.Wo, wo = (pok ? pi : p0) - ho * p.Wo;
-  const int base = (2 * (ho - ho_lo)) * p.PW + 2 * wo + 1 + h;
-  const int plane = nrows_in * p.PW;
-
-  floatx16 acc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  __syncthreads();
-  for (int ch = 0; ch < NCH; ++ch) {
-    const int cur = ch & 1;
-    if (ch + 1 < NCH) load_w(ch + 1);
-    const float* Wb = Ws + cur * FWD_CH * 8 * WS_LD + l31;
-    // operands of kernel row rr+1 are fetched before the 8 MFMAs of row rr issue (pinned with sched_barrier:
-    // the compiler otherwise puts every ds_read right in front of its MFMA and exposes the LDS latency 16
-    // times per chunk); rows past R read valid LDS and multiply by the zero-filled weight rows
-    float af[2][4], b0f[2][4], b1f[2][4];
-    auto frag = [&](int rr, int buf) {
-      const int row = min(ch * FWD_CH + rr, R - 1);
-      const int dh = row % 7, pl = row / 7;
-      const float* Pr = P + pl * plane + dh * p.PW + base;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        af[buf][q] = Pr[2 * q];
-        b0f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD];
-        b1f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD + 32];
-      }
-    };
-    frag(0, 0);
-#pragma unroll
-    for (int rr = 0; rr < FWD_CH; ++rr) {
-      if (rr + 1 < FWD_CH) frag(rr + 1, (rr + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rr & 1][q], b0f[rr & 1][q], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rr & 1][q], b1f[rr & 1][q], acc[1], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (ch + 1 < NCH) store_w(cur ^ 1);
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const TileGeo g = geo(tile);
+    const int p0 = g.p0, p1 = g.p1, ho_lo = g.ho_lo;
+    __syncthreads();                          // the previous tile's patch reads are done
+    commit(g);
     __syncthreads();
-  }
+    if (tile + (int)gridDim.x < p.ntiles) prefetch(geo(tile + gridDim.x));
 
-  // epilogue: row = (r&3) + 8*(r>>2) + 4*h within the wave's 32 pixels, col = l31 (+32)
-  const long long m_base = (long long)frame * npix + p0 + wave * 32;
+    // this lane's pixel; patch col of tap dw = 2*wo + dw + 1 (4-float left pad, conv pad 3)
+    const int pi = p0 + wave * 32 + l31;
+    const bool pok = pi < p1;
+    const int ho = (pok ? pi : p0) / p.Wo, wo = (pok ? pi : p0) - ho * p.Wo;
+    const int base = (2 * (ho - ho_lo)) * p.PW + 2 * wo + 1 + h;
+    const int plane = g.nrows_in * p.PW;
+
+    floatx16 acc[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (p0 + wave * 32 + rr < p1) p.y[(m_base + rr) * 64 + j * 32 + l31] = acc[j][r];
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    for (int ch = 0; ch < NCH; ++ch, u ^= 1) {
+      load_w(ch + 1 < NCH ? ch + 1 : 0);      // cyclic: the last chunk of a tile fetches chunk 0 of the next
+      const float* Wb = Ws + u * FWD_CH * 8 * WS_LD + l31;
+      // operands of kernel row rr+1 are fetched before the 8 MFMAs of row rr issue (pinned with sched_barrier:
+      // the compiler otherwise puts every ds_read right in front of its MFMA and exposes the LDS latency 16
+      // times per chunk); rows past R read valid LDS and multiply by the zero-filled weight rows
+      float af[2][4], b0f[2][4], b1f[2][4];
+      auto frag = [&](int rr, int buf) {
+        const int row = min(ch * FWD_CH + rr, R - 1);
+        const int dh = row % 7, pl = row / 7;
+        const float* Pr = P + pl * plane + dh * p.PW + base;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          af[buf][q] = Pr[2 * q];
+          b0f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD];
+          b1f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD + 32];
+        }
+      };
+      frag(0, 0);
+#pragma unroll
+      for (int rr = 0; rr < FWD_CH; ++rr) {
+        if (rr + 1 < FWD_CH) frag(rr + 1, (rr + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rr & 1][q], b0f[rr & 1][q], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rr & 1][q], b1f[rr & 1][q], acc[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      store_w(u ^ 1);
+      __syncthreads();
     }
+
+    // epilogue: row = (r&3) + 8*(r>>2) + 4*h within the wave's 32 pixels, col = l31 (+32)
+    const long long m_base = (long long)g.frame * npix + p0 + wave * 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (p0 + wave * 32 + rr < p1) p.y[(m_base + rr) * 64 + j * 32 + l31] = acc[j][r];
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,7 +473,11 @@ static size_t stem_wgrad_lds(const avid_conv_desc* d) {
   return sizeof(float) * (STEM_TILE * WS_LD + STEM_TILE + stem_patch_floats(d, STEM_TILE));
 }
 
-bool stem_fwd_supported(const avid_conv_desc* d) { return stem_match(d) && stem_fwd_lds(d) <= 160 * 1024; }
+bool stem_fwd_supported(const avid_conv_desc* d) {
+  // two workgroups per CU; 16 float4 patch items per thread of 256 (the kernel's register prefetch)
+  return stem_match(d) && stem_fwd_lds(d) <= 80 * 1024 && stem_patch_floats(d, FWD_TILE) <= 16 * 256 * 4 &&
+         d->Wi % 4 == 0 && (long long)d->Cin * d->Ti * d->Hi * d->Wi * 4 < (1ll << 31);
+}
 bool stem_wgrad_supported(const avid_conv_desc* d) {
   // 11 float4 patch items per thread of 512 (the kernel's register prefetch) cover any patch that fits the LDS
   return stem_match(d) && stem_wgrad_lds(d) <= 160 * 1024 && stem_patch_floats(d, STEM_TILE) <= 11 * 512 * 4 &&
@@ -447,7 +508,8 @@ static int stem_fwd_launch(const avid_conv_desc* d, const float* x, const float*
   const double M = (double)d->B * d->To * d->Ho * d->Wo, K = (double)CIN * KT * 49;
   ScopedTimer t(s, CIN == 3 ? "stem_fwd_kernel<3,3>" : "stem_fwd_kernel<1,1>", 2.0 * M * 64 * K,
                 4.0 * ((double)d->B * CIN * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
-  hipLaunchKernelGGL((stem_fwd_kernel<CIN, KT>), dim3(a.ntiles), dim3(256), lds, s, a);
+  const int grid = a.ntiles < 512 ? a.ntiles : 512;       // 2 workgroups on each of the 256 CUs
+  hipLaunchKernelGGL((stem_fwd_kernel<CIN, KT>), dim3(grid), dim3(256), lds, s, a);
   return check_launch("stem_fwd");
 }
 
