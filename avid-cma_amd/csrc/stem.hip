@@ -24,6 +24,7 @@ struct StemArgs {
   float* __restrict__ part;       // wgrad partials [G][64][R*8]
   int B, Ti, Hi, Wi, Ho, Wo;
   int PW, rows_in_max, tiles_per_frame;
+  int tile_px;                    // wgrad: output pixels per tile (whole rows when a row fits, <= STEM_TILE)
   int ntiles;                     // B*Ti*tiles_per_frame
 };
 
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const StemArgs p) {
 
 // ------------------------------------------------------------------------------------------------
 // Stem wgrad: dW[n][k'] = sum_pixels dy[pixel][n] * patch(pixel, k').  Persistent workgroups (one per
-// CU) walk tiles of 256 pixels, keep the 64 x (R*8) accumulator in registers (each of the 8 waves owns
+// CU) walk tiles of up to 256 pixels (whole output rows), keep the 64 x (R*8) accumulator in registers (each of the 8 waves owns
 // 2 n-tiles x NKT k'-tiles), and write one partial slab each; a fixed-order reduce finishes.
 //   A[i = n][k = pixel] = dyS[pixel][n]         (LDS, [256][64+4])
 //   B[k = pixel][j = k'] = patch[pixbase[pixel] + koff(k'_j)]
@@ -282,8 +283,8 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
     g.frame = tile / p.tiles_per_frame;
     g.to = g.frame % p.Ti;
     g.b = g.frame / p.Ti;
-    g.p0 = tf * STEM_TILE;
-    g.p1 = min(g.p0 + STEM_TILE, npix);
+    g.p0 = tf * p.tile_px;
+    g.p1 = min(g.p0 + p.tile_px, npix);
     g.ho_lo = g.p0 / p.Wo;
     g.nrows_in = 2 * ((g.p1 - 1) / p.Wo - g.ho_lo) + 7;
     return g;
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
     float a0[2], a1[2], bv[2][NKT];
     const float* dsp = Ds + h * WS_LD + l31;        // this lane's dy column, row 2*kk + h
     const int* pbp = pixbase + h;
+    const int nkk = (p.tile_px + 3) / 4 * 2;      // k-steps (pixel pairs), even; rows past the tile are zero dy rows
     int pbn;
     {
       const int pb0 = pbp[0];
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
     }
     auto step = [&](int kk, int cur) {   // MFMAs of k-step kk from set `cur`; operands of kk+1 into the other set
       const int nx = cur ^ 1;
-      const int r1 = 2 * min(kk + 1, STEM_TILE / 2 - 1), r2 = 2 * min(kk + 2, STEM_TILE / 2 - 1);
+      const int r1 = 2 * min(kk + 1, nkk - 1), r2 = 2 * min(kk + 2, nkk - 1);
       a0[nx] = dsp[r1 * WS_LD];
       a1[nx] = dsp[r1 * WS_LD + 32];
 #pragma unroll
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    for (int kk = 0; kk < STEM_TILE / 2; kk += 2) {
+    for (int kk = 0; kk < nkk; kk += 2) {
       step(kk, 0);
       step(kk + 1, 1);
     }
@@ -450,12 +452,20 @@ static bool stem_match(const avid_conv_desc* d) {
          d->To == d->Ti;
 }
 
+// Pixels per wgrad tile: whole output rows (no ragged last tile per frame: 4 x 56 = 224 of 256 pixel slots
+// instead of 13 tiles x 256 slots for 3136 pixels) when at least one row fits.
+static int stem_wgrad_tile_px(const avid_conv_desc* d) {
+  const int rows = STEM_TILE / d->Wo;
+  return rows >= 1 ? rows * d->Wo : STEM_TILE;
+}
+
 static void stem_geometry(const avid_conv_desc* d, StemArgs& a, int tile) {
   a.B = d->B; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo;
   a.PW = (d->Wi + 4 + 4 + 3) / 4 * 4;                       // 4 left pad + >= 4 right pad (taps reach wi = W+3)
   const int npix = d->Ho * d->Wo;
+  a.tile_px = tile;
   a.tiles_per_frame = (npix + tile - 1) / tile;
-  const int rows_out = (tile - 1 + d->Wo - 1) / d->Wo + 1;
+  const int rows_out = tile % d->Wo == 0 ? tile / d->Wo : (tile - 1 + d->Wo - 1) / d->Wo + 1;
   a.rows_in_max = 2 * (rows_out - 1) + 7;
   a.ntiles = d->B * d->Ti * a.tiles_per_frame;
 }
@@ -470,7 +480,7 @@ static size_t stem_fwd_lds(const avid_conv_desc* d) {
   return sizeof(float) * (2 * FWD_CH * 8 * WS_LD + stem_patch_floats(d, FWD_TILE));
 }
 static size_t stem_wgrad_lds(const avid_conv_desc* d) {
-  return sizeof(float) * (STEM_TILE * WS_LD + STEM_TILE + stem_patch_floats(d, STEM_TILE));
+  return sizeof(float) * (STEM_TILE * WS_LD + STEM_TILE + stem_patch_floats(d, stem_wgrad_tile_px(d)));
 }
 
 bool stem_fwd_supported(const avid_conv_desc* d) {
@@ -480,7 +490,7 @@ bool stem_fwd_supported(const avid_conv_desc* d) {
 }
 bool stem_wgrad_supported(const avid_conv_desc* d) {
   // 11 float4 patch items per thread of 512 (the kernel's register prefetch) cover any patch that fits the LDS
-  return stem_match(d) && stem_wgrad_lds(d) <= 160 * 1024 && stem_patch_floats(d, STEM_TILE) <= 11 * 512 * 4 &&
+  return stem_match(d) && stem_wgrad_lds(d) <= 160 * 1024 && stem_patch_floats(d, stem_wgrad_tile_px(d)) <= 11 * 512 * 4 &&
          d->Wi % 4 == 0 && (long long)d->Cin * d->Ti * d->Hi * d->Wi * 4 < (1ll << 31);
 }
 
@@ -517,7 +527,7 @@ template <int CIN, int KT>
 static int stem_wgrad_launch(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,
                              hipStream_t s) {
   StemArgs a{};
-  stem_geometry(d, a, STEM_TILE);
+  stem_geometry(d, a, stem_wgrad_tile_px(d));
   a.x = x; a.dy = dy; a.part = static_cast<float*>(ws);
   int G = stem_wgrad_groups();
   if (G > a.ntiles) G = a.ntiles;
