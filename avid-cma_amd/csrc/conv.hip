@@ -826,7 +826,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
         (void*)(p.addend ? p.addend + d_base : p.dst + d_base), 0, rows * row_bytes, 0x00020000);
     // The uniform cases are told apart once per tile, not per element: the element loops below are straight
     // lines of (load,) VALU, store.
-    auto emit = [&](auto DIRECT, auto HAS_ADD, auto RELU) {
+    auto emit = [&](auto DIRECT, auto HAS_ADD, auto RELU, auto OP) {   // OP: addend combines by 0 add, 1 min, 2 max
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
             float v = acc[i][jj][r];
             if (DIRECT) {
               v += bv;
-              if (HAS_ADD) v += ad[r];
+              if (HAS_ADD) v = decltype(OP)::value == 0 ? v + ad[r] : (decltype(OP)::value == 1 ? fminf(v, ad[r]) : fmaxf(v, ad[r]));
               if (RELU) v = fmaxf(v, 0.f);
               if (MODE == 0) { cs[jj] += v; cq[jj] = fmaf(v, v, cq[jj]); }   // rows past M are exact zeros
             }
@@ -858,9 +858,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     };
     constexpr std::true_type Y{};
     constexpr std::false_type N{};
-    if (!direct) emit(N, N, N);
-    else if (p.addend) { if (p.relu) emit(Y, Y, Y); else emit(Y, Y, N); }
-    else { if (p.relu) emit(Y, N, Y); else emit(Y, N, N); }
+    constexpr std::integral_constant<int, 0> ADD{};
+    if (!direct) emit(N, N, N, ADD);
+    else if (p.addend) {
+      if (MODE == 0 && p.epi_op == 1) emit(Y, Y, N, std::integral_constant<int, 1>{});        // CMA agreement scores
+      else if (MODE == 0 && p.epi_op == 2) emit(Y, Y, N, std::integral_constant<int, 2>{});
+      else if (p.relu) emit(Y, Y, Y, ADD);
+      else emit(Y, Y, N, ADD);
+    } else {
+      if (p.relu) emit(Y, N, Y, ADD); else emit(Y, N, N, ADD);
+    }
   }
   write_stats();
 }
@@ -2400,6 +2407,10 @@ int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin,
   a.nsplit = 1; a.ksteps_per_split = 1 << 30; a.part = nullptr; a.ncls = 1; a.cls_ptiles_total = 0;
   a.mt2_begin = 0; a.mt2_count = (int)((((long long)M + 127) / 128 + 1) / 2); a.part_row_begin = 0;
   a.ssB = a.ssT = a.ssH = a.ssW = a.ssC = 0;
+  a.stats = nullptr;
+  a.mgW = a.mgH = a.mgT = 0; a.shW = a.shH = a.shT = 0;
+  // persistent kernel, no K-split (K = 128: 4 k-tiles per tile, thousands of tiles): 54 -> ~90 TFLOP/s
+  if (pk_enabled()) return dispatch_igemm<0>(a, nullptr, 0, s);
   return launch_igemm<4, 1, 1, 2, 0>(a, s);
 }
 

@@ -379,6 +379,57 @@ def test_cma_topk_vs_reference_golden(golden, gpu_device):
     assert torch.equal(torch.cat([a, b]), full)
 
 
+def test_cma_topk_filter_path_vs_oracle(gpu_device):
+    """Banks of >= 4096 rows take the threshold-filter selection (csrc/cma_topk.hip): all four agreement types
+    against the oracle's dense search; rows sorted, self excluded; a ragged last query batch; sharded ranges."""
+    from avid_hip import topk
+    N, Pk = 6000, 32
+    gen = torch.Generator().manual_seed(11)
+    v1 = torch.nn.functional.normalize(torch.randn(N, 128, generator=gen), dim=1)
+    v2 = torch.nn.functional.normalize(torch.randn(N, 128, generator=gen), dim=1)
+    d1, d2 = v1.to(gpu_device), v2.to(gpu_device)
+    for kind, name in enumerate(["consensus", "union", "video", "audio"]):
+        got = topk.cma_topk(d1, d2, 0, N, Pk, kind, batch=1024).cpu().numpy()
+        want = O.cma_topk(v1, v2, Pk, name)
+        same = np.mean([set(got[i]) == set(want[i]) for i in range(N)])
+        assert same > 0.998, (name, same)          # fp32 summation order may swap a boundary pair
+        for i in range(0, N, 7):
+            assert i not in set(got[i]) and len(set(got[i]) & set(want[i])) >= Pk - 1
+        assert (np.diff(got, axis=1) > 0).all()
+    a = topk.cma_topk(d1, d2, 0, 2500, Pk, 0, batch=512)
+    b = topk.cma_topk(d1, d2, 2500, N, Pk, 0, batch=256)
+    assert torch.equal(torch.cat([a, b]), topk.cma_topk(d1, d2, 0, N, Pk, 0, batch=1024))
+
+
+def test_cma_topk_tie_overflow_falls_back_to_exact_scan(gpu_device):
+    """Heavy ties overflow the filter's candidate lists; the exact insertion-list scan then redoes the batch.
+    All rows identical: every score ties, order is (value desc, index asc) -> top 33 = rows 0..32, rank 0
+    (row 0) dropped -> 1..32 for every query.  Half identical / half random: the identical half still resolves
+    by index, the random half is still a valid top-K."""
+    from avid_hip import topk
+    N, Pk = 5000, 32
+    row = torch.nn.functional.normalize(torch.randn(1, 128, generator=torch.Generator().manual_seed(3)), dim=1)
+    bank = row.repeat(N, 1).contiguous().to(gpu_device)
+    got = topk.cma_topk(bank, bank, 0, N, Pk, 0, batch=512).cpu()
+    assert torch.equal(got, torch.arange(1, Pk + 1, dtype=got.dtype).repeat(N, 1))
+    gen = torch.Generator().manual_seed(5)
+    mixed = torch.nn.functional.normalize(torch.randn(N, 128, generator=gen), dim=1)
+    mixed[:2000] = row
+    got = topk.cma_topk(mixed.to(gpu_device), mixed.to(gpu_device), 0, N, Pk, 2, batch=1024).cpu().numpy()
+    assert (got[:2000] == np.arange(1, Pk + 1)[None]).all()       # the 2000 duplicates tie at score 1.0
+    # random half: a valid top-(Pk+1) minus self under ties (the 2000 duplicates share one score per query, so
+    # set equality with torch.topk's arbitrary tie order is not the criterion)
+    sims = (mixed @ mixed[2000::15].t()).numpy()                  # [N, nq']
+    for col, q in enumerate(range(2000, N, 15)):
+        sc = sims[:, col]
+        kth = np.sort(sc)[::-1][Pk]                               # (Pk+1)-th best score
+        sel = set(got[q].tolist())
+        assert q not in sel and len(sel) == Pk
+        assert all(sc[i] >= kth - 2e-6 for i in sel)
+        must = set(np.nonzero(sc > kth + 2e-6)[0].tolist()) - {q}
+        assert must <= sel
+
+
 def test_avid_cma_constructor_end_to_end(gpu_device):
     """criterions.AVID_CMA(...) builds its positive_set with the HIP search and trains one step."""
     import criterions
