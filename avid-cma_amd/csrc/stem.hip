@@ -72,15 +72,17 @@ __device__ __forceinline__ void stem_load_patch(const StemArgs& p, float* P, int
   }
 }
 
-constexpr int FWD_TILE = 128;     // forward: 128 pixels / 4 waves per workgroup -> two workgroups per CU
 constexpr int FWD_CH = 4;         // kernel rows per weight chunk (32 k')
 
 // Persistent: 2 workgroups per CU walk the 128-pixel tiles; the next tile's patch is fetched into registers
 // under the current tile's MFMAs and written to LDS between tiles (with the loads between the tiles the
 // kernel took 1.10 ms, of which 0.28 ms were the loads and only ~0.1 ms of that hidden by the co-resident
 // workgroup).  The weight chunks cycle through their two LDS stages across tile boundaries.
-template <int CIN, int KT>
-__global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const StemArgs p) {
+// WAVES = 4: 128-pixel tiles, two workgroups per CU (<= 80 KB of LDS each); WAVES = 8: 256-pixel tiles, one
+// workgroup per CU — the form the 224 x 224 inputs of the shipped configs need (their 13-row patch is 109 KB).
+template <int CIN, int KT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const StemArgs p) {
+  constexpr int NT = WAVES * 64, TILE = WAVES * 32;
   constexpr int R = CIN * KT * 7;             // kernel rows (c, dt, dh)
   constexpr int NCH = (R + FWD_CH - 1) / FWD_CH;
   constexpr int PIT = 16;                     // float4 patch items per thread (2 x 80 KB of LDS bound it)
@@ -100,8 +102,8 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const StemArgs p) {
     g.frame = tile / p.tiles_per_frame;
     g.to = g.frame % p.Ti;
     g.b = g.frame / p.Ti;
-    g.p0 = tf * FWD_TILE;
-    g.p1 = min(g.p0 + FWD_TILE, npix);
+    g.p0 = tf * TILE;
+    g.p1 = min(g.p0 + TILE, npix);
     g.ho_lo = g.p0 / p.Wo;
     g.nrows_in = 2 * ((g.p1 - 1) / p.Wo - g.ho_lo) + 7;
     return g;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const StemArgs p) {
     asm volatile("" : "+v"(t0));
 #pragma unroll
     for (int it = 0; it < PIT; ++it) {
-      const int e = t0 + it * 256;
+      const int e = t0 + it * NT;
       const int r = (int)__umulhi((unsigned)e, mgq), cq = e - r * q4;
       const int pl = (int)__umulhi((unsigned)r, mgn), row = r - pl * g.nrows_in;
       const int dt = pl % KT, c = pl / KT;
@@ -136,26 +138,27 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(const StemArgs p) {
     const int total = CIN * KT * g.nrows_in * q4;
 #pragma unroll
     for (int it = 0; it < PIT; ++it) {
-      const int e = tid + it * 256;
+      const int e = tid + it * NT;
       if (e < total) *reinterpret_cast<floatx4*>(P + 4 * e) = pre_p[it];
     }
   };
 
-  // weight chunk: 32 rows x 16 float4 = 512 float4 -> 2 per thread
-  const int wrow = tid >> 4, wcol = (tid & 15) * 4;   // 16 rows per pass
-  floatx4 wv[2];
+  // weight chunk: 32 rows x 16 float4 = 512 float4 -> WPT per thread
+  constexpr int WPT = 512 / NT, WROWS = NT / 16;      // rows per pass
+  const int wrow = tid >> 4, wcol = (tid & 15) * 4;
+  floatx4 wv[WPT];
   auto load_w = [&](int ch) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int kp = ch * FWD_CH * 8 + wrow + 16 * i;
+    for (int i = 0; i < WPT; ++i) {
+      const int kp = ch * FWD_CH * 8 + wrow + WROWS * i;
       const floatx4 z = {0.f, 0.f, 0.f, 0.f};
       wv[i] = kp < R * 8 ? *reinterpret_cast<const floatx4*>(p.wt + (long long)kp * 64 + wcol) : z;
     }
   };
   auto store_w = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<floatx4*>(&Ws[buf * FWD_CH * 8 * WS_LD + (wrow + 16 * i) * WS_LD + wcol]) = wv[i];
+    for (int i = 0; i < WPT; ++i)
+      *reinterpret_cast<floatx4*>(&Ws[buf * FWD_CH * 8 * WS_LD + (wrow + WROWS * i) * WS_LD + wcol]) = wv[i];
   };
 
   int tile = blockIdx.x;
@@ -476,17 +479,23 @@ size_t stem_patch_floats(const avid_conv_desc* d, int tile) {
   return (size_t)d->Cin * d->kt * a.rows_in_max * a.PW + 16;
 }
 
-static size_t stem_fwd_lds(const avid_conv_desc* d) {
-  return sizeof(float) * (2 * FWD_CH * 8 * WS_LD + stem_patch_floats(d, FWD_TILE));
+static size_t stem_fwd_lds(const avid_conv_desc* d, int tile) {
+  return sizeof(float) * (2 * FWD_CH * 8 * WS_LD + stem_patch_floats(d, tile));
+}
+// forward tile: 128 pixels x 2 workgroups per CU when that fits, else 256 pixels x 1; 0 = neither
+static int stem_fwd_tile(const avid_conv_desc* d) {
+  // 16 float4 patch items per thread (the kernel's register prefetch)
+  if (stem_fwd_lds(d, 128) <= 80 * 1024 && stem_patch_floats(d, 128) <= 16 * 256 * 4) return 128;
+  if (stem_fwd_lds(d, 256) <= 160 * 1024 && stem_patch_floats(d, 256) <= 16 * 512 * 4) return 256;
+  return 0;
 }
 static size_t stem_wgrad_lds(const avid_conv_desc* d) {
   return sizeof(float) * (STEM_TILE * WS_LD + STEM_TILE + stem_patch_floats(d, stem_wgrad_tile_px(d)));
 }
 
 bool stem_fwd_supported(const avid_conv_desc* d) {
-  // two workgroups per CU; 16 float4 patch items per thread of 256 (the kernel's register prefetch)
-  return stem_match(d) && stem_fwd_lds(d) <= 80 * 1024 && stem_patch_floats(d, FWD_TILE) <= 16 * 256 * 4 &&
-         d->Wi % 4 == 0 && (long long)d->Cin * d->Ti * d->Hi * d->Wi * 4 < (1ll << 31);
+  return stem_match(d) && stem_fwd_tile(d) != 0 && d->Wi % 4 == 0 &&
+         (long long)d->Cin * d->Ti * d->Hi * d->Wi * 4 < (1ll << 31);
 }
 bool stem_wgrad_supported(const avid_conv_desc* d) {
   // 11 float4 patch items per thread of 512 (the kernel's register prefetch) cover any patch that fits the LDS
@@ -500,26 +509,27 @@ size_t stem_wgrad_ws_bytes(const avid_conv_desc* d) {
   return sizeof(float) * (size_t)stem_wgrad_groups() * 64 * d->Cin * d->kt * 7 * 8;
 }
 
-template <int CIN, int KT>
+template <int CIN, int KT, int WAVES>
 static int stem_fwd_launch(const avid_conv_desc* d, const float* x, const float* w, float* y, void* ws, hipStream_t s) {
   StemArgs a{};
-  stem_geometry(d, a, FWD_TILE);
+  stem_geometry(d, a, WAVES * 32);
   a.x = x; a.w = w; a.y = y; a.wt = static_cast<float*>(ws);
   constexpr int R = CIN * KT * 7;
   hipLaunchKernelGGL((stem_repack_kernel<CIN, KT>), dim3((R * 8 * 64 + 255) / 256), dim3(256), 0, s, w,
                      static_cast<float*>(ws));
-  const size_t lds = stem_fwd_lds(d);
+  const size_t lds = stem_fwd_lds(d, WAVES * 32);
   static bool set = false;
   if (!set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<CIN, KT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_kernel<CIN, KT, WAVES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     set = true;
   }
   const double M = (double)d->B * d->To * d->Ho * d->Wo, K = (double)CIN * KT * 49;
   ScopedTimer t(s, CIN == 3 ? "stem_fwd_kernel<3,3>" : "stem_fwd_kernel<1,1>", 2.0 * M * 64 * K,
                 4.0 * ((double)d->B * CIN * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
-  const int grid = a.ntiles < 512 ? a.ntiles : 512;       // 2 workgroups on each of the 256 CUs
-  hipLaunchKernelGGL((stem_fwd_kernel<CIN, KT>), dim3(grid), dim3(256), lds, s, a);
+  const int slots = (8 / WAVES) * 256;                    // workgroups resident on the 256 CUs
+  const int grid = a.ntiles < slots ? a.ntiles : slots;
+  hipLaunchKernelGGL((stem_fwd_kernel<CIN, KT, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s, a);
   return check_launch("stem_fwd");
 }
 
@@ -553,7 +563,9 @@ static int stem_wgrad_launch(const avid_conv_desc* d, const float* x, const floa
 }
 
 int stem_fwd(const avid_conv_desc* d, const float* x, const float* w, float* y, void* ws, hipStream_t s) {
-  return d->Cin == 3 ? stem_fwd_launch<3, 3>(d, x, w, y, ws, s) : stem_fwd_launch<1, 1>(d, x, w, y, ws, s);
+  if (stem_fwd_tile(d) == 128)
+    return d->Cin == 3 ? stem_fwd_launch<3, 3, 4>(d, x, w, y, ws, s) : stem_fwd_launch<1, 1, 4>(d, x, w, y, ws, s);
+  return d->Cin == 3 ? stem_fwd_launch<3, 3, 8>(d, x, w, y, ws, s) : stem_fwd_launch<1, 1, 8>(d, x, w, y, ws, s);
 }
 int stem_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, hipStream_t s) {
   return d->Cin == 3 ? stem_wgrad_launch<3, 3>(d, x, dy, dw, ws, s) : stem_wgrad_launch<1, 1>(d, x, dy, dw, ws, s);
