@@ -1105,359 +1105,13 @@ struct WgradArgs {
 
 constexpr int WG_LD = 64 + 4;
 
-template <int NB, int KC>
-__global__ __launch_bounds__(512, 4) void wgrad_kernel(const WgradArgs p) {
-  // Ping-pong like igemm_kernel: two groups of 4 waves, each reducing its own pixel range (split
-  // 2*blockIdx.y + grp) of the same dw tile through a private single-buffered LDS stage, shifted by one
-  // phase so one wave per SIMD is always in its MFMA phase.
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int DW = 64 * NB + 4;                 // dy tile row (floats)
-  constexpr int STAGE = 32 * (DW + KC * WG_LD);   // one group's stage
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-  float* Ds = smem + grp * STAGE;
-  float* Xs = Ds + 32 * DW;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntaps = p.kt * p.kh * p.kw;
-  const int K = ntaps * p.Cs;
-  const int cpt = p.Cs / 64, nchunks = ntaps * cpt;
-
-  // 1-D grid, XCD-local order: the dw tiles of one pixel range (same dy rows, overlapping x rows) are
-  // consecutive logical ids, which xcd_remap keeps on one XCD — they share its L2 instead of each pulling
-  // dy and x from HBM (measured before: 2x the algorithmic HBM bytes for conv2x, 4x for the 128-wide layers)
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bx = (int)(lid % (unsigned)p.tiles), by = (int)(lid / (unsigned)p.tiles);
-  const int ktile = bx % p.kt_tiles, ntile = bx / p.kt_tiles;
-  const int n0 = ntile * 64 * NB;
-  // the KC (tap, c0) chunks of this k tile (uniform)
-  int q_tap[KC], q_c0[KC], q_dt[KC], q_dh[KC], q_dw[KC];
-  unsigned q_off[KC];
-  bool q_ok[KC];
-#pragma unroll
-  for (int j = 0; j < KC; ++j) {
-    const int q = ktile * KC + j;
-    q_ok[j] = q < nchunks;
-    const int qq = q_ok[j] ? q : 0;
-    q_tap[j] = qq / cpt;
-    q_c0[j] = (qq - q_tap[j] * cpt) * 64;
-    q_dw[j] = q_tap[j] % p.kw;
-    const int r = q_tap[j] / p.kw;
-    q_dh[j] = r % p.kh;
-    q_dt[j] = r / p.kh;
-    q_off[j] = (unsigned)(((q_dt[j] * p.Hs + q_dh[j]) * p.Ws + q_dw[j]) * p.Cs + q_c0[j]) * 4;
-  }
-
-  const int split = by * 2 + grp;
-  const int total_chunks = (p.M + 31) / 32;
-  const int chunk0 = min(split * p.chunks_per_split, total_chunks);
-  const int nloop = p.chunks_per_split;           // both groups run the same trip count (barriers!)
-
-  // buffer descriptors (dy and x based at the first batch item this split touches)
-  const int pix_out = p.Td * p.Hd * p.Wd, pix_in = p.Ts * p.Hs * p.Ws;
-  int b_lo = (chunk0 * 32) / pix_out;
-  if (b_lo >= p.B) b_lo = p.B - 1;
-  const long long x_base = (long long)b_lo * pix_in * p.Cs;
-  long long x_bytes = ((long long)p.B * pix_in * p.Cs - x_base) * 4;
-  if (x_bytes > 0x7fffffffll) x_bytes = 0x7fffffffll;
-  const __amdgpu_buffer_rsrc_t rsX =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + x_base), 0, (int)x_bytes, 0x00020000);
-  const long long d_base = (long long)min(chunk0 * 32, p.M - 1) * p.Cd;
-  long long d_bytes = ((long long)p.M * p.Cd - d_base) * 4;
-  if (d_bytes > 0x7fffffffll) d_bytes = 0x7fffffffll;
-  const __amdgpu_buffer_rsrc_t rsD =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + d_base), 0, (int)d_bytes, 0x00020000);
-
-  const int lrow = tid >> 4;         // 0..15 (+16)
-  const int lcol = (tid & 15) * 4;   // 0..60
-  const int cs4 = p.Cs * 4;
-
-  floatx4 vd[2][NB], vx[2][KC];
-
-  auto load_chunk = [&](int it) {     // it = chunk index relative to chunk0
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int mrel = it * 32 + lrow + 16 * i;   // row relative to the split base
-      const int m = chunk0 * 32 + mrel;
-      // row decode by multiply-shift division (the generic integer divisions cost ~100 VALU per row, per chunk)
-      const bool ok = m < p.M;
-      const unsigned mm = ok ? (unsigned)m : 0u;
-      const unsigned q1 = magic_div(mm, p.mgW, p.shW);
-      const int wd = mm - q1 * p.Wd;
-      const unsigned q2 = magic_div(q1, p.mgH, p.shH);
-      const int hd = q1 - q2 * p.Hd;
-      const int b = magic_div(q2, p.mgT, p.shT);
-      const int td = q2 - b * p.Td;
-      const unsigned doff = (unsigned)(mrel * p.Cd + n0 + lcol) * 4;
-#pragma unroll
-      for (int t = 0; t < NB; ++t) vd[i][t] = buf_load4(rsD, ok ? doff + t * 256 : OOB);
-      const int t0 = td * p.st - p.pt, h0 = hd * p.sh - p.ph, w0 = wd * p.sw - p.pw;
-      // byte offset of tap (0,0,0), channel 0; a tap adds a uniform offset (q_off)
-      const unsigned base = (unsigned)((((b - b_lo) * p.Ts + t0) * p.Hs + h0) * p.Ws + w0) * cs4 + lcol * 4;
-#pragma unroll
-      for (int j = 0; j < KC; ++j) {
-        const bool okx = ok & q_ok[j] & ((unsigned)(t0 + q_dt[j]) < (unsigned)p.Ts) &
-                         ((unsigned)(h0 + q_dh[j]) < (unsigned)p.Hs) & ((unsigned)(w0 + q_dw[j]) < (unsigned)p.Ws);
-        vx[i][j] = buf_load4(rsX, okx ? base + q_off[j] : OOB);
-      }
-    }
-  };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int t = 0; t < NB; ++t)
-        *reinterpret_cast<floatx4*>(&Ds[(lrow + 16 * i) * DW + t * 64 + lcol]) = vd[i][t];
-#pragma unroll
-      for (int j = 0; j < KC; ++j)
-        *reinterpret_cast<floatx4*>(&Xs[j * 32 * WG_LD + (lrow + 16 * i) * WG_LD + lcol]) = vx[i][j];
-    }
-  };
-
-  floatx16 acc[NB][KC];
-#pragma unroll
-  for (int t = 0; t < NB; ++t)
-#pragma unroll
-    for (int j = 0; j < KC; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
-  const int h = lane >> 5, l31 = lane & 31;
-  const float* Db = Ds + wm * 32 * NB + l31;
-  const float* Xb = Xs + wn * 32 + l31;
-
-  load_chunk(0);
-  store_chunk();
-  if (1 < nloop) load_chunk(1);
-  __syncthreads();
-  if (grp == 1) __syncthreads();
-  for (int it = 0; it < nloop; ++it) {
-    // phase A: matrix pipe
-    // fragments of k-step pair kp+1 are fetched before the MFMAs of pair kp issue (pinned with
-    // sched_barrier: left alone the compiler sinks each ds_read next to its use and exposes the LDS latency
-    // sixteen times per chunk); a pair per fetch keeps the ds_read2_b32 merging
-    float a[2][2][NB], b[2][2][KC];
-    auto frag = [&](int kp, int buf) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int kk = 2 * kp + q;
-#pragma unroll
-        for (int t = 0; t < NB; ++t) a[buf][q][t] = Db[(2 * kk + h) * DW + t * 32];             // A[i = n][k = m]
-#pragma unroll
-        for (int j = 0; j < KC; ++j) b[buf][q][j] = Xb[j * 32 * WG_LD + (2 * kk + h) * WG_LD];  // B[k = m][j = c]
-      }
-    };
-    frag(0, 0);
-#pragma unroll
-    for (int kp = 0; kp < 8; ++kp) {
-      if (kp + 1 < 8) frag(kp + 1, (kp + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int t = 0; t < NB; ++t)
-#pragma unroll
-          for (int j = 0; j < KC; ++j)
-            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][q][t], b[kp & 1][q][j], acc[t][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-    // phase B: stage
-    if (it + 1 < nloop) {
-      store_chunk();
-      if (it + 2 < nloop) load_chunk(it + 2);
-    }
-    __syncthreads();
-  }
-  if (grp == 0) __syncthreads();
-
-  if (split >= p.nsplit) return;                  // odd split count: the partner group had no slab
-  float* o = p.out + (long long)split * p.Cd * K;
-#pragma unroll
-  for (int t = 0; t < NB; ++t)
-#pragma unroll
-    for (int j = 0; j < KC; ++j) {
-      if (!q_ok[j]) continue;
-      const int kcol = q_tap[j] * p.Cs + q_c0[j] + wn * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wm * 32 * NB + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        o[(long long)n * K + kcol] = acc[t][j][r];
-      }
-    }
-}
-
-// Double-buffered 4-wave variant (one split per workgroup): used for the 128x128 tile, whose 64
-// accumulator registers do not leave room for two 8-wave workgroups per CU.
-template <int NB, int KC>
-__global__ __launch_bounds__(256) void wgrad_db_kernel(const WgradArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int DW = 64 * NB + 4;                 // dy tile row (floats)
-  constexpr int BUF = 32 * (DW + KC * WG_LD);     // one stage
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntaps = p.kt * p.kh * p.kw;
-  const int K = ntaps * p.Cs;
-  const int cpt = p.Cs / 64, nchunks = ntaps * cpt;
-
-  // 1-D grid, XCD-local order: the dw tiles of one pixel range (same dy rows, overlapping x rows) are
-  // consecutive logical ids, which xcd_remap keeps on one XCD — they share its L2 instead of each pulling
-  // dy and x from HBM (measured before: 2x the algorithmic HBM bytes for conv2x, 4x for the 128-wide layers)
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bx = (int)(lid % (unsigned)p.tiles), by = (int)(lid / (unsigned)p.tiles);
-  const int ktile = bx % p.kt_tiles, ntile = bx / p.kt_tiles;
-  const int n0 = ntile * 64 * NB;
-  // the KC (tap, c0) chunks of this k tile (uniform)
-  int q_tap[KC], q_c0[KC], q_dt[KC], q_dh[KC], q_dw[KC];
-  unsigned q_off[KC];
-  bool q_ok[KC];
-#pragma unroll
-  for (int j = 0; j < KC; ++j) {
-    const int q = ktile * KC + j;
-    q_ok[j] = q < nchunks;
-    const int qq = q_ok[j] ? q : 0;
-    q_tap[j] = qq / cpt;
-    q_c0[j] = (qq - q_tap[j] * cpt) * 64;
-    q_dw[j] = q_tap[j] % p.kw;
-    const int r = q_tap[j] / p.kw;
-    q_dh[j] = r % p.kh;
-    q_dt[j] = r / p.kh;
-    q_off[j] = (unsigned)(((q_dt[j] * p.Hs + q_dh[j]) * p.Ws + q_dw[j]) * p.Cs + q_c0[j]) * 4;
-  }
-
-  const int total_chunks = (p.M + 31) / 32;
-  const int chunk0 = by * p.chunks_per_split;
-  const int chunk1 = min(chunk0 + p.chunks_per_split, total_chunks);
-
-  // buffer descriptors (dy and x based at the first batch item this split touches)
-  const int pix_out = p.Td * p.Hd * p.Wd, pix_in = p.Ts * p.Hs * p.Ws;
-  const int b_lo = (chunk0 * 32) / pix_out;
-  const long long x_base = (long long)b_lo * pix_in * p.Cs;
-  long long x_bytes = ((long long)p.B * pix_in * p.Cs - x_base) * 4;
-  if (x_bytes > 0x7fffffffll) x_bytes = 0x7fffffffll;
-  const __amdgpu_buffer_rsrc_t rsX =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + x_base), 0, (int)x_bytes, 0x00020000);
-  const long long d_base = (long long)chunk0 * 32 * p.Cd;
-  long long d_bytes = ((long long)p.M * p.Cd - d_base) * 4;
-  if (d_bytes > 0x7fffffffll) d_bytes = 0x7fffffffll;
-  const __amdgpu_buffer_rsrc_t rsD =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + d_base), 0, (int)(d_bytes > 0 ? d_bytes : 0), 0x00020000);
-
-  const int lrow = tid >> 4;         // 0..15 (+16)
-  const int lcol = (tid & 15) * 4;   // 0..60
-  const int cs4 = p.Cs * 4;
-
-  floatx4 vd[2][NB], vx[2][KC];
-
-  auto load_chunk = [&](int ch) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int mrel = (ch - chunk0) * 32 + lrow + 16 * i;   // row relative to the split base
-      const int m = chunk0 * 32 + mrel;
-      // row decode by multiply-shift division (the generic integer divisions cost ~100 VALU per row, per chunk)
-      const bool ok = m < p.M;
-      const unsigned mm = ok ? (unsigned)m : 0u;
-      const unsigned q1 = magic_div(mm, p.mgW, p.shW);
-      const int wd = mm - q1 * p.Wd;
-      const unsigned q2 = magic_div(q1, p.mgH, p.shH);
-      const int hd = q1 - q2 * p.Hd;
-      const int b = magic_div(q2, p.mgT, p.shT);
-      const int td = q2 - b * p.Td;
-      const unsigned doff = (unsigned)(mrel * p.Cd + n0 + lcol) * 4;
-#pragma unroll
-      for (int t = 0; t < NB; ++t) vd[i][t] = buf_load4(rsD, ok ? doff + t * 256 : OOB);
-      const int t0 = td * p.st - p.pt, h0 = hd * p.sh - p.ph, w0 = wd * p.sw - p.pw;
-      // byte offset of tap (0,0,0), channel 0; a tap adds a uniform offset (q_off)
-      const unsigned base = (unsigned)((((b - b_lo) * p.Ts + t0) * p.Hs + h0) * p.Ws + w0) * cs4 + lcol * 4;
-#pragma unroll
-      for (int j = 0; j < KC; ++j) {
-        const bool okx = ok & q_ok[j] & ((unsigned)(t0 + q_dt[j]) < (unsigned)p.Ts) &
-                         ((unsigned)(h0 + q_dh[j]) < (unsigned)p.Hs) & ((unsigned)(w0 + q_dw[j]) < (unsigned)p.Ws);
-        vx[i][j] = buf_load4(rsX, okx ? base + q_off[j] : OOB);
-      }
-    }
-  };
-  auto store_chunk = [&](int buf) {
-    float* Ds = smem + buf * BUF;
-    float* Xs = Ds + 32 * DW;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int t = 0; t < NB; ++t)
-        *reinterpret_cast<floatx4*>(&Ds[(lrow + 16 * i) * DW + t * 64 + lcol]) = vd[i][t];
-#pragma unroll
-      for (int j = 0; j < KC; ++j)
-        *reinterpret_cast<floatx4*>(&Xs[j * 32 * WG_LD + (lrow + 16 * i) * WG_LD + lcol]) = vx[i][j];
-    }
-  };
-
-  floatx16 acc[NB][KC];
-#pragma unroll
-  for (int t = 0; t < NB; ++t)
-#pragma unroll
-    for (int j = 0; j < KC; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
-  const int h = lane >> 5, l31 = lane & 31;
-
-  if (chunk0 < chunk1) {
-    load_chunk(chunk0);
-    store_chunk(0);
-  }
-  __syncthreads();
-  for (int ch = chunk0; ch < chunk1; ++ch) {
-    const int cur = (ch - chunk0) & 1;
-    if (ch + 1 < chunk1) load_chunk(ch + 1);
-    const float* Db = smem + cur * BUF + wm * 32 * NB + l31;
-    const float* Xb = smem + cur * BUF + 32 * DW + wn * 32 + l31;
-    float a[2][2][NB], b[2][2][KC];   // fragment prefetch one k-step pair ahead (see wgrad_kernel)
-    auto frag = [&](int kp, int buf) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int kk = 2 * kp + q;
-#pragma unroll
-        for (int t = 0; t < NB; ++t) a[buf][q][t] = Db[(2 * kk + h) * DW + t * 32];             // A[i = n][k = m]
-#pragma unroll
-        for (int j = 0; j < KC; ++j) b[buf][q][j] = Xb[j * 32 * WG_LD + (2 * kk + h) * WG_LD];  // B[k = m][j = c]
-      }
-    };
-    frag(0, 0);
-#pragma unroll
-    for (int kp = 0; kp < 8; ++kp) {
-      if (kp + 1 < 8) frag(kp + 1, (kp + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int t = 0; t < NB; ++t)
-#pragma unroll
-          for (int j = 0; j < KC; ++j)
-            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][q][t], b[kp & 1][q][j], acc[t][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (ch + 1 < chunk1) store_chunk(cur ^ 1);
-    __syncthreads();
-  }
-
-  float* o = p.out + (long long)by * p.Cd * K;
-#pragma unroll
-  for (int t = 0; t < NB; ++t)
-#pragma unroll
-    for (int j = 0; j < KC; ++j) {
-      if (!q_ok[j]) continue;
-      const int kcol = q_tap[j] * p.Cs + q_c0[j] + wn * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wm * 32 * NB + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        o[(long long)n * K + kcol] = acc[t][j][r];
-      }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Row-table variant: the weight-gradient kernel of every vector-path layer.
 //
 // A GEMM of this shape with a GEMM's loader (tools/gemm_tn_lab.hip: reduction-major operands, 4-byte
-// fragment reads, 4 waves, double-buffered) runs at 113-119 TFLOP/s; the two kernels above reach 80-98
-// because every one of the 16 threads that share a pixel row re-derives that row's coordinates, tap
+// fragment reads, 4 waves, double-buffered) runs at 113-119 TFLOP/s; the first two versions of this kernel
+// (8-wave ping-pong, 4-wave double-buffered; see git history) reached 80-98 because every one of the 16 threads
+// that share a pixel row re-derived that row's coordinates, tap
 // validity and offset for every 32-pixel chunk (~130 VALU per thread per chunk — and an MFMA only overlaps
 // with OTHER waves' instructions).  Here the workgroup decodes each of its rows ONCE into an LDS table
 // (byte offset of tap (0,0,0), 3x8 validity bits); per chunk a thread reads its two entries and spends
@@ -2649,24 +2303,41 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
   if (rc) return rc;
   AVID_REQUIRE(buf && len > 0 && which >= 0 && which <= 2, AVID_E_BADARG, "conv_kernel_name: bad argument");
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
+  auto pk_name = [&](long long M, int Cd, int nk, int mode) {
+    const PkPlan pk = plan_pk(M, Cd, nk);
+    static const char* kPk[] = {"2,2,2,2", "4,1,1,2", "4,2,2,2", "4,2,2,1"};
+    snprintf(buf, len, "igemm_pk_kernel<%s,%d> full=%d tail_units=%d f=%d", kPk[pk.tile], mode, pk.full, pk.tail_units, pk.f);
+  };
   if (which == 0) {
     const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
     if (!vec) {
-      snprintf(buf, len, "igemm_gather_kernel<%s>", ((M + 127) / 128) * (d->Cout / 64) >= 256 ? "4,1,1,2" : "2,2,1,1");
+      if (stem_fwd_supported(d))
+        snprintf(buf, len, "stem_fwd_kernel<%d,%d>", d->Cin, d->kt);
+      else
+        snprintf(buf, len, "igemm_gather_kernel<%s>", ((M + 127) / 128) * (d->Cout / 64) >= 256 ? "4,1,1,2" : "2,2,1,1");
+    } else if (pk_enabled()) {
+      pk_name(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK), 0);
     } else {
       IgemmPlan pl = plan_igemm(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK), true);
       snprintf(buf, len, "igemm_kernel<%s,0> splitk=%d", kTileName[pl.tile], pl.nsplit);
     }
   } else if (which == 1) {
     const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
-    IgemmPlan pl = plan_igemm(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK), true);
-    snprintf(buf, len, "igemm_kernel<%s,1> splitk=%d", kTileName[pl.tile], pl.nsplit);
+    const bool strided = d->st > 1 || d->sh > 1 || d->sw > 1;
+    if (pk_enabled() && strided) {
+      snprintf(buf, len, "igemm_pk_kernel<%s,1>s2 (stride-parity classes)", d->Cin % 128 == 0 ? "2,2,2,2" : "4,1,1,2");
+    } else if (pk_enabled()) {
+      pk_name(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK), 1);
+    } else {
+      IgemmPlan pl = plan_igemm(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK), true);
+      snprintf(buf, len, "igemm_kernel<%s,1> splitk=%d", kTileName[pl.tile], pl.nsplit);
+    }
   } else {
     WgradPlan pl = wgrad_plan(d);
     if (!pl.vec)
-      snprintf(buf, len, "wgrad_gather_kernel splits=%d", pl.nsplit);
+      snprintf(buf, len, stem_wgrad_supported(d) ? "stem_wgrad_kernel splits=%d" : "wgrad_gather_kernel splits=%d", pl.nsplit);
     else
-      snprintf(buf, len, "wgrad_kernel<%d,%d> splits=%d", pl.NB, pl.KC, pl.nsplit);
+      snprintf(buf, len, "wgrad_tab_kernel<%d,%d> splits=%d", pl.NB, pl.KC, pl.nsplit);
   }
   return AVID_OK;
 }
