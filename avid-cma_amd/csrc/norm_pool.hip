@@ -27,7 +27,7 @@ static BnPlan bn_plan(int64_t M, int C) {
   p.G = C / 4;
   p.rows_per_pass = 256 / p.G;
   int64_t rpb = ceil_div(M, 1024);
-  if (rpb < 64) rpb = 64;
+  if (rpb < 16) rpb = 16;   // small layers: more, shorter blocks (64-row blocks left conv5x with 16 blocks of 8 dependent iterations)
   rpb = ceil_div(rpb, p.rows_per_pass) * p.rows_per_pass;
   p.rows_per_block = (int)rpb;
   p.nblk = (int)ceil_div(M, rpb);
