@@ -76,41 +76,51 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// Combine the per-block partials in fp64.  Block = 16 channels x 64 slices of the partial list, every
-// thread keeping 4 independent row streams in flight (the first version, 64 channels x 16 slices with one
-// dependent chain of <= 64 loads per thread, took 11-13 us per BatchNorm layer — 1 ms per training step);
-// the 4 slices that share a wave are folded with lane shuffles, the 16 waves through LDS.
-constexpr int FIN_CH = 16, FIN_SLICES = 64;
+// Combine the per-block partials in fp64.  Block = 16 channels (4 float4 groups) x 256 slices of the partial
+// list: with up to 1024 partial rows a thread has at most 4 rows and all of its 8 float4 loads are in flight
+// at once — the kernel is one memory round trip plus the fold (lane shuffles across the 16 slices that share a
+// wave, LDS across the 16 waves).  History: 64 channels x 16 slices with one dependent chain of <= 64 scalar
+// loads per thread took 11-13 us per BatchNorm layer (1 ms per training step); 16 x 64 slices with 4 scalar
+// streams 6-10 us (rocprofv3; 82 launches per step).
+constexpr int FIN_CH = 16, FIN_SLICES = 256;
 
-__device__ __forceinline__ void finalize_sums(const float* __restrict__ part, int nblk, int C, int c, int slice,
+__device__ __forceinline__ void finalize_sums(const float* __restrict__ part, int nblk, int C, int blk,
                                               double (*sh)[2][FIN_CH], double& s0, double& s1) {
-  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-  if (c < C) {
+  const int g = threadIdx.x & 3, slice = threadIdx.x >> 2;
+  const int c0 = blk * FIN_CH + g * 4;
+  double a[4][4], b[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[u][j] = b[u][j] = 0.0;
+  if (c0 < C) {
     const long long st = 2ll * C;
-    int k = slice;
-    for (; k + 3 * FIN_SLICES < nblk; k += 4 * FIN_SLICES) {
-      const float* q = part + (long long)k * st + c;
-      const float x0 = q[0], y0 = q[C];
-      const float x1 = q[FIN_SLICES * st], y1 = q[FIN_SLICES * st + C];
-      const float x2 = q[2 * FIN_SLICES * st], y2 = q[2 * FIN_SLICES * st + C];
-      const float x3 = q[3 * FIN_SLICES * st], y3 = q[3 * FIN_SLICES * st + C];
-      a0 += (double)x0; b0 += (double)y0;
-      a1 += (double)x1; b1 += (double)y1;
-      a2 += (double)x2; b2 += (double)y2;
-      a3 += (double)x3; b3 += (double)y3;
-    }
-    for (; k < nblk; k += FIN_SLICES) {
-      a0 += (double)part[(long long)k * st + c];
-      b0 += (double)part[(long long)k * st + C + c];
+    for (int k = slice; k < nblk; k += 4 * FIN_SLICES) {
+      floatx4 x[4], y[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = k + u * FIN_SLICES;
+        const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+        const float* q = part + (long long)(row < nblk ? row : k) * st + c0;
+        x[u] = row < nblk ? *reinterpret_cast<const floatx4*>(q) : z;
+        y[u] = row < nblk ? *reinterpret_cast<const floatx4*>(q + C) : z;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[u][j] += (double)x[u][j]; b[u][j] += (double)y[u][j]; }
     }
   }
-  double a = (a0 + a1) + (a2 + a3), b = (b0 + b1) + (b2 + b3);
-  a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-  a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
   const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 48) == 0) {
-    sh[wave][0][threadIdx.x & 15] = a;
-    sh[wave][1][threadIdx.x & 15] = b;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double sa = (a[0][j] + a[1][j]) + (a[2][j] + a[3][j]), sb = (b[0][j] + b[1][j]) + (b[2][j] + b[3][j]);
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) { sa += __shfl_xor(sa, m, 64); sb += __shfl_xor(sb, m, 64); }
+    if ((threadIdx.x & 63) < 4) {
+      sh[wave][0][g * 4 + j] = sa;
+      sh[wave][1][g * 4 + j] = sb;
+    }
   }
   __syncthreads();
   s0 = 0;
@@ -132,10 +142,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ shift,
                                                            long long* __restrict__ num_batches_tracked) {
   __shared__ double sh[16][2][FIN_CH];
-  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), slice = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
   if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   double s, ss;
-  finalize_sums(part, nblk, C, c, slice, sh, s, ss);
+  finalize_sums(part, nblk, C, blockIdx.x, sh, s, ss);
   if (threadIdx.x >= FIN_CH || c >= C) return;
   const double mean = s / (double)M;
   double var = ss / (double)M - mean * mean;
@@ -300,9 +310,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                                float* __restrict__ dbeta, float* __restrict__ k1,
                                                                float* __restrict__ k2) {
   __shared__ double sh[16][2][FIN_CH];
-  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), slice = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
   double s, sx;
-  finalize_sums(part, nblk, C, c, slice, sh, s, sx);
+  finalize_sums(part, nblk, C, blockIdx.x, sh, s, sx);
   if (threadIdx.x >= FIN_CH || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)sx;
@@ -737,7 +747,7 @@ extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* 
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
                        p.rows_per_pass, p.rows_per_block);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SLICES), 0, s, part, nblk, (long long)M,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, nblk, (long long)M,
                      C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift,
                      reinterpret_cast<long long*>(num_batches_tracked));
   const long long n4 = (long long)M * p.G;
@@ -781,7 +791,7 @@ extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, co
                        save_invstd, part,
                        (long long)M, C, p.G, p.rows_per_pass, p.rows_per_block, relu);
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SLICES), 0, s, part, p.nblk,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, p.nblk,
                      (long long)M, C, dgamma, dbeta, k1, k2);
   const long long n4 = (long long)M * p.G;
   {
@@ -813,7 +823,7 @@ extern "C" int avid_bn_relu_maxpool_fwd(int B, int T, int H, int W, int C, const
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
                        p.rows_per_pass, p.rows_per_block);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SLICES), 0, s, part, p.nblk,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, p.nblk,
                      (long long)M, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
                      save_scale, save_shift, reinterpret_cast<long long*>(num_batches_tracked));
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
@@ -854,7 +864,7 @@ extern "C" int avid_bn_relu_maxpool_bwd(int B, int T, int H, int W, int C, const
     hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3(nblk), dim3(256), 0, s, x, save_scale, save_shift, dy, argmax,
                        save_mean, save_invstd, part, cells, C, p.G, p.rows_per_pass, (int)cpb, H, W, Ho, Wo);
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_SLICES), 0, s, part, nblk,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, nblk,
                      (long long)M, C, dgamma, dbeta, k1, k2);
   const long long nc4 = cells * p.G;
   {
