@@ -29,7 +29,11 @@ struct StemArgs {
 };
 
 constexpr int STEM_TILE = 256;    // output pixels per workgroup tile
-constexpr int WS_LD = 64 + 4;     // padded weight-stage row
+// LDS rows of 64 floats read as MFMA operands by (lane & 31 = column, lane >> 5 = row parity): the two 32-column
+// halves of ODD rows are stored swapped (column ^ 32), so the half-waves land on disjoint banks without padding
+// (with a 68-float pitch the odd-row half-wave overlapped 28 of the even row's 32 banks: 21-28 % of the LDS
+// cycles of the stem kernels were bank conflicts).
+constexpr int WS_LD = 64;
 
 // Wt[k'][n] = w[n][dt][dh][dw][c]   (k' = ((c*KT+dt)*7+dh)*8+dw ; dw == 7 -> 0)
 template <int CIN, int KT>
@@ -158,7 +162,8 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const S
   auto store_w = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
-      *reinterpret_cast<floatx4*>(&Ws[buf * FWD_CH * 8 * WS_LD + (wrow + WROWS * i) * WS_LD + wcol]) = wv[i];
+      *reinterpret_cast<floatx4*>(&Ws[buf * FWD_CH * 8 * WS_LD + (wrow + WROWS * i) * WS_LD +
+                                      (wcol ^ (((wrow + WROWS * i) & 1) << 5))]) = wv[i];
   };
 
   int tile = blockIdx.x;
@@ -202,8 +207,8 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const S
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           af[buf][q] = Pr[2 * q];
-          b0f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD];
-          b1f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD + 32];
+          b0f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD + 32 * h];          // row parity == h: swapped halves
+          b1f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD + 32 - 32 * h];
         }
       };
       frag(0, 0);
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
 #pragma unroll
     for (int it = 0; it < STEM_TILE * 16 / 512; ++it) {
       const int e = tid + it * 512;
-      *reinterpret_cast<floatx4*>(&Ds[(e >> 4) * WS_LD + (e & 15) * 4]) = pre_d[it];
+      *reinterpret_cast<floatx4*>(&Ds[(e >> 4) * WS_LD + (((e & 15) * 4) ^ (((e >> 4) & 1) << 5))]) = pre_d[it];
     }
   };
 
@@ -361,14 +366,15 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
     // k' columns read patch word pb + 0: their accumulator columns are never read (stem_wgrad_reduce_kernel
     // skips dw == 7, the slab write skips k' >= KP), so no select is spent on them.
     float a0[2], a1[2], bv[2][NKT];
-    const float* dsp = Ds + h * WS_LD + l31;        // this lane's dy column, row 2*kk + h
+    const float* dsp = Ds + h * WS_LD + l31;        // this lane's dy column, row 2*kk + h (odd rows: halves swapped)
+    const int c0 = 32 * h, c1 = 32 - 32 * h;
     const int* pbp = pixbase + h;
     const int nkk = (p.tile_px + 3) / 4 * 2;      // k-steps (pixel pairs), even; rows past the tile are zero dy rows
     int pbn;
     {
       const int pb0 = pbp[0];
-      a0[0] = dsp[0];
-      a1[0] = dsp[32];
+      a0[0] = dsp[c0];
+      a1[0] = dsp[c1];
 #pragma unroll
       for (int j = 0; j < NKT; ++j) bv[0][j] = P[pb0 + koff[j]];
       pbn = pbp[2];
@@ -376,8 +382,8 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
     auto step = [&](int kk, int cur) {   // MFMAs of k-step kk from set `cur`; operands of kk+1 into the other set
       const int nx = cur ^ 1;
       const int r1 = 2 * min(kk + 1, nkk - 1), r2 = 2 * min(kk + 2, nkk - 1);
-      a0[nx] = dsp[r1 * WS_LD];
-      a1[nx] = dsp[r1 * WS_LD + 32];
+      a0[nx] = dsp[r1 * WS_LD + c0];
+      a1[nx] = dsp[r1 * WS_LD + c1];
 #pragma unroll
       for (int j = 0; j < NKT; ++j) bv[nx][j] = P[pbn + koff[j]];
       pbn = pbp[r2];
