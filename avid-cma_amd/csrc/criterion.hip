@@ -84,7 +84,7 @@ __global__ void alias_draw_kernel(long long n, long long K, const float* __restr
 
 // ---------------------------------------------------------------------------------------------
 // scores[b][j] = <bank[idx[b][j]], emb[b]> * inv_T.  grid = (row chunks, bs); 4 waves/block, each
-// wave keeps 4 independent 512-B row reads in flight.
+// wave keeps its 16 independent 512-B row reads in flight.
 // ---------------------------------------------------------------------------------------------
 constexpr int SC_ROWS_PER_BLOCK = 64;
 
@@ -103,29 +103,37 @@ __global__ __launch_bounds__(256) void bank_scores_fwd_kernel(const long long* _
   const int j0 = blockIdx.x * SC_ROWS_PER_BLOCK;
   const int j1 = min(j0 + SC_ROWS_PER_BLOCK, R);
   const long long* ib = idx + (long long)b * R;
-  for (int j = j0 + wave * 4; j < j1; j += 16) {
-    float acc[4];
+  // a wave owns 16 consecutive rows: lanes 0..15 fetch their indices, then all 16 x DPL row loads are issued
+  // before the first use (with 4 rows per trip and the index load inside the trip a wave made 8 dependent
+  // round trips to random HBM rows: 1.8 TB/s on the 2M-row bank)
+  constexpr int RPW = SC_ROWS_PER_BLOCK / 4;
+  const int jw = j0 + wave * RPW;
+  long long mine = 0;
+  if (lane < RPW && jw + lane < j1) {
+    mine = ib[jw + lane];
+    mine = mine < 0 ? 0 : (mine >= N ? N - 1 : mine);   // never read outside the bank
+  }
+  float v[RPW][DPL];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc[u] = 0.f;
-      if (j + u < j1) {
-        long long row = ib[j + u];
-        row = row < 0 ? 0 : (row >= N ? N - 1 : row);  // never read outside the bank
-        const float* p = bank + row * D;
-        float* ro = rows_out ? rows_out + ((long long)b * R + j + u) * D : nullptr;
+  for (int u = 0; u < RPW; ++u) {
+    const long long row = __shfl(mine, u, 64);
+    const float* p = bank + row * D;
 #pragma unroll
-        for (int k = 0; k < DPL; ++k) {
-          const float v = p[k * 64 + lane];
-          acc[u] += v * e[k];
-          if (ro) ro[k * 64 + lane] = v;  // snapshot of the pre-update row for backward
-        }
-      }
+    for (int k = 0; k < DPL; ++k) v[u][k] = p[k * 64 + lane];   // (rows past j1 re-read row 0: discarded below)
+  }
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const int j = jw + u;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) acc += v[u][k] * e[k];
+    if (rows_out && j < j1) {   // snapshot of the pre-update row for backward
+      float* ro = rows_out + ((long long)b * R + j) * D;
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) ro[k * 64 + lane] = v[u][k];
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float s = wave_sum(acc[u]);
-      if (lane == 0 && j + u < j1) scores[(long long)b * R + j + u] = s * inv_T;
-    }
+    const float s = wave_sum(acc);
+    if (lane == 0 && j < j1) scores[(long long)b * R + j] = s * inv_T;
   }
 }
 

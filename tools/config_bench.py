@@ -23,6 +23,16 @@ def run(name, crit, N):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     print(f"{name}: {dt*1e3:.2f} ms/step  {B/dt:.0f} clips/s  loss {float(loss):.4f}  "
           f"(HBM in use {torch.cuda.memory_allocated()/2**30:.1f} GiB)")
+    from avid_hip import lib
+    m.overlap_towers = False
+    lib.timing_enable(True)
+    for i in range(3): e.step(v, a, ids[i])
+    torch.cuda.synchronize()
+    k = lib.timing_report(); lib.timing_enable(False)
+    for n, x in k.items():
+        if n.startswith(("bank_", "nce_", "alias", "cma_neg")):
+            print(f"    {n:28s} {x['launches']/3:4.1f}/step {x['ms']/x['launches']*1e3:7.1f} us/launch  "
+                  f"{x['bytes']/(x['ms']*1e-3)/1e9:7.1f} GB/s (algorithmic bytes)")
 
 if which in ("cma", "both"):
     N = 240000
