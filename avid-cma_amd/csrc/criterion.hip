@@ -154,23 +154,36 @@ __global__ __launch_bounds__(1024) void bank_scores_bwd_kernel(const float* __re
   float acc[DPL];
 #pragma unroll
   for (int k = 0; k < DPL; ++k) acc[k] = 0.f;
-  for (int j = wave * 4; j < R; j += 64) {
+  // four trips' worth of rows (16 x DPL loads) are issued before the first use; the accumulation order is
+  // the one-trip-at-a-time order (one trip = 4 rows cost a dependent memory round trip each: 16 per block)
+  for (int j = wave * 4; j < R; j += 256) {
+    float v[4][4][DPL], g[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (j + u < R) {
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int jj = j + 64 * t + u;
+        const bool ok = jj < R;
         const float* p;
         if (rows) {
-          p = rows + ((long long)b * R + j + u) * D;
+          p = rows + ((long long)b * R + (ok ? jj : 0)) * D;
         } else {
-          long long row = ib[j + u];
+          long long row = ib[ok ? jj : 0];
           row = row < 0 ? 0 : (row >= N ? N - 1 : row);
           p = bank + row * D;
         }
-        const float g = db[j + u];
+        g[t][u] = ok ? db[jj] : 0.f;
 #pragma unroll
-        for (int k = 0; k < DPL; ++k) acc[k] += g * p[k * 64 + lane];
+        for (int k = 0; k < DPL; ++k) v[t][u][k] = p[k * 64 + lane];
       }
-    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j + 64 * t + u < R) {
+#pragma unroll
+          for (int k = 0; k < DPL; ++k) acc[k] += g[t][u] * v[t][u][k];
+        }
   }
 #pragma unroll
   for (int k = 0; k < DPL; ++k) sh[wave][k * 64 + lane] = acc[k];
