@@ -104,7 +104,8 @@ SIGNATURES = {
     "avid_bank_scores_fwd": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "avid_bank_scores_bwd": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
     "avid_mean_exp": (_i, [_i, _i, _i, _vp, _vp, _vp]),
-    "avid_nce_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _i, _vp, _vp]),
+    "avid_nce_workspace_bytes": (_sz, []),
+    "avid_nce_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _i, _vp, _vp, _sz, _vp]),
     "avid_nce_bwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "avid_bank_update": (_i, [_i, _i, _i64, _vp, _vp, _vp, _f, _vp]),
     "avid_cma_negatives": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

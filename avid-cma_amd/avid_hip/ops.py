@@ -640,6 +640,20 @@ def mean_exp(s):
     return out
 
 
+_NCE_WS = {}
+
+
+def _nce_ws(device):
+    """Per-(device, stream) scratch of avid_nce_fwd: zero-filled once, then the kernel re-arms its own ticket.
+    Keyed by stream as well: two streams must not share the partial sums of a launch in flight."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _NCE_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(int(lib.raw("avid_nce_workspace_bytes")()), dtype=torch.uint8, device=device)
+        _NCE_WS[key] = ws
+    return ws
+
+
 class _NCELoss(Function):
     @staticmethod
     def forward(ctx, spos, sneg, Z):
@@ -651,8 +665,9 @@ class _NCELoss(Function):
         bs, P = spos.shape
         K = sneg.shape[1]
         loss = torch.empty((), dtype=torch.float32, device=spos.device)
+        ws = _nce_ws(spos.device)
         lib.call("avid_nce_fwd", bs, P, K, _p(spos), spos.stride(0), _p(sneg), sneg.stride(0), _p(Z), 1.0, 0,
-                 _p(loss), _stream())
+                 _p(loss), _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(spos, sneg, Z)
         return loss
 

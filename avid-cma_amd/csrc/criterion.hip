@@ -222,28 +222,60 @@ __global__ __launch_bounds__(1024) void mean_exp_kernel(const float* __restrict_
   if (threadIdx.x == 0) out[0] = (float)(t / (double)n);
 }
 
+// One launch, `gridDim.x` blocks (a single 1024-thread block is compute-bound on ONE CU: 25-36 us for the
+// 64 x 1025 exp / log pairs of a step).  Each block leaves its fp64 partial in `partial`, takes a ticket, and
+// the block that draws the last ticket adds the partials in block order (fixed summation order) and writes the
+// loss; it also re-arms the ticket counter, so the scratch needs zeroing only once.
 __global__ __launch_bounds__(1024) void nce_fwd_kernel(const float* __restrict__ spos, const float* __restrict__ sneg,
                                                        const float* __restrict__ Zp, int bs, int P, int K, int ldp,
                                                        int ldn, float scale, int accumulate,
-                                                       float* __restrict__ loss) {
+                                                       float* __restrict__ loss, double* partial, unsigned* ticket) {
   __shared__ double sh[16];
   const float KZ = (float)K * Zp[0];
   double acc = 0;
   const long long nn = (long long)bs * K, np = (long long)bs * P;
-  for (long long i = threadIdx.x; i < nn; i += 1024) {
-    const float e = expf(sneg[(i / K) * ldn + (i % K)]);
-    acc += (double)(-logf(KZ / (e + KZ)));
+  const long long stride = (long long)gridDim.x * 1024, first = (long long)blockIdx.x * 1024 + threadIdx.x;
+  // element i = first + stride * m -> (row, col) kept incrementally (a 64-bit divide + modulo per element is most
+  // of this kernel's instructions otherwise), four independent loads per trip
+  {
+    const int sr = (int)(stride / K), sc = (int)(stride % K);
+    int row = (int)(first / K), col = (int)(first % K);
+    auto next = [&]() {
+      long long o = (long long)row * ldn + col;
+      row += sr; col += sc;
+      if (col >= K) { col -= K; ++row; }
+      return o;
+    };
+    long long i = first;
+    for (; i + 3 * stride < nn; i += 4 * stride) {
+      const long long o0 = next(), o1 = next(), o2 = next(), o3 = next();
+      const float s0 = sneg[o0], s1 = sneg[o1], s2 = sneg[o2], s3 = sneg[o3];
+      acc += (double)(-logf(KZ / (expf(s0) + KZ)));
+      acc += (double)(-logf(KZ / (expf(s1) + KZ)));
+      acc += (double)(-logf(KZ / (expf(s2) + KZ)));
+      acc += (double)(-logf(KZ / (expf(s3) + KZ)));
+    }
+    for (; i < nn; i += stride) acc += (double)(-logf(KZ / (expf(sneg[next()]) + KZ)));
   }
   const double invP = 1.0 / (double)P;
-  for (long long i = threadIdx.x; i < np; i += 1024) {
+  for (long long i = first; i < np; i += stride) {
     const float e = expf(spos[(i / P) * ldp + (i % P)]);
     acc += (double)(-logf(e / (e + KZ))) * invP;
   }
-  const double t = block_sum_d(acc, sh);
-  if (threadIdx.x == 0) {
-    const float v = (float)(t / (double)bs) * scale;
-    loss[0] = accumulate ? loss[0] + v : v;
+  double t = block_sum_d(acc, sh);
+  if (threadIdx.x != 0) return;
+  if (gridDim.x > 1) {
+    __hip_atomic_store(&partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();                                     // the partial is visible device-wide before the ticket
+    if (atomicAdd(ticket, 1u) != gridDim.x - 1) return;
+    __threadfence();
+    t = 0;
+    for (unsigned g = 0; g < gridDim.x; ++g)
+      t += __hip_atomic_load(&partial[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  const float v = (float)(t / (double)bs) * scale;
+  loss[0] = accumulate ? loss[0] + v : v;
 }
 
 __global__ void nce_bwd_kernel(const float* __restrict__ spos, const float* __restrict__ sneg,
@@ -400,12 +432,19 @@ extern "C" int avid_mean_exp(int rows, int cols, int ld, const float* s, float* 
   return check_launch("mean_exp");
 }
 
+extern "C" size_t avid_nce_workspace_bytes(void) { return 8 * 64 + 64; }
+
 extern "C" int avid_nce_fwd(int bs, int P, int K, const float* spos, int ld_pos, const float* sneg, int ld_neg,
-                            const float* Z, float scale, int accumulate, float* loss, avid_stream_t stream) {
+                            const float* Z, float scale, int accumulate, float* loss, void* ws, size_t ws_bytes,
+                            avid_stream_t stream) {
   AVID_REQUIRE(bs > 0 && P > 0 && K > 0 && spos && sneg && Z && loss && ld_pos >= P && ld_neg >= K, AVID_E_BADARG,
                "nce_fwd: bad argument");
-  hipLaunchKernelGGL(nce_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, spos, sneg, Z, bs, P, K, ld_pos,
-                     ld_neg, scale, accumulate, loss);
+  // ws (zero-filled once by the caller, then owned by this op): [64] fp64 partials + the ticket counter
+  const bool multi = ws && ws_bytes >= avid_nce_workspace_bytes() && (long long)bs * K >= 16 * 1024;
+  double* partial = static_cast<double*>(ws);
+  unsigned* ticket = multi ? reinterpret_cast<unsigned*>(partial + 64) : nullptr;
+  hipLaunchKernelGGL(nce_fwd_kernel, dim3(multi ? 16 : 1), dim3(1024), 0, (hipStream_t)stream, spos, sneg, Z, bs, P, K,
+                     ld_pos, ld_neg, scale, accumulate, loss, partial, ticket);
   return check_launch("nce_fwd");
 }
 

@@ -199,8 +199,12 @@ int avid_bank_scores_bwd(int bs, int R, int D, int64_t N, const float* rows, con
  * fwd: loss[0] (+)= scale * mean_b( -mean_p log Pmt - sum_k log Pon ); Z is read from device memory.
  * bwd: dpos [bs][P], dneg [bs][K] (dense) = dloss[0] * scale * dL/ds. */
 int avid_mean_exp(int rows, int cols, int ld, const float* s, float* out, avid_stream_t stream);
+size_t avid_nce_workspace_bytes(void);
+/* ws: optional scratch of avid_nce_workspace_bytes(), ZERO-FILLED ONCE by the caller and then left to this op
+ * (per-block partial sums + a ticket counter the kernel re-arms itself); NULL -> single-block kernel. */
 int avid_nce_fwd(int bs, int P, int K, const float* spos, int ld_pos, const float* sneg, int ld_neg,
-                 const float* Z, float scale, int accumulate, float* loss, avid_stream_t stream);
+                 const float* Z, float scale, int accumulate, float* loss, void* ws, size_t ws_bytes,
+                 avid_stream_t stream);
 int avid_nce_bwd(int bs, int P, int K, const float* spos, int ld_pos, const float* sneg, int ld_neg,
                  const float* Z, const float* dloss, float scale, float* dpos, float* dneg,
                  avid_stream_t stream);

@@ -370,6 +370,28 @@ def test_nce_matches_golden(golden, gpu_device):
         np.testing.assert_allclose(loss3.item(), float(crit(sp.detach(), sn.detach())), rtol=1e-7)
 
 
+def test_nce_multi_block_path(gpu_device):
+    """At the benchmark size (64 x 1024 negatives) avid_nce_fwd runs 16 blocks whose fp64 partials are summed by
+    the last block to finish (device-side ticket, re-armed by the kernel).  vs the oracle's formula in float64;
+    repeated calls (ticket re-arm) are bit-identical; P = 32 positives and a ragged K take the same path."""
+    from avid_hip import ops
+    for bs, Pn, K in ((64, 1, 1024), (64, 32, 1000), (48, 32, 1024)):
+        gen = torch.Generator().manual_seed(bs + Pn + K)
+        sp = (torch.rand(bs, Pn, generator=gen) * 16 - 8)
+        sn = (torch.rand(bs, K, generator=gen) * 16 - 8)
+        Z = torch.tensor(0.37)
+        want, _ = O.nce_loss(sp.double(), sn.double(), Z.double())
+        spd, snd, Zd = sp.to(gpu_device).requires_grad_(True), sn.to(gpu_device).requires_grad_(True), Z.to(gpu_device)
+        losses = [ops.nce_loss(spd, snd, Zd) for _ in range(5)]
+        np.testing.assert_allclose(losses[0].item(), float(want), rtol=2e-6)
+        assert all(torch.equal(l, losses[0]) for l in losses[1:])
+        losses[-1].backward()
+        spr, snr = sp.double().requires_grad_(True), sn.double().requires_grad_(True)
+        O.nce_loss(spr, snr, Z.double())[0].backward()
+        np.testing.assert_allclose(spd.grad.cpu().numpy(), spr.grad.float().numpy(), rtol=2e-5, atol=1e-9)
+        np.testing.assert_allclose(snd.grad.cpu().numpy(), snr.grad.float().numpy(), rtol=2e-5, atol=1e-9)
+
+
 def test_bank_update(gpu_device):
     from avid_hip import ops
     N, B = 3000, 40
