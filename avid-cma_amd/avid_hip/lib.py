@@ -84,7 +84,7 @@ SIGNATURES = {
     "avid_bn_fwd_eval": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
     "avid_bn_bwd": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_bn_relu_maxpool_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                      _vp, _sz, _vp]),
+                                      _vp, _i, _vp, _sz, _vp]),
     "avid_bn_relu_maxpool_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                       _vp]),
     "avid_logspec_basis_floats": (_sz, [_i]),

@@ -434,10 +434,11 @@ class _BnReluMaxPool(Function):
     """maxpool_hw3s2(relu(bn_train(x))) in one pass over x (the video stem's tail, models/video.py:21-23)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, stats, momentum, eps, counter):
+    def forward(ctx, x, gamma, beta, stats, momentum, eps, counter, partials=None):
         _need_cuda(x, gamma, beta)
         if not x.is_contiguous():
             raise AvidHipError("bn_relu_maxpool: x must be contiguous channels-last")
+        nparts = 0 if partials is None or partials.numel() == 0 else partials.shape[0]
         B, T, H, W, Cc = x.shape
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         rm, rv = stats
@@ -447,7 +448,7 @@ class _BnReluMaxPool(Function):
         ws = workspace(x.device, _bn_ws_bytes(B * T * H * W, Cc))
         lib.call("avid_bn_relu_maxpool_fwd", B, T, H, W, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv),
                  float(momentum), float(eps), _p(y), _p(am), _p(stats4[0]), _p(stats4[1]), _p(stats4[2]), _p(stats4[3]),
-                 _p(counter), _p(ws), ws.numel(), _stream())
+                 _p(counter), _p(partials) if nparts else None, nparts, _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(x, gamma, stats4, am)
         ctx.beta_ptr = beta.data_ptr()
         return y
@@ -469,13 +470,16 @@ class _BnReluMaxPool(Function):
         if sb is not None:
             _grad_done(sb)
             dbeta = None
-        return dx, dgamma, dbeta, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None
 
 
-def bn_relu_maxpool(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, num_batches_tracked=None):
+def bn_relu_maxpool(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, num_batches_tracked=None,
+                    partials=None):
     """Training-mode BatchNorm + ReLU + MaxPool (1,3,3)/(1,2,2)/(0,1,1) fused (the normalised activation is
-    never written; backward rebuilds the un-pooled gradient from the argmax slots)."""
-    return _BnReluMaxPool.apply(x, gamma, beta, (running_mean, running_var), momentum, eps, num_batches_tracked)
+    never written; backward rebuilds the un-pooled gradient from the argmax slots).  ``partials``: the BatchNorm
+    partial sums the stem convolution produced with its output (conv_cl(..., bn_stats=True))."""
+    return _BnReluMaxPool.apply(x, gamma, beta, (running_mean, running_var), momentum, eps, num_batches_tracked,
+                                partials)
 
 
 # ------------------------------------------------------------------------------------------------

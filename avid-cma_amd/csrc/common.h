@@ -51,7 +51,8 @@ bool stem_fwd_supported(const avid_conv_desc* d);
 bool stem_wgrad_supported(const avid_conv_desc* d);
 size_t stem_fwd_ws_bytes(const avid_conv_desc* d);
 size_t stem_wgrad_ws_bytes(const avid_conv_desc* d);
-int stem_fwd(const avid_conv_desc* d, const float* x, const float* w, float* y, void* ws, hipStream_t s);
+int stem_fwd(const avid_conv_desc* d, const float* x, const float* w, float* y, float* stats, void* ws, hipStream_t s);
+int stem_fwd_grid(const avid_conv_desc* d);
 int stem_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, hipStream_t s);
 
 // 64-lane wave reductions (DPP/ds_swizzle chosen by the compiler from __shfl_xor).

@@ -2084,7 +2084,8 @@ extern "C" size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d) {
 extern "C" int avid_conv_fwd_stats_rows(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
-  if (!vec || !pk_enabled() || d->Cout > 1024 || (256 % (d->Cout / 4)) != 0) return 0;
+  if (!vec) return stem_fwd_supported(d) ? stem_fwd_grid(d) : 0;     // LDS-patch stems: one row per workgroup
+  if (!pk_enabled() || d->Cout > 1024 || (256 % (d->Cout / 4)) != 0) return 0;
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
   const PkPlan pk = plan_pk(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK));
   return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cout)) : 0);
@@ -2097,7 +2098,7 @@ extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const floa
   if (rc) return rc;
   AVID_REQUIRE(x && w && y, AVID_E_BADARG, "conv_fwd: null pointer");
   if (stem_fwd_supported(d) && !addend && !bias && !relu && ws && ws_bytes >= stem_fwd_ws_bytes(d))
-    return stem_fwd(d, x, w, y, ws, (hipStream_t)stream);
+    return stem_fwd(d, x, w, y, bn_partials, ws, (hipStream_t)stream);
   ConvArgs a;
   fill_common(a, d);
   a.src = x; a.wk = w; a.addend = addend; a.bias = bias; a.dst = y;
@@ -2109,6 +2110,7 @@ extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const floa
   fill_src_strides(d, a.ssB, a.ssT, a.ssH, a.ssW, a.ssC);
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
   if (bn_partials) {
+    AVID_REQUIRE(vec, AVID_E_BADARG, "conv_fwd: BatchNorm partials of a stem need its workspace (and no addend / bias / ReLU)");
     AVID_REQUIRE(!bias && !relu && avid_conv_fwd_stats_rows(d) > 0, AVID_E_UNSUPPORTED,
                  "conv_fwd: BatchNorm partials need the persistent kernel, no bias and no ReLU");
     a.stats = bn_partials;

@@ -806,8 +806,9 @@ extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, co
 extern "C" int avid_bn_relu_maxpool_fwd(int B, int T, int H, int W, int C, const float* x, const float* gamma,
                                         const float* beta, float* running_mean, float* running_var, float momentum,
                                         float eps, float* y, uint8_t* argmax, float* save_mean, float* save_invstd,
-                                        float* save_scale, float* save_shift, int64_t* num_batches_tracked, void* ws,
-                                        size_t ws_bytes, avid_stream_t stream) {
+                                        float* save_scale, float* save_shift, int64_t* num_batches_tracked,
+                                        const float* partials, int nparts, void* ws, size_t ws_bytes,
+                                        avid_stream_t stream) {
   const int64_t M = (int64_t)B * T * H * W;
   int rc = bn_check(M, C, "bn_relu_maxpool_fwd");
   if (rc) return rc;
@@ -817,13 +818,17 @@ extern "C" int avid_bn_relu_maxpool_fwd(int B, int T, int H, int W, int C, const
   AVID_REQUIRE(ws_bytes >= avid_bn_workspace_bytes(M, C), AVID_E_BADARG, "bn_relu_maxpool_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   BnPlan p = bn_plan(M, C);
-  float* part = static_cast<float*>(ws);
-  {
+  const float* part = static_cast<float*>(ws);
+  int nblk = p.nblk;
+  if (partials && nparts > 0) {   // statistics already reduced to partial rows by the producing convolution
+    part = partials;
+    nblk = nparts;
+  } else {
     ScopedTimer t(s, "bn_stats_partial_kernel", 0.0, 4.0 * M * C);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
-                       p.rows_per_pass, p.rows_per_block);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, static_cast<float*>(ws), (long long)M,
+                       C, p.G, p.rows_per_pass, p.rows_per_block);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, p.nblk,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, nblk,
                      (long long)M, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
                      save_scale, save_shift, reinterpret_cast<long long*>(num_batches_tracked));
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;

@@ -22,6 +22,7 @@ struct StemArgs {
   const float* __restrict__ w;    // [64][kt][7][7][CIN]  (for wgrad / repack)
   const float* __restrict__ dy;   // wgrad: [B][To][Ho][Wo][64]
   float* __restrict__ part;       // wgrad partials [G][64][R*8]
+  float* __restrict__ stats;      // forward: BatchNorm partial sums of y, one row [2][64] per workgroup, or null
   int B, Ti, Hi, Wi, Ho, Wo;
   int PW, rows_in_max, tiles_per_frame;
   int tile_px;                    // wgrad: output pixels per tile (whole rows when a row fits, <= STEM_TILE)
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const S
   int tile = blockIdx.x;
   if (tile >= p.ntiles) return;
   int u = 0;                                  // LDS stage of the weight chunk about to be multiplied
+  float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};   // this lane's running column sums / sums of squares of y
   load_w(0);
   prefetch(geo(tile));
   store_w(0);
@@ -234,8 +236,33 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const S
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (p0 + wave * 32 + rr < p1) p.y[(m_base + rr) * 64 + j * 32 + l31] = acc[j][r];
+        if (p0 + wave * 32 + rr < p1) {
+          const float v = acc[j][r];
+          p.y[(m_base + rr) * 64 + j * 32 + l31] = v;
+          cs[j] += v;                       // BatchNorm statistics of the output ride along (p.stats)
+          cq[j] = fmaf(v, v, cq[j]);
+        }
       }
+  }
+  if (p.stats) {   // one partial row [2][64] per workgroup: fold the half-waves, then the waves in fixed order
+    float* red = smem;                      // [2][WAVES][64]; the weight stages are dead
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a = cs[j] + __shfl_xor(cs[j], 32, 64), b = cq[j] + __shfl_xor(cq[j], 32, 64);
+      if (h == 0) {
+        red[wave * 64 + j * 32 + l31] = a;
+        red[WAVES * 64 + wave * 64 + j * 32 + l31] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid & 63, q = tid >> 6;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) t += red[q * WAVES * 64 + w * 64 + c];
+      p.stats[(long long)blockIdx.x * 128 + q * 64 + c] = t;
+    }
   }
 }
 
@@ -516,10 +543,11 @@ size_t stem_wgrad_ws_bytes(const avid_conv_desc* d) {
 }
 
 template <int CIN, int KT, int WAVES>
-static int stem_fwd_launch(const avid_conv_desc* d, const float* x, const float* w, float* y, void* ws, hipStream_t s) {
+static int stem_fwd_launch(const avid_conv_desc* d, const float* x, const float* w, float* y, float* stats, void* ws,
+                           hipStream_t s) {
   StemArgs a{};
   stem_geometry(d, a, WAVES * 32);
-  a.x = x; a.w = w; a.y = y; a.wt = static_cast<float*>(ws);
+  a.x = x; a.w = w; a.y = y; a.wt = static_cast<float*>(ws); a.stats = stats;
   constexpr int R = CIN * KT * 7;
   hipLaunchKernelGGL((stem_repack_kernel<CIN, KT>), dim3((R * 8 * 64 + 255) / 256), dim3(256), 0, s, w,
                      static_cast<float*>(ws));
@@ -568,10 +596,20 @@ static int stem_wgrad_launch(const avid_conv_desc* d, const float* x, const floa
   return check_launch("stem_wgrad_reduce");
 }
 
-int stem_fwd(const avid_conv_desc* d, const float* x, const float* w, float* y, void* ws, hipStream_t s) {
+// workgroups of the forward launch == rows of its BatchNorm partial sums
+int stem_fwd_grid(const avid_conv_desc* d) {
+  const int tile = stem_fwd_tile(d);
+  if (!tile) return 0;
+  StemArgs a{};
+  stem_geometry(d, a, tile);
+  const int slots = tile == 128 ? 512 : 256;
+  return a.ntiles < slots ? a.ntiles : slots;
+}
+
+int stem_fwd(const avid_conv_desc* d, const float* x, const float* w, float* y, float* stats, void* ws, hipStream_t s) {
   if (stem_fwd_tile(d) == 128)
-    return d->Cin == 3 ? stem_fwd_launch<3, 3, 4>(d, x, w, y, ws, s) : stem_fwd_launch<1, 1, 4>(d, x, w, y, ws, s);
-  return d->Cin == 3 ? stem_fwd_launch<3, 3, 8>(d, x, w, y, ws, s) : stem_fwd_launch<1, 1, 8>(d, x, w, y, ws, s);
+    return d->Cin == 3 ? stem_fwd_launch<3, 3, 4>(d, x, w, y, stats, ws, s) : stem_fwd_launch<1, 1, 4>(d, x, w, y, stats, ws, s);
+  return d->Cin == 3 ? stem_fwd_launch<3, 3, 8>(d, x, w, y, stats, ws, s) : stem_fwd_launch<1, 1, 8>(d, x, w, y, stats, ws, s);
 }
 int stem_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, hipStream_t s) {
   return d->Cin == 3 ? stem_wgrad_launch<3, 3>(d, x, dy, dw, ws, s) : stem_wgrad_launch<1, 1>(d, x, dy, dw, ws, s);

@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from avid_hip import ops
-from .network_blocks import Basic2DBlock, BatchNormCL, ConvCL
+from .network_blocks import Basic2DBlock, BatchNormCL, ConvCL, _conv_bn
 
 __all__ = ["Conv2D"]
 
@@ -32,7 +32,7 @@ class Conv2D(nn.Module):
 
     def forward(self, x, return_embs=False):
         x5 = x.contiguous().unsqueeze(2)            # [B,1,1,H,W]: 2-D conv == 3-D conv with T = kt = 1
-        x_c1 = self.conv1[1](self.conv1[0](x5), relu=True)
+        x_c1 = _conv_bn(self.conv1[0], self.conv1[1], x5)   # stem conv + BN(+ReLU), statistics from the conv epilogue
         x_b1 = self.block1(x_c1)
         x_b2 = self.block2(x_b1)
         x_b3 = self.block3(x_b2)

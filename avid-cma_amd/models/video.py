@@ -7,6 +7,14 @@ from .network_blocks import BasicR2P1DBlock, BatchNormCL, ConvCL, MaxPoolHW3S2
 
 _FUSE_STEM_TAIL = os.environ.get("AVID_FUSE_STEM_TAIL", "1") == "1"
 
+
+def _stem_conv(conv, x):
+    """Stem convolution + (when the layer can) the BatchNorm partial sums of its output from the epilogue."""
+    from .network_blocks import _FUSE_BN_STATS
+    if not _FUSE_BN_STATS:
+        return conv(x), None
+    return conv(x, bn_stats=True)
+
 __all__ = ["R2Plus1D"]
 
 _STAGES = {10: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
@@ -48,8 +56,10 @@ class R2Plus1D(nn.Module):
         conv, bn = self.conv1[0], self.conv1[1]
         if self.training and x.is_cuda and _FUSE_STEM_TAIL:
             # BN + ReLU + max-pool in one pass over the 411 MB stem activation (bs 64)
-            x_c1 = ops.bn_relu_maxpool(conv(x.contiguous()), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                       bn.momentum, bn.eps, bn.num_batches_tracked)
+            # (its batch statistics come out of the stem convolution's epilogue when the layer can: _FUSE_BN_STATS)
+            y, part = _stem_conv(conv, x.contiguous())
+            x_c1 = ops.bn_relu_maxpool(y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       bn.momentum, bn.eps, bn.num_batches_tracked, partials=part)
         else:
             x_c1 = self.conv1[3](bn(conv(x.contiguous()), relu=True))
         x_b1 = self.conv2x(x_c1)

@@ -136,12 +136,13 @@ int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, const float* 
  * ---------------------------------------------------------------------------------------------- */
 /* Stem tail fused (models/video.py:21-23): y = maxpool(relu(bn_train(x))) with x [B,T,H,W,C] the stem conv
  * output, y / argmax [B,T,Ho,Wo,C]; the normalised activation is never materialised.  Backward rebuilds the
- * un-pooled gradient from (dy, argmax) on the fly.  Same saved tensors / workspace as avid_bn_fwd_train. */
+ * un-pooled gradient from (dy, argmax) on the fly.  Same saved tensors / workspace / `partials` (the stem
+ * convolution's own BatchNorm partial sums, avid_conv_fwd) as avid_bn_fwd_train. */
 int avid_bn_relu_maxpool_fwd(int B, int T, int H, int W, int C, const float* x, const float* gamma,
                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                              float* y, uint8_t* argmax, float* save_mean, float* save_invstd, float* save_scale,
-                             float* save_shift, int64_t* num_batches_tracked, void* ws, size_t ws_bytes,
-                             avid_stream_t stream);
+                             float* save_shift, int64_t* num_batches_tracked, const float* partials, int nparts,
+                             void* ws, size_t ws_bytes, avid_stream_t stream);
 int avid_bn_relu_maxpool_bwd(int B, int T, int H, int W, int C, const float* x, const float* dy,
                              const uint8_t* argmax, const float* gamma, const float* save_mean,
                              const float* save_invstd, const float* save_scale, const float* save_shift, float* dx,

@@ -121,7 +121,7 @@ def test_conv_transpose_detecting(gpu_device):
 
 @pytest.mark.parametrize("which", ["video", "audio"])
 def test_stem_conv(which, gpu_device):
-    """The two stems read the reference's channel-first input directly (gather path)."""
+    """The two stems read the reference's channel-first input directly (LDS-patch kernels, csrc/stem.hip)."""
     from avid_hip import ops
     if which == "video":
         cin, k, stride, pad, shp = 3, (3, 7, 7), (1, 2, 2), (1, 3, 3), (2, 3, 4, 20, 26)
@@ -140,6 +140,29 @@ def test_stem_conv(which, gpu_device):
     y.backward(cl(gy).to(gpu_device))
     assert relerr(ncdhw(y.detach()), yr.detach()) < 2e-5
     assert relerr(wd.grad, wr.grad) < 5e-5
+
+
+@pytest.mark.parametrize("which", ["video", "audio", "video_ragged"])
+def test_stem_bn_partials(which, gpu_device):
+    """BatchNorm partial sums from the LDS-patch stem kernel's epilogue (one row per workgroup; the pixels past a
+    ragged last tile are masked): column totals == column sums / sums of squares of the output, output unchanged."""
+    from avid_hip import ops
+    if which == "audio":
+        cin, k, stride, pad, shp = 1, (1, 7, 7), (1, 2, 2), (0, 3, 3), (3, 1, 1, 40, 100)
+    else:
+        cin, k, stride, pad = 3, (3, 7, 7), (1, 2, 2), (1, 3, 3)
+        shp = (2, 3, 4, 24, 28) if which == "video" else (5, 3, 2, 38, 44)     # 19 x 22 = 418 pixels: ragged tiles
+    x = T(detgen.det_normalish(f"stembn:{which}:x", shp)).to(gpu_device)
+    wd = ops.make_weight(64, cin, *k)
+    wd.copy_(T(detgen.det_param(f"stembn:{which}:w.weight", (64, cin) + k)))
+    wd = wd.to(gpu_device)
+    y = ops.conv_cl(x, wd, stride, pad, channel_first=True)
+    y2, part = ops.conv_cl(x, wd, stride, pad, channel_first=True, bn_stats=True)
+    assert torch.equal(y2, y)
+    assert part.dim() == 3 and part.shape[1:] == (2, 64) and part.shape[0] >= 1
+    yd = y2.double().reshape(-1, 64)
+    assert relerr(part[:, 0].double().sum(0), yd.sum(0)) < 1e-5 * max(1.0, float(yd.abs().sum(0).max() / (yd.sum(0).abs().max() + 1e-30)))
+    assert relerr(part[:, 1].double().sum(0), (yd * yd).sum(0)) < 1e-5
 
 
 def test_conv_fused_addend(gpu_device):
