@@ -29,6 +29,12 @@ LIB_PATH = os.path.join(_HERE, "libavid_hip.so")
 AVID_OK = 0
 
 
+class BnBwdFuse(C.Structure):
+    """Mirror of ``avid_bn_bwd_fuse`` (include/avid_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p),
+                ("invstd", C.c_void_p), ("relu", C.c_int32), ("partials", C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     """Mirror of ``avid_conv_desc`` (include/avid_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
@@ -74,7 +80,8 @@ SIGNATURES = {
     "avid_conv_fwd_stats_rows": (_i, [_dp]),
     "avid_conv_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "avid_conv_dgrad_workspace_bytes": (_sz, [_dp]),
-    "avid_conv_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avid_conv_dgrad_bn_rows": (_i, [_dp]),
+    "avid_conv_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_weight_transpose_batched": (_i, [_i, _vp, _i64, _vp]),
     "avid_conv_wgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_wgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -82,7 +89,7 @@ SIGNATURES = {
     "avid_bn_workspace_bytes": (_sz, [_i64, _i]),
     "avid_bn_fwd_train": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "avid_bn_fwd_eval": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
-    "avid_bn_bwd": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avid_bn_bwd": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "avid_bn_relu_maxpool_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _i, _vp, _sz, _vp]),
     "avid_bn_relu_maxpool_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,

@@ -11,6 +11,7 @@ memory as ``[Cout][kt][kh][kw][Cin]`` (torch ``channels_last_3d``); see ``make_w
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 from torch.autograd import Function
@@ -84,7 +85,8 @@ _BN_WS_CACHE = {}
 
 
 def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
-    """(ConvDesc, fwd_ws_bytes, dgrad_ws_bytes, wgrad_ws_bytes, bn_partial_rows) — once per distinct layer geometry."""
+    """(ConvDesc, fwd_ws_bytes, dgrad_ws_bytes, wgrad_ws_bytes, bn_partial_rows) — once per distinct layer geometry.
+    (``d.bn_bwd_rows``: rows of BatchNorm-backward partials its dgrad can write, 0 = cannot.)"""
     key = (xs, cin, cout, k, stride, pad, channel_first)
     hit = _DESC_CACHE.get(key)
     if hit is None:
@@ -93,6 +95,7 @@ def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
                0 if channel_first else lib.raw("avid_conv_dgrad_workspace_bytes")(C.byref(d)),
                lib.raw("avid_conv_wgrad_workspace_bytes")(C.byref(d)),
                lib.raw("avid_conv_fwd_stats_rows")(C.byref(d)))
+        d.bn_bwd_rows = 0 if channel_first else lib.raw("avid_conv_dgrad_bn_rows")(C.byref(d))
         _DESC_CACHE[key] = hit
     return hit
 
@@ -238,12 +241,27 @@ def _wt_for(w):
     return _TRANSPOSED.map.get(w.data_ptr())
 
 
+FUSE_BN_BWD = os.environ.get("AVID_FUSE_BN_BWD", "1") == "1"
+
+
+class BnSource:
+    """Hand-over between a training-mode BatchNorm(+ReLU) and the convolution that is the SOLE consumer of its
+    output: the conv's input-gradient kernel then also produces the BatchNorm's backward partial sums (while the
+    gradient is in registers) and leaves them here; the BatchNorm's backward, which autograd runs next, takes
+    them instead of making its own pass over dy and x.  One object per forward call."""
+    __slots__ = ("x", "stats4", "relu", "partials")
+
+    def __init__(self, x, stats4, relu):
+        self.x, self.stats4, self.relu, self.partials = x, stats4, relu, None
+
+
 class _ConvCL(Function):
     """y = conv(x, w) [+ addend] [+ bias] [relu]  — avid_conv_fwd / avid_conv_dgrad / avid_conv_wgrad."""
 
     @staticmethod
-    def forward(ctx, x, w, addend, bias, stride, pad, relu, channel_first, want_stats=False, tap=False):
+    def forward(ctx, x, w, addend, bias, stride, pad, relu, channel_first, want_stats=False, tap=False, bn_src=None):
         _need_cuda(x, w, addend, bias)
+        ctx.bn_src = bn_src
         if not x.is_contiguous():
             raise AvidHipError("conv: x must be contiguous (channels-last [B,T,H,W,C])")
         if not weight_layout_ok(w):
@@ -294,7 +312,7 @@ class _ConvCL(Function):
         d = ctx.d
         d_tap = more[-1] if (ctx.tap and more) else None
         if dy is None:                     # only the tap carried a gradient
-            return d_tap, None, None, None, None, None, None, None, None, None
+            return d_tap, None, None, None, None, None, None, None, None, None, None
         dy = dy.contiguous()
         if d_tap is not None:
             d_tap = d_tap.contiguous()
@@ -330,7 +348,16 @@ class _ConvCL(Function):
         if need_dx:
             ws = workspace(x.device, ctx.nb_dgrad)
             dx = torch.empty_like(x)
-            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_wt_for(w)), _p(d_tap), _p(dx), _p(ws), ws.numel(), st)
+            fuse = None
+            src = ctx.bn_src
+            if src is not None and FUSE_BN_BWD and d.bn_bwd_rows > 0 and src.x.shape == x.shape:
+                # dx is the whole gradient of the BatchNorm output x: its backward partial sums ride along
+                src.partials = torch.empty((d.bn_bwd_rows, 2, d.Cin), dtype=torch.float32, device=x.device)
+                s4 = src.stats4
+                fuse = lib.BnBwdFuse(_p(src.x), _p(s4[2]), _p(s4[3]), _p(s4[0]), _p(s4[1]), int(src.relu),
+                                     _p(src.partials))
+            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_wt_for(w)), _p(d_tap), _p(dx),
+                     C.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), st)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
@@ -349,17 +376,19 @@ class _ConvCL(Function):
                 dbias = None
         if d_tap is not None and not need_dx:
             dx = d_tap
-        return dx, dw, dadd, dbias, None, None, None, None, None, None
+        return dx, dw, dadd, dbias, None, None, None, None, None, None, None
 
 
 def conv_cl(x, w, stride=(1, 1, 1), pad=(0, 0, 0), addend=None, bias=None, relu=False, channel_first=False,
-            bn_stats=False, tap=False):
+            bn_stats=False, tap=False, bn_src=None):
     """``bn_stats=True`` adds ``partials`` to the result: y's BatchNorm partial sums from the conv epilogue (pass
     them to ``batch_norm_cl``), or an empty tensor when the layer cannot produce them.  ``tap=True`` adds an
-    alias of ``x`` for a second consumer whose gradient is then summed inside this op's dgrad kernel."""
-    if bn_stats or tap:
+    alias of ``x`` for a second consumer whose gradient is then summed inside this op's dgrad kernel.
+    ``bn_src`` (a ``BnSource``): x is the output of that BatchNorm and this conv (with its tap, if any) is the
+    only consumer — the BatchNorm's backward partial sums are then produced by this op's dgrad kernel."""
+    if bn_stats or tap or bn_src is not None:
         return _ConvCL.apply(x, w, addend, bias, tuple(stride), tuple(pad), bool(relu), bool(channel_first),
-                             bool(bn_stats), bool(tap))
+                             bool(bn_stats), bool(tap), bn_src)
     return _ConvCL.apply(x, w, addend, bias, tuple(stride), tuple(pad), bool(relu), bool(channel_first))
 
 
@@ -375,8 +404,9 @@ def linear(x, w, bias=None, relu=False):
 # ------------------------------------------------------------------------------------------------
 class _BatchNormCL(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, stats, training, momentum, eps, relu, counter=None, partials=None):
+    def forward(ctx, x, gamma, beta, stats, training, momentum, eps, relu, counter=None, partials=None, src=None):
         _need_cuda(x, gamma, beta)
+        ctx.src = src
         if not x.is_contiguous():
             raise AvidHipError("bn: x must be contiguous channels-last")
         Cc = x.shape[-1]
@@ -392,6 +422,8 @@ class _BatchNormCL(Function):
                      _p(counter), _p(partials), 0 if partials is None else partials.shape[0], _p(ws), ws.numel(), st)
             ctx.save_for_backward(x, gamma, stats4)
             ctx.beta_ptr = beta.data_ptr()
+            if src is not None:
+                src.x, src.stats4, src.relu = x, stats4, relu
         else:
             lib.call("avid_bn_fwd_eval", M, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv), float(eps), int(relu),
                      _p(y), st)
@@ -409,25 +441,29 @@ class _BatchNormCL(Function):
         dgamma, sg = _grad_dst(gamma.data_ptr(), shape=(ctx.C,), device=x.device)
         dbeta, sb = _grad_dst(ctx.beta_ptr, shape=(ctx.C,), device=x.device)
         ws = workspace(x.device, _bn_ws_bytes(ctx.M, ctx.C))
+        part = None
+        if ctx.src is not None:           # left by the dgrad kernel that produced dy (see BnSource)
+            part, ctx.src.partials = ctx.src.partials, None
         lib.call("avid_bn_bwd", ctx.M, ctx.C, _p(x), _p(dy), _p(gamma), _p(stats4[0]), _p(stats4[1]), _p(stats4[2]),
-                 _p(stats4[3]), int(ctx.relu), _p(dx), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream())
+                 _p(stats4[3]), int(ctx.relu), _p(dx), _p(dgamma), _p(dbeta), _p(part),
+                 0 if part is None else part.shape[0], _p(ws), ws.numel(), _stream())
         if sg is not None:
             _grad_done(sg)
             dgamma = None
         if sb is not None:
             _grad_done(sb)
             dbeta = None
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def batch_norm_cl(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False,
-                  num_batches_tracked=None, partials=None):
+                  num_batches_tracked=None, partials=None, src=None):
     """``num_batches_tracked`` (0-d int64 device tensor or None) is bumped by the kernel in training mode;
     ``partials``: x's partial sums from ``conv_cl(..., bn_stats=True)`` (skips the statistics pass)."""
     if partials is not None and (partials.numel() == 0 or not training):
         partials = None
     return _BatchNormCL.apply(x, gamma, beta, (running_mean, running_var), bool(training), momentum, eps, bool(relu),
-                              num_batches_tracked, partials)
+                              num_batches_tracked, partials, src if training else None)
 
 
 class _BnReluMaxPool(Function):

@@ -66,6 +66,11 @@ struct ConvArgs {
   unsigned cls_mg[8][3];   // igemm_pk_kernel<STRIDED>: multiply-shift division by a class's (T,H,W) extents
   int cls_shf[8][3];
   float* stats;    // BatchNorm partial sums [rows][2][Cd] of the output (igemm_pk_kernel forward), or null
+  // dgrad whose output is the gradient of a BatchNorm(+ReLU) output: the BN's backward partial sums
+  // (sum dy_m, sum dy_m * xhat; dy_m = dy masked by the recomputed ReLU) go to `stats` from the epilogue
+  const float* bnb_x;        // the BN's input (this dgrad's dx has its shape), or null
+  const float *bnb_scale, *bnb_shift, *bnb_mean, *bnb_invstd;
+  int bnb_relu;
   int pk_rot;      // tail unit u runs on workgroup (u + pk_rot) mod G: the ones that got one full tile less
   int pk_paired;   // grid = 2 workgroups per CU: number them so that v and v + G/2 share a CU
 };
@@ -824,9 +829,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
         (void*)(direct ? p.dst + d_base : p.part + s_base), 0, rows * row_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.addend ? p.addend + d_base : p.dst + d_base), 0, rows * row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsXb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.bnb_x ? p.bnb_x + d_base : p.dst + d_base), 0, rows * row_bytes, 0x00020000);
     // The uniform cases are told apart once per tile, not per element: the element loops below are straight
     // lines of (load,) VALU, store.
-    auto emit = [&](auto DIRECT, auto HAS_ADD, auto RELU, auto OP) {   // OP: addend combines by 0 add, 1 min, 2 max
+    auto emit = [&](auto DIRECT, auto HAS_ADD, auto RELU, auto OP, auto BNB) {   // OP: addend combines by 0 add, 1 min, 2 max
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -841,6 +848,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
                                                     rsE, voff, ((r & 3) + 8 * (r >> 2)) * row_bytes, 0));
           }
           const float bv = (DIRECT && p.bias) ? p.bias[col] : 0.f;
+          float xb[16], bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
+          if (BNB) {   // the BatchNorm input at the positions of this tile + this column's saved coefficients
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              xb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                    rsXb, voff, ((r & 3) + 8 * (r >> 2)) * row_bytes, 0));
+            bsc = p.bnb_scale[col]; bsh = p.bnb_shift[col]; bmu = p.bnb_mean[col]; bis = p.bnb_invstd[col];
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int soff = ((r & 3) + 8 * (r >> 2)) * row_bytes;
@@ -850,6 +865,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
               if (HAS_ADD) v = decltype(OP)::value == 0 ? v + ad[r] : (decltype(OP)::value == 1 ? fminf(v, ad[r]) : fmaxf(v, ad[r]));
               if (RELU) v = fmaxf(v, 0.f);
               if (MODE == 0) { cs[jj] += v; cq[jj] = fmaf(v, v, cq[jj]); }   // rows past M are exact zeros
+              if (BNB) {       // bn_bwd_partial_kernel's sums, from the gradient while it is in registers
+                const float dm = (!p.bnb_relu || fmaf(xb[r], bsc, bsh) > 0.f) ? v : 0.f;
+                cs[jj] += dm;
+                cq[jj] = fmaf(dm, (xb[r] - bmu) * bis, cq[jj]);
+              }
             }
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff, soff, 0);
           }
@@ -859,14 +879,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     constexpr std::true_type Y{};
     constexpr std::false_type N{};
     constexpr std::integral_constant<int, 0> ADD{};
-    if (!direct) emit(N, N, N, ADD);
-    else if (p.addend) {
-      if (MODE == 0 && p.epi_op == 1) emit(Y, Y, N, std::integral_constant<int, 1>{});        // CMA agreement scores
-      else if (MODE == 0 && p.epi_op == 2) emit(Y, Y, N, std::integral_constant<int, 2>{});
-      else if (p.relu) emit(Y, Y, Y, ADD);
-      else emit(Y, Y, N, ADD);
+    if (!direct) emit(N, N, N, ADD, N);
+    else if (MODE == 1 && p.bnb_x) {
+      if (p.addend) emit(Y, Y, N, ADD, Y); else emit(Y, N, N, ADD, Y);
+    } else if (p.addend) {
+      if (MODE == 0 && p.epi_op == 1) emit(Y, Y, N, std::integral_constant<int, 1>{}, N);        // CMA agreement scores
+      else if (MODE == 0 && p.epi_op == 2) emit(Y, Y, N, std::integral_constant<int, 2>{}, N);
+      else if (p.relu) emit(Y, Y, Y, ADD, N);
+      else emit(Y, Y, N, ADD, N);
     } else {
-      if (p.relu) emit(Y, N, Y, ADD); else emit(Y, N, N, ADD);
+      if (p.relu) emit(Y, N, Y, ADD, N); else emit(Y, N, N, ADD, N);
     }
   }
   write_stats();
@@ -913,6 +935,57 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
     reinterpret_cast<floatx4*>(dst)[i] = v;
     s += v;
     q += v * v;
+  }
+  sh[0][tid] = s;
+  sh[1][tid] = q;
+  __syncthreads();
+  if (r == 0) {
+    for (int k = 1; k < rpp; ++k) {
+      s += sh[0][k * G + g];
+      q += sh[1][k * G + g];
+    }
+    float* o = stats + (long long)blockIdx.x * 2 * C;
+    *reinterpret_cast<floatx4*>(o + g * 4) = s;
+    *reinterpret_cast<floatx4*>(o + C + g * 4) = q;
+  }
+}
+
+// splitk_reduce_kernel for a dgrad whose output is the gradient of a BatchNorm(+ReLU) output: dst = sum_s part[s]
+// (+ addend), and the BN backward's partial sums of the rows this block wrote (sum dy_m, sum dy_m * xhat with
+// dy_m the gradient masked by the recomputed ReLU) go to one partial row [2][C] — bn_bwd_partial_kernel's output
+// without its pass over dy and x.  Same block shape as splitk_reduce_stats_kernel.
+__global__ __launch_bounds__(256) void splitk_reduce_bnb_kernel(const float* __restrict__ part, float* __restrict__ dst,
+                                                                const float* __restrict__ addend, long long rows, int C,
+                                                                int nsplit, int rows_per_block,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int relu,
+                                                                float* __restrict__ stats) {
+  __shared__ floatx4 sh[2][256];
+  const int G = C >> 2, tid = threadIdx.x;
+  const int g = tid % G, r = tid / G, rpp = 256 / G;
+  const long long n4 = rows * G;
+  const long long row0 = (long long)blockIdx.x * rows_per_block;
+  const floatx4 sc = reinterpret_cast<const floatx4*>(scale)[g], sf = reinterpret_cast<const floatx4*>(shift)[g];
+  const floatx4 mu = reinterpret_cast<const floatx4*>(mean)[g], is = reinterpret_cast<const floatx4*>(invstd)[g];
+  floatx4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  for (int k = r; k < rows_per_block; k += rpp) {
+    const long long row = row0 + k;
+    if (row >= rows) break;
+    const long long i = row * G + g;
+    floatx4 v = reinterpret_cast<const floatx4*>(part)[i];
+    for (int j = 1; j < nsplit; ++j) v += reinterpret_cast<const floatx4*>(part)[(long long)j * n4 + i];
+    if (addend) v += reinterpret_cast<const floatx4*>(addend)[i];
+    reinterpret_cast<floatx4*>(dst)[i] = v;
+    const floatx4 xv = reinterpret_cast<const floatx4*>(x)[i];
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaf(xv[j], sc[j], sf[j]) > 0.f ? v[j] : 0.f;
+    }
+    s += v;
+    q += v * ((xv - mu) * is);
   }
   sh[0][tid] = s;
   sh[1][tid] = q;
@@ -1895,7 +1968,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
   if (pk_enabled()) {
     PkPlan pk = plan_pk(a.M, a.Cd, nk_total);
     if (pk.f > 1 && (ws == nullptr || ws_bytes < sizeof(float) * pk.ws_floats)) {   // no scratch: unsplit
-      AVID_REQUIRE(!a.stats, AVID_E_BADARG, "conv_fwd: BatchNorm partials need the planned workspace");
+      AVID_REQUIRE(!a.stats, AVID_E_BADARG, "conv: BatchNorm partials need the planned workspace");
       pk.tail_units /= pk.f;
       pk.f = 1;
       pk.kps = nk_total;
@@ -1911,7 +1984,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     k.pk_kps = pk.kps;
     k.pk_rot = pk.rot;
     k.pk_paired = pk.paired ? 1 : 0;
-    k.stats = MODE == 0 ? a.stats : nullptr;
+    k.stats = (MODE == 0 || a.bnb_x) ? a.stats : nullptr;
     k.part = static_cast<float*>(ws);
     k.part_row_begin = (int)pk.tail_row0;
     magic_for(k.Wd, k.mgW, k.shW);
@@ -1926,6 +1999,15 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     }
     if (rc || pk.f == 1) return rc;
     const long long rows = a.M - pk.tail_row0, n4 = rows * a.Cd / 4, off = pk.tail_row0 * a.Cd;
+    if (MODE == 1 && a.bnb_x && a.stats) {   // the tail rows' BatchNorm-backward partials come out of the reduce
+      ScopedTimer t(s, "splitk_reduce_bnb_kernel", 0.0, 4.0 * rows * a.Cd * (pk.f + 2 + (a.addend ? 1 : 0)));
+      const int rpb = stats_rpb(rows, a.Cd);
+      hipLaunchKernelGGL(splitk_reduce_bnb_kernel, dim3((unsigned)ceil_div(rows, rpb)), dim3(256), 0, s, k.part,
+                         a.dst + off, a.addend ? a.addend + off : nullptr, rows, a.Cd, pk.f, rpb, a.bnb_x + off,
+                         a.bnb_scale, a.bnb_shift, a.bnb_mean, a.bnb_invstd, a.bnb_relu,
+                         a.stats + (long long)pk.grid * 2 * a.Cd);
+      return check_launch("splitk_reduce_bnb");
+    }
     if (MODE == 0 && a.stats) {   // the tail rows' BatchNorm partials come out of the reduce
       ScopedTimer t(s, "splitk_reduce_stats_kernel", 0.0, 4.0 * rows * a.Cd * (pk.f + 1 + (a.addend ? 1 : 0)));
       const int rpb = stats_rpb(rows, a.Cd);
@@ -2039,6 +2121,8 @@ static void fill_common(ConvArgs& a, const avid_conv_desc* d) {
   a.ncls = 1;
   a.mgW = a.mgH = a.mgT = 0; a.shW = a.shH = a.shT = 0;
   a.stats = nullptr;
+  a.bnb_x = a.bnb_scale = a.bnb_shift = a.bnb_mean = a.bnb_invstd = nullptr;
+  a.bnb_relu = 0;
   a.cls_ptiles_total = 0;
   a.mt2_begin = 0;
   a.mt2_count = 0;
@@ -2062,6 +2146,8 @@ int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin,
   a.mt2_begin = 0; a.mt2_count = (int)((((long long)M + 127) / 128 + 1) / 2); a.part_row_begin = 0;
   a.ssB = a.ssT = a.ssH = a.ssW = a.ssC = 0;
   a.stats = nullptr;
+  a.bnb_x = a.bnb_scale = a.bnb_shift = a.bnb_mean = a.bnb_invstd = nullptr;
+  a.bnb_relu = 0;
   a.mgW = a.mgH = a.mgT = 0; a.shW = a.shH = a.shT = 0;
   // persistent kernel, no K-split (K = 128: 4 k-tiles per tile, thousands of tiles): 54 -> ~90 TFLOP/s
   if (pk_enabled()) return dispatch_igemm<0>(a, nullptr, 0, s);
@@ -2148,11 +2234,31 @@ extern "C" int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_de
   return check_launch("weight_transpose_batched");
 }
 
+// rows of BatchNorm-backward partial sums a dgrad of this layer writes (0: this layer cannot — strided, or not on
+// the persistent kernel); dense layers: one row per workgroup + the K-split tail's reduce blocks
+extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
+  if (!d || validate(d)) return 0;
+  if (d->x_channel_first || d->Cin % 64 || d->Cout % 32 || d->st > 1 || d->sh > 1 || d->sw > 1) return 0;
+  if (!pk_enabled() || d->Cin > 1024 || (256 % (d->Cin / 4)) != 0) return 0;
+  const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
+  const PkPlan pk = plan_pk(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK));
+  return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cin)) : 0);
+}
+
 extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* wt_in,
-                               const float* addend, float* dx, void* ws, size_t ws_bytes, avid_stream_t stream) {
+                               const float* addend, float* dx, const avid_bn_bwd_fuse* bn, void* ws, size_t ws_bytes,
+                               avid_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
   AVID_REQUIRE(dy && w && dx && ws, AVID_E_BADARG, "conv_dgrad: null pointer");
+  if (bn) {
+    AVID_REQUIRE(bn->x && bn->scale && bn->shift && bn->mean && bn->invstd && bn->partials, AVID_E_BADARG,
+                 "conv_dgrad: incomplete BatchNorm descriptor");
+    AVID_REQUIRE(avid_conv_dgrad_bn_rows(d) > 0, AVID_E_UNSUPPORTED,
+                 "conv_dgrad: this layer cannot produce BatchNorm-backward partial sums (avid_conv_dgrad_bn_rows == 0)");
+    AVID_REQUIRE(ws_bytes >= avid_conv_dgrad_workspace_bytes(d), AVID_E_BADARG,
+                 "conv_dgrad: BatchNorm partials need the planned workspace");
+  }
   AVID_REQUIRE(!d->x_channel_first && d->Cin % 64 == 0 && d->Cout % 32 == 0, AVID_E_UNSUPPORTED,
                "conv_dgrad: needs channels-last x, Cin %% 64 == 0 and Cout %% 32 == 0 (Cin=%d Cout=%d)", d->Cin,
                d->Cout);
@@ -2182,6 +2288,11 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
   a.mode = 1;
   a.relu = 0;
   a.ssB = a.ssT = a.ssH = a.ssW = a.ssC = 0;
+  if (bn) {
+    a.bnb_x = bn->x; a.bnb_scale = bn->scale; a.bnb_shift = bn->shift; a.bnb_mean = bn->mean;
+    a.bnb_invstd = bn->invstd; a.bnb_relu = bn->relu;
+    a.stats = bn->partials;
+  }
   return dispatch_igemm<1>(a, static_cast<char*>(ws) + dgrad_wt_bytes(d), ws_bytes - dgrad_wt_bytes(d), s);
 }
 

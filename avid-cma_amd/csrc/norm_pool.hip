@@ -772,8 +772,8 @@ extern "C" int avid_bn_fwd_eval(int64_t M, int C, const float* x, const float* g
 
 extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, const float* gamma,
                            const float* save_mean, const float* save_invstd, const float* save_scale,
-                           const float* save_shift, int relu, float* dx, float* dgamma, float* dbeta, void* ws,
-                           size_t ws_bytes, avid_stream_t stream) {
+                           const float* save_shift, int relu, float* dx, float* dgamma, float* dbeta,
+                           const float* partials, int nparts, void* ws, size_t ws_bytes, avid_stream_t stream) {
   int rc = bn_check(M, C, "bn_bwd");
   if (rc) return rc;
   AVID_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, AVID_E_BADARG,
@@ -782,16 +782,21 @@ extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, co
   AVID_REQUIRE(ws_bytes >= avid_bn_workspace_bytes(M, C), AVID_E_BADARG, "bn_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   BnPlan p = bn_plan(M, C);
-  float* part = static_cast<float*>(ws);
-  float* k1 = part + (size_t)p.nblk * 2 * C;
+  float* wsf = static_cast<float*>(ws);
+  float* k1 = wsf + (size_t)p.nblk * 2 * C;
   float* k2 = k1 + C;
-  {
+  const float* part = wsf;
+  int nblk = p.nblk;
+  if (partials && nparts > 0) {   // the dgrad that produced dy already reduced it to partial rows
+    part = partials;
+    nblk = nparts;
+  } else {
     ScopedTimer t(s, "bn_bwd_partial_kernel", 0.0, 4.0 * M * C * 2);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, save_scale, save_shift, dy, save_mean,
-                       save_invstd, part,
+                       save_invstd, wsf,
                        (long long)M, C, p.G, p.rows_per_pass, p.rows_per_block, relu);
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, p.nblk,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, nblk,
                      (long long)M, C, dgamma, dbeta, k1, k2);
   const long long n4 = (long long)M * p.G;
   {

@@ -35,11 +35,11 @@ class ConvCL(nn.Module):
         self.weight = nn.Parameter(ops.make_weight(out_planes, in_planes, *self.kernel_size))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
 
-    def forward(self, x, addend=None, bn_stats=False, tap=False):
+    def forward(self, x, addend=None, bn_stats=False, tap=False, bn_src=None):
         """``bn_stats=True``: also return the BatchNorm partial sums of the output (for the BN that follows);
-        ``tap=True``: also return an alias of ``x`` for a second consumer (see ``ops.conv_cl``)."""
+        ``tap=True``: also return an alias of ``x`` for a second consumer; ``bn_src``: see ``ops.conv_cl``."""
         return ops.conv_cl(x, self.weight, self.stride3, self.padding3, addend=addend,
-                           channel_first=self.channel_first, bn_stats=bn_stats, tap=tap)
+                           channel_first=self.channel_first, bn_stats=bn_stats, tap=tap, bn_src=bn_src)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
@@ -61,11 +61,11 @@ class BatchNormCL(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, relu=False, partials=None):
+    def forward(self, x, relu=False, partials=None, src=None):
         return ops.batch_norm_cl(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
                                  self.momentum, self.eps, relu,
                                  self.num_batches_tracked if self.training else None,   # bumped inside the kernel
-                                 partials)
+                                 partials, src)
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"
@@ -74,17 +74,23 @@ class BatchNormCL(nn.Module):
 _FUSE_BN_STATS = os.environ.get("AVID_FUSE_BN_STATS", "1") == "1"
 
 
-def _conv_bn(conv, bn, x, addend=None, tap=False):
+def _conv_bn(conv, bn, x, addend=None, tap=False, sole=True):
     """ReLU(bn(conv(x) [+ addend])).  In training the conv epilogue hands the BatchNorm its batch statistics
     as partial sums, so the BN does not re-read the activation for them.  ``tap``: also return an alias of x
-    whose gradient is folded into this conv's input-gradient kernel (the residual branch)."""
-    fuse = bn.training and x.is_cuda and _FUSE_BN_STATS
-    out = conv(x, addend=addend, bn_stats=fuse, tap=tap)
+    whose gradient is folded into this conv's input-gradient kernel (the residual branch).
+    ``sole``: this conv (with its tap) is the only consumer of x; if x is itself the output of a ``_conv_bn``, the
+    backward partial sums of THAT BatchNorm are then made by this conv's input-gradient kernel (ops.BnSource)."""
+    train = bn.training and x.is_cuda
+    fuse = train and _FUSE_BN_STATS
+    src_in = getattr(x, "_avid_bn_src", None) if (sole and train and torch.is_grad_enabled()) else None
+    out = conv(x, addend=addend, bn_stats=fuse, tap=tap, bn_src=src_in)
+    src_out = ops.BnSource(None, None, True) if (train and torch.is_grad_enabled()) else None
     if not (fuse or tap):
-        return bn(out, relu=True)
-    y = out[0]
-    partials = out[1] if fuse else None
-    h = bn(y, relu=True, partials=partials)
+        h = bn(out, relu=True, src=src_out)
+    else:
+        h = bn(out[0], relu=True, partials=out[1] if fuse else None, src=src_out)
+    if src_out is not None:
+        h._avid_bn_src = src_out          # read by the next _conv_bn that takes h as its input
     return (h, out[-1]) if tap else h
 
 
@@ -137,8 +143,8 @@ class BasicR2P1DBlock(nn.Module):
         tap = x.is_cuda and x.requires_grad and torch.is_grad_enabled()
         if tap:     # the residual branch reads an alias of x: its gradient is added inside spt_conv1's dgrad
             h, x = _conv_bn(self.spt_conv1, self.spt_bn1, x, tap=True)
-        else:
-            h = _conv_bn(self.spt_conv1, self.spt_bn1, x)
+        else:       # (x also feeds the residual branch directly: spt_conv1 is not its only consumer)
+            h = _conv_bn(self.spt_conv1, self.spt_bn1, x, sole=False)
         h = _conv_bn(self.tmp_conv1, self.tmp_bn1, h)
         h = _conv_bn(self.spt_conv2, self.spt_bn2, h)
         x_res = self.res_conv(x) if self.res else x

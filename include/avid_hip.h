@@ -80,8 +80,25 @@ int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const
  * wt: the weights already repacked as [Cin][taps][Cout] by avid_weight_transpose_batched (current for
  * this w), or NULL to repack inside the call (one extra small launch per layer). */
 size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d);
+/* bn (or NULL): dx is the COMPLETE gradient of the output of a training-mode BatchNorm(+ReLU) whose input was
+ * bn->x (shape of dx) — the usual conv <- ReLU <- BN chain of models/network_blocks.py:30-60.  The dgrad epilogue
+ * then also writes that BatchNorm's backward partial sums ([rows][2][Cin]: sum dy_m, sum dy_m * xhat with dy_m the
+ * gradient masked by the recomputed ReLU; rows = avid_conv_dgrad_bn_rows(d), 0 = this layer cannot), which
+ * avid_bn_bwd takes instead of making its own pass over dy and x.  scale / shift / mean / invstd: the tensors
+ * avid_bn_fwd_train saved. */
+typedef struct {
+  const float* x;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  int32_t relu;
+  float* partials;
+} avid_bn_bwd_fuse;
+int avid_conv_dgrad_bn_rows(const avid_conv_desc* d);
 int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* wt,
-                    const float* addend, float* dx, void* ws, size_t ws_bytes, avid_stream_t stream);
+                    const float* addend, float* dx, const avid_bn_bwd_fuse* bn, void* ws, size_t ws_bytes,
+                    avid_stream_t stream);
 
 /* One launch that repacks every conv / linear weight of a model for its input-gradient pass:
  * w[Cout][taps][Cin] -> wt[Cin][taps][Cout] for each descriptor.  descs_dev: n descriptors in DEVICE
@@ -124,11 +141,13 @@ int avid_bn_fwd_eval(int64_t M, int C, const float* x, const float* gamma, const
                      const float* running_mean, const float* running_var, float eps, int relu,
                      float* y, avid_stream_t stream);
 /* Backward of train-mode BN(+ReLU).  The ReLU mask is fma(x, scale, shift) > 0 recomputed from the conv
- * output x (the forward's exact expression), so the saved activation is not re-read: 2 + 3 passes. */
+ * output x (the forward's exact expression), so the saved activation is not re-read: 2 + 3 passes.
+ * partials / nparts: the partial sums the dgrad that produced dy already made (avid_conv_dgrad's `bn`), or
+ * NULL / 0 — then the 2-read statistics pass runs here. */
 int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, const float* gamma,
                 const float* save_mean, const float* save_invstd, const float* save_scale,
-                const float* save_shift, int relu, float* dx, float* dgamma, float* dbeta, void* ws,
-                size_t ws_bytes, avid_stream_t stream);
+                const float* save_shift, int relu, float* dx, float* dgamma, float* dbeta,
+                const float* partials, int nparts, void* ws, size_t ws_bytes, avid_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pooling.  MaxPool3d((1,3,3),(1,2,2),(0,1,1)) — models/video.py:23;  AdaptiveMaxPool{3,2}d(1) —

@@ -101,6 +101,50 @@ def test_conv_bn_partials(shape, cout, gpu_device):
         assert relerr(q, (yd * yd).sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("shape,cmid,cout,k,pad", [
+    ((2, 4, 12, 12), 64, 64, (1, 3, 3), (0, 1, 1)),        # one partial tile
+    ((7, 8, 45, 47), 64, 128, (3, 1, 1), (1, 0, 0)),       # whole rounds + a K-split tail (reduce kernel path)
+    ((4, 3, 17, 19), 128, 128, (1, 3, 3), (0, 1, 1)),      # 128-wide tiles, ragged
+])
+def test_bn_backward_partials_from_dgrad(shape, cmid, cout, k, pad, gpu_device):
+    """conv1 -> BN+ReLU -> conv2 [+ tap]: with ops.BnSource the BatchNorm's backward partial sums come out of
+    conv2's input-gradient kernel (epilogue / K-split reduce) instead of the BatchNorm's own pass over dy and x.
+    Gradients vs the same chain without the hand-over: 2e-5 of the gradient scale (fp32 partial sums in a
+    different order); the consumer conv's output gradient dx is bit-identical (the sums only ride along)."""
+    from avid_hip import ops
+    B, Ti, Hi, Wi = shape
+    x = T(detgen.det_normalish(f"bnb:{shape}:x", (B, Ti, Hi, Wi, 64))).to(gpu_device)
+    w1 = ops.make_weight(cmid, 64, 1, 3, 3); w1.copy_(T(detgen.det_param(f"bnb:{cmid}:w1.weight", (cmid, 64, 1, 3, 3))))
+    w2 = ops.make_weight(cout, cmid, *k); w2.copy_(T(detgen.det_param(f"bnb:{cout}:{k}:w2.weight", (cout, cmid) + k)))
+    w1, w2 = w1.to(gpu_device), w2.to(gpu_device)
+    gam = (T(detgen.det_uniform(f"bnb:{cmid}:g", (cmid,))) + 1.5).to(gpu_device)
+    bet = T(detgen.det_uniform(f"bnb:{cmid}:b", (cmid,))).to(gpu_device)
+    gy = None
+    res = {}
+    for fused in (False, True):
+        for tap in (False, True):
+            xx = x.clone().requires_grad_(True)
+            g_, b_ = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+            rm, rv = torch.zeros(cmid, device=gpu_device), torch.ones(cmid, device=gpu_device)
+            y1 = ops.conv_cl(xx, w1, (1, 1, 1), (0, 1, 1))
+            src = ops.BnSource(None, None, True) if fused else None
+            h = ops.batch_norm_cl(y1, g_, b_, rm, rv, True, relu=True, src=src)
+            out = ops.conv_cl(h, w2, (1, 1, 1), pad, tap=tap, bn_src=src)
+            y2, alias = (out[0], out[-1]) if tap else (out, None)
+            if gy is None:
+                gy = T(detgen.det_uniform(f"bnb:{shape}:{cout}:gy", tuple(y2.shape))).to(gpu_device)
+            loss = (y2 * gy).sum()
+            if tap:
+                loss = loss + (alias * alias).sum() * 0.25          # a second consumer through the tap
+            loss.backward()
+            if fused:
+                assert src.partials is None                          # consumed by the BatchNorm's backward
+            res[(fused, tap)] = (xx.grad.clone(), g_.grad.clone(), b_.grad.clone())
+    for tap in (False, True):
+        for a, b in zip(res[(False, tap)], res[(True, tap)]):
+            assert relerr(b, a) < 2e-5
+
+
 def test_conv_transpose_detecting(gpu_device):
     """A = identity-like with ASYMMETRIC weights: catches a row<->col swap in the MFMA C-write."""
     from avid_hip import ops
