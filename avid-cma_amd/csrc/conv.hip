@@ -793,29 +793,43 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
           (void*)(direct ? p.dst : p.part + (long long)split * p.M * p.Cd), 0, (int)((long long)p.M * row_bytes), 0x00020000);
       const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(p.addend ? p.addend : p.dst), 0, (int)((long long)p.M * row_bytes), 0x00020000);
-      auto emit = [&](auto HAS_ADD) {
+      const __amdgpu_buffer_rsrc_t rsXb = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.bnb_x ? p.bnb_x : p.dst), 0, (int)((long long)p.M * row_bytes), 0x00020000);
+      auto emit = [&](auto HAS_ADD, auto BNB) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
           for (int jj = 0; jj < TN; ++jj) {
-            const int col4 = (n0 + (wn * TN + jj) * 32 + l31) * 4;
+            const int col = n0 + (wn * TN + jj) * 32 + l31;
+            const int col4 = col * 4;
             unsigned voff[16];
-            float ad[16];
+            float ad[16], xb[16], bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               voff[r] = (unsigned)drow[(wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] + col4;
               if (HAS_ADD) ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, voff[r], 0, 0));
+              if (BNB) xb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsXb, voff[r], 0, 0));
             }
+            if (BNB) { bsc = p.bnb_scale[col]; bsh = p.bnb_shift[col]; bmu = p.bnb_mean[col]; bis = p.bnb_invstd[col]; }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               float v = acc[i][jj][r];
               if (HAS_ADD) v += ad[r];
+              if (BNB) {       // BatchNorm-backward partial sums of the gradient being written (see the dense epilogue)
+                const float dm = (!p.bnb_relu || fmaf(xb[r], bsc, bsh) > 0.f) ? v : 0.f;
+                cs[jj] += dm;
+                cq[jj] = fmaf(dm, (xb[r] - bmu) * bis, cq[jj]);
+              }
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff[r], 0, 0);
             }
           }
         }
       };
-      if (direct && p.addend) emit(std::true_type{}); else emit(std::false_type{});
+      constexpr std::true_type Y{};
+      constexpr std::false_type N{};
+      if (direct && p.bnb_x) { if (p.addend) emit(Y, Y); else emit(N, Y); }
+      else if (direct && p.addend) emit(Y, N);
+      else emit(N, N);
       continue;
     }
     const int mt = tile / ntn, nt = tile - mt * ntn;
@@ -1944,8 +1958,20 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     k.pk_rot = 0;
     const int grid = k.pk_full < 2 * cus ? k.pk_full : 2 * cus;
     k.pk_paired = (grid == 2 * cus && grid % 16 == 0) ? 1 : 0;
+    // BatchNorm-backward partials: from the epilogue when tiles are written directly (f == 1: one row per
+    // workgroup), from the reduce when every tile is K-split
+    k.stats = (a.bnb_x && f == 1) ? a.stats : nullptr;
+    if (f > 1) k.bnb_x = nullptr;
     int rc = wide ? launch_pk<2, 2, 2, 2, 1, true>(k, grid, s) : launch_pk<4, 1, 1, 2, 1, true>(k, grid, s);
     if (rc || f == 1) return rc;
+    if (a.bnb_x && a.stats) {
+      ScopedTimer t(s, "splitk_reduce_bnb_kernel", 0.0, 4.0 * a.M * a.Cd * (f + 2 + (a.addend ? 1 : 0)));
+      const int rpb = stats_rpb(a.M, a.Cd);
+      hipLaunchKernelGGL(splitk_reduce_bnb_kernel, dim3((unsigned)ceil_div((long long)a.M, rpb)), dim3(256), 0, s, k.part,
+                         a.dst, a.addend, (long long)a.M, a.Cd, f, rpb, a.bnb_x, a.bnb_scale, a.bnb_shift, a.bnb_mean,
+                         a.bnb_invstd, a.bnb_relu, a.stats);
+      return check_launch("splitk_reduce_bnb");
+    }
     const long long n4 = (long long)a.M * a.Cd / 4;
     long long rgrid = ceil_div(n4, 256);
     if (rgrid > 2048) rgrid = 2048;
@@ -2238,9 +2264,20 @@ extern "C" int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_de
 // the persistent kernel); dense layers: one row per workgroup + the K-split tail's reduce blocks
 extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
-  if (d->x_channel_first || d->Cin % 64 || d->Cout % 32 || d->st > 1 || d->sh > 1 || d->sw > 1) return 0;
+  if (d->x_channel_first || d->Cin % 64 || d->Cout % 32 || d->st > 2 || d->sh > 2 || d->sw > 2) return 0;
   if (!pk_enabled() || d->Cin > 1024 || (256 % (d->Cin / 4)) != 0) return 0;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
+  if (d->st > 1 || d->sh > 1 || d->sw > 1) {   // strided: the plan of dispatch_igemm<1>'s parity-class branch
+    if (M * d->Cin * 4 >= (1ll << 31)) return 0;
+    ConvArgs a;
+    fill_common(a, d);
+    a.Td = d->Ti; a.Hd = d->Hi; a.Wd = d->Wi; a.Cd = d->Cin;
+    const int BN = d->Cin % 128 == 0 ? 128 : 64;
+    const int total = build_classes_pk(a, 128, d->Cin / BN);
+    const int f = strided_splits(total);
+    if (f > 1) return (int)ceil_div(M, stats_rpb(M, d->Cin));
+    return total < 2 * device_cus() ? total : 2 * device_cus();
+  }
   const PkPlan pk = plan_pk(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK));
   return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cin)) : 0);
 }

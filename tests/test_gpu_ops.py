@@ -101,12 +101,15 @@ def test_conv_bn_partials(shape, cout, gpu_device):
         assert relerr(q, (yd * yd).sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("shape,cmid,cout,k,pad", [
-    ((2, 4, 12, 12), 64, 64, (1, 3, 3), (0, 1, 1)),        # one partial tile
-    ((7, 8, 45, 47), 64, 128, (3, 1, 1), (1, 0, 0)),       # whole rounds + a K-split tail (reduce kernel path)
-    ((4, 3, 17, 19), 128, 128, (1, 3, 3), (0, 1, 1)),      # 128-wide tiles, ragged
+@pytest.mark.parametrize("shape,cmid,cout,k,pad,stride", [
+    ((2, 4, 12, 12), 64, 64, (1, 3, 3), (0, 1, 1), (1, 1, 1)),        # one partial tile
+    ((7, 8, 45, 47), 64, 128, (3, 1, 1), (1, 0, 0), (1, 1, 1)),       # whole rounds + a K-split tail (reduce kernel)
+    ((4, 3, 17, 19), 128, 128, (1, 3, 3), (0, 1, 1), (1, 1, 1)),      # 128-wide tiles, ragged
+    ((8, 8, 28, 28), 64, 128, (1, 3, 3), (0, 1, 1), (1, 2, 2)),       # strided consumer, tiles written directly
+    ((3, 4, 13, 15), 128, 256, (1, 3, 3), (0, 1, 1), (1, 2, 2)),      # strided, every tile K-split (reduce kernel)
+    ((3, 5, 9, 9), 64, 64, (3, 1, 1), (1, 0, 0), (2, 1, 1)),          # temporal stride, odd extent
 ])
-def test_bn_backward_partials_from_dgrad(shape, cmid, cout, k, pad, gpu_device):
+def test_bn_backward_partials_from_dgrad(shape, cmid, cout, k, pad, stride, gpu_device):
     """conv1 -> BN+ReLU -> conv2 [+ tap]: with ops.BnSource the BatchNorm's backward partial sums come out of
     conv2's input-gradient kernel (epilogue / K-split reduce) instead of the BatchNorm's own pass over dy and x.
     Gradients vs the same chain without the hand-over: 2e-5 of the gradient scale (fp32 partial sums in a
@@ -129,7 +132,7 @@ def test_bn_backward_partials_from_dgrad(shape, cmid, cout, k, pad, gpu_device):
             y1 = ops.conv_cl(xx, w1, (1, 1, 1), (0, 1, 1))
             src = ops.BnSource(None, None, True) if fused else None
             h = ops.batch_norm_cl(y1, g_, b_, rm, rv, True, relu=True, src=src)
-            out = ops.conv_cl(h, w2, (1, 1, 1), pad, tap=tap, bn_src=src)
+            out = ops.conv_cl(h, w2, stride, pad, tap=tap, bn_src=src)
             y2, alias = (out[0], out[-1]) if tap else (out, None)
             if gy is None:
                 gy = T(detgen.det_uniform(f"bnb:{shape}:{cout}:gy", tuple(y2.shape))).to(gpu_device)
