@@ -2,7 +2,7 @@
 import torch.nn as nn
 
 from avid_hip import ops
-from .network_blocks import Basic2DBlock, BatchNormCL, ConvCL, _conv_bn
+from .network_blocks import Basic2DBlock, BatchNormCL, ConvCL, _conv_bn, no_bn_handover
 
 __all__ = ["Conv2D"]
 
@@ -31,6 +31,12 @@ class Conv2D(nn.Module):
         self.out_dim = 512
 
     def forward(self, x, return_embs=False):
+        if return_embs:        # intermediate activations leave the module: no single-consumer hand-over
+            with no_bn_handover():
+                return self._forward(x, True)
+        return self._forward(x, False)
+
+    def _forward(self, x, return_embs):
         x5 = x.contiguous().unsqueeze(2)            # [B,1,1,H,W]: 2-D conv == 3-D conv with T = kt = 1
         x_c1 = _conv_bn(self.conv1[0], self.conv1[1], x5)   # stem conv + BN(+ReLU), statistics from the conv epilogue
         x_b1 = self.block1(x_c1)

@@ -74,6 +74,21 @@ class BatchNormCL(nn.Module):
 _FUSE_BN_STATS = os.environ.get("AVID_FUSE_BN_STATS", "1") == "1"
 
 
+_HANDOVER = [True]
+
+
+class no_bn_handover:
+    """Context: activations produced inside are NOT marked as single-consumer BatchNorm outputs (``return_embs``
+    hands intermediate activations to the caller, who may put them in the loss: then the next convolution's
+    input gradient is only part of the BatchNorm output's gradient and the hand-over would be wrong)."""
+
+    def __enter__(self):
+        self.prev, _HANDOVER[0] = _HANDOVER[0], False
+
+    def __exit__(self, *exc):
+        _HANDOVER[0] = self.prev
+
+
 def _conv_bn(conv, bn, x, addend=None, tap=False, sole=True):
     """ReLU(bn(conv(x) [+ addend])).  In training the conv epilogue hands the BatchNorm its batch statistics
     as partial sums, so the BN does not re-read the activation for them.  ``tap``: also return an alias of x
@@ -84,7 +99,7 @@ def _conv_bn(conv, bn, x, addend=None, tap=False, sole=True):
     fuse = train and _FUSE_BN_STATS
     src_in = getattr(x, "_avid_bn_src", None) if (sole and train and torch.is_grad_enabled()) else None
     out = conv(x, addend=addend, bn_stats=fuse, tap=tap, bn_src=src_in)
-    src_out = ops.BnSource(None, None, True) if (train and torch.is_grad_enabled()) else None
+    src_out = ops.BnSource(None, None, True) if (train and torch.is_grad_enabled() and _HANDOVER[0]) else None
     if not (fuse or tap):
         h = bn(out, relu=True, src=src_out)
     else:

@@ -3,7 +3,7 @@ import os
 import torch.nn as nn
 
 from avid_hip import ops
-from .network_blocks import BasicR2P1DBlock, BatchNormCL, ConvCL, MaxPoolHW3S2
+from .network_blocks import BasicR2P1DBlock, BatchNormCL, ConvCL, MaxPoolHW3S2, no_bn_handover
 
 _FUSE_STEM_TAIL = os.environ.get("AVID_FUSE_STEM_TAIL", "1") == "1"
 
@@ -53,6 +53,12 @@ class R2Plus1D(nn.Module):
         self.out_dim = 512
 
     def forward(self, x, return_embs=False):
+        if return_embs:        # intermediate activations leave the module: no single-consumer hand-over
+            with no_bn_handover():
+                return self._forward(x, True)
+        return self._forward(x, False)
+
+    def _forward(self, x, return_embs):
         conv, bn = self.conv1[0], self.conv1[1]
         if self.training and x.is_cuda and _FUSE_STEM_TAIL:
             # BN + ReLU + max-pool in one pass over the 411 MB stem activation (bs 64)

@@ -19,6 +19,11 @@ def cl(x):
     return x.permute(0, 2, 3, 4, 1).contiguous()
 
 
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
 def load_det(module, tag):
     sd = module.state_dict()
     module.load_state_dict({k: T(detgen.det_param(f"{tag}:{k}", tuple(v.shape)).copy()).to(v.dtype)
@@ -79,6 +84,38 @@ def _build_model(gpu_device, tag="w"):
     m = models.av_wrapper("R2Plus1D", {"depth": 18}, "Conv2D", {"depth": 10}, proj_dim=[512, 512, 128])
     load_det(m, tag)
     return m.to(gpu_device)
+
+
+def test_return_embs_in_the_loss_keeps_exact_bn_gradients(gpu_device):
+    """return_embs hands intermediate activations to the caller; with one of them in the loss a BatchNorm output
+    has a second consumer, so the dgrad -> BatchNorm hand-over of the partial sums (ops.BnSource) must be off
+    for that forward: gradients are then bit-identical to a run with the hand-over disabled globally, and the
+    plain training forward (hand-over on) agrees with both to fp32 summation-order noise."""
+    from avid_hip import ops
+    m = _build_model(gpu_device).train().video_model
+    video = T(detgen.det_normalish("embs:video", (2, 3, 8, 112, 112))).to(gpu_device)
+
+    def run(return_embs, extra):
+        for p in m.parameters():
+            p.grad = None
+        e = m(video, return_embs=True) if return_embs else {"pool": m(video)}
+        loss = (e["pool"] ** 2).sum()
+        if extra:
+            loss = loss + (e["conv3x"] ** 2).sum() * 1e-3
+        loss.backward()
+        return [p.grad.clone() for p in m.parameters()]
+
+    with_embs = run(True, True)
+    saved, ops.FUSE_BN_BWD = ops.FUSE_BN_BWD, False
+    try:
+        plain_off = run(True, True)
+        base_off = run(False, False)
+    finally:
+        ops.FUSE_BN_BWD = saved
+    assert all(torch.equal(a, b) for a, b in zip(with_embs, plain_off))
+    base_on = run(False, False)               # the normal training forward: hand-over active
+    for a, b in zip(base_on, base_off):
+        assert relerr(a, b) < 1e-4
 
 
 def test_av_wrapper_vs_reference_golden(golden, gpu_device):
