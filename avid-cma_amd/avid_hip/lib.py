@@ -94,6 +94,7 @@ SIGNATURES = {
                                       _vp, _i, _vp, _sz, _vp]),
     "avid_bn_relu_maxpool_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                       _vp]),
+    "avid_clip_normalize": (_i, [_i, _i, _i, _i, _vp, C.POINTER(_f), C.POINTER(_f), _vp, _vp]),
     "avid_logspec_basis_floats": (_sz, [_i]),
     "avid_logspec_basis": (_i, [_i, _vp, _vp]),
     "avid_logspec_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -519,6 +519,23 @@ def bn_relu_maxpool(x, gamma, beta, running_mean, running_var, momentum=0.1, eps
 
 
 # ------------------------------------------------------------------------------------------------
+# video front end: ClipToTensor + Normalize on the GPU
+# ------------------------------------------------------------------------------------------------
+def clip_normalize(frames, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """``frames [B, T, H, W, 3]`` uint8 on the GPU -> ``[B, 3, T, H, W]`` fp32 = ((u / 255) - mean) / std — the
+    reference's ``ClipToTensor`` + ``Normalize`` (datasets/preprocessing.py:45-48), bit-identical.  No gradient."""
+    _need_cuda(frames)
+    if frames.dim() != 5 or frames.shape[-1] != 3 or frames.dtype != torch.uint8 or not frames.is_contiguous():
+        raise AvidHipError("clip_normalize: frames must be a contiguous uint8 [B, T, H, W, 3] tensor")
+    B, T_, H, W, _ = frames.shape
+    out = torch.empty((B, 3, T_, H, W), dtype=torch.float32, device=frames.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    lib.call("avid_clip_normalize", B, T_, H, W, _p(frames), m, s, _p(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # audio front end (SURVEY §8(f) rank 4)
 # ------------------------------------------------------------------------------------------------
 _LOGSPEC_BASIS = {}

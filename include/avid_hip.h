@@ -256,6 +256,13 @@ int avid_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, floa
                    float beta2, float eps, float weight_decay, int64_t step, const int64_t* step_dev,
                    float grad_scale, avid_stream_t stream);
 
+/* Video clip front end: frames [B][T][H][W][3] uint8 (what the decoder / augmentation hands over)
+ * -> out [B][3][T][H][W] fp32 = ((u / 255) - mean[c]) / std[c], the reference's ClipToTensor + Normalize
+ * (utils/videotransforms/volume_transforms.py:14-66, tensor_transforms.py:13-37; datasets/preprocessing.py:45-48)
+ * in the same fp32 operation order (bit-identical).  mean3 / std3: HOST pointers to 3 floats. */
+int avid_clip_normalize(int B, int T, int H, int W, const uint8_t* frames, const float* mean3, const float* std3,
+                        float* out, avid_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Audio front end on the GPU — datasets/preprocessing.py:158-186 LogSpectrogram:
  * out[b][0][t][f] = z-score( top_db-floored dB( bin-pair mean( |STFT(sig[b])|^2 ) ) ), STFT = librosa.stft
