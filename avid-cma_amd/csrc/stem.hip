@@ -6,11 +6,12 @@
 // pixels of one (b, t) frame, stages the input patch they touch (<= 19 rows x (W + 6) cols x Cin*kt
 // planes, zero padded, read once with coalesced row loads from the reference's channel-first tensor)
 // in LDS, and feeds the fp32 MFMA straight from it:
-//     k' = ((c*kt + dt)*7 + dh)*8 + dw      (dw padded 7 -> 8 with zero weights)
 //     A[pixel i][k'] = patch[plane(c,dt)][2*(ho_i - ho_lo) + dh][2*wo_i + dw]
-// so lane (i, h) reads patch[base_i + rowoff + 2q + h] — one ds_read_b32 per MFMA, no address tables.
-// Weights are repacked once per call to Wt[k'][64] and streamed through a double-buffered 16 KB LDS
-// stage (8 kernel rows per chunk).  441 of the 504 padded k' are useful (87.5 %).
+// so a lane reads patch[base_i + dh*PW + dw] — one ds_read_b32 per MFMA pair, no address tables.
+// wgrad:   k' = ((c*kt + dt)*7 + dh)*8 + dw   (dw padded 7 -> 8: k' tiles of 32 = 4 kernel rows; 441 of 504 useful)
+// forward: k' = (c*kt + dt)*50 + dh*7 + dw    (the 49 taps of a plane flattened, padded to 50: 441 of 450 useful);
+//          weights repacked once per call to Wt[k'][64] and streamed through a double-buffered LDS stage, one
+//          plane (25 k-steps) per chunk.
 #include "common.h"
 
 namespace avid {
@@ -37,16 +38,18 @@ constexpr int STEM_TILE = 256;    // output pixels per workgroup tile
 constexpr int WS_LD = 64;
 
 // Wt[k'][n] = w[n][dt][dh][dw][c]   (k' = ((c*KT+dt)*7+dh)*8+dw ; dw == 7 -> 0)
+// Forward weight layout: Wt[plane = c*KT+dt][f][n] with f = dh*7 + dw flattened to 50 per plane (f = 49 -> 0):
+// 49 of 50 k' are useful (the 8-per-kernel-row layout of the wgrad kernel wastes 1 in 8).
+constexpr int FK = 50;
 template <int CIN, int KT>
 __global__ void stem_repack_kernel(const float* __restrict__ w, float* __restrict__ wt) {
-  constexpr int R = CIN * KT * 7;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R * 8 * 64) return;
+  if (i >= CIN * KT * FK * 64) return;
   const int n = i & 63, kp = i >> 6;
-  const int dw = kp & 7, row = kp >> 3;
-  const int dh = row % 7, pl = row / 7;
+  const int f = kp % FK, pl = kp / FK;
+  const int dh = f / 7, dw = f - dh * 7;
   const int dt = pl % KT, c = pl / KT;
-  wt[i] = dw < 7 ? w[(((n * KT + dt) * 7 + dh) * 7 + dw) * CIN + c] : 0.f;
+  wt[i] = f < 49 ? w[(((n * KT + dt) * 7 + dh) * 7 + dw) * CIN + c] : 0.f;
 }
 
 // patch[plane = c*KT+dt][row][col] ; row 0 <-> hi = 2*ho_lo - 3 ; col 0 <-> wi = -4 (4-float left pad keeps
@@ -77,7 +80,6 @@ __device__ __forceinline__ void stem_load_patch(const StemArgs& p, float* P, int
   }
 }
 
-constexpr int FWD_CH = 4;         // kernel rows per weight chunk (32 k')
 
 // Persistent: 2 workgroups per CU walk the 128-pixel tiles; the next tile's patch is fetched into registers
 // under the current tile's MFMAs and written to LDS between tiles (with the loads between the tiles the
@@ -88,12 +90,11 @@ constexpr int FWD_CH = 4;         // kernel rows per weight chunk (32 k')
 template <int CIN, int KT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const StemArgs p) {
   constexpr int NT = WAVES * 64, TILE = WAVES * 32;
-  constexpr int R = CIN * KT * 7;             // kernel rows (c, dt, dh)
-  constexpr int NCH = (R + FWD_CH - 1) / FWD_CH;
-  constexpr int PIT = 16;                     // float4 patch items per thread (2 x 80 KB of LDS bound it)
+  constexpr int NCH = CIN * KT;               // weight chunks = input planes (c, dt): 50 k' (25 k-steps) each
+  constexpr int PIT = WAVES == 4 ? 14 : 16;   // float4 patch items per thread (the LDS left beside the weight stages bounds it)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ws = smem;                           // [2][FWD_CH*8][WS_LD]
-  float* P = smem + 2 * FWD_CH * 8 * WS_LD;   // patch
+  float* Ws = smem;                           // [2][FK][WS_LD]
+  float* P = smem + 2 * FK * WS_LD;           // patch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int npix = p.Ho * p.Wo;
@@ -148,23 +149,24 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const S
     }
   };
 
-  // weight chunk: 32 rows x 16 float4 = 512 float4 -> WPT per thread
-  constexpr int WPT = 512 / NT, WROWS = NT / 16;      // rows per pass
-  const int wrow = tid >> 4, wcol = (tid & 15) * 4;
+  // weight chunk: FK rows x 16 float4 = 800 float4 -> up to WPT per thread
+  constexpr int WPT = (FK * 16 + NT - 1) / NT;
   floatx4 wv[WPT];
   auto load_w = [&](int ch) {
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-      const int kp = ch * FWD_CH * 8 + wrow + WROWS * i;
+      const int idx = tid + NT * i;
       const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-      wv[i] = kp < R * 8 ? *reinterpret_cast<const floatx4*>(p.wt + (long long)kp * 64 + wcol) : z;
+      wv[i] = idx < FK * 16 ? *reinterpret_cast<const floatx4*>(p.wt + ((long long)ch * FK * 16 + idx) * 4) : z;
     }
   };
   auto store_w = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < WPT; ++i)
-      *reinterpret_cast<floatx4*>(&Ws[buf * FWD_CH * 8 * WS_LD + (wrow + WROWS * i) * WS_LD +
-                                      (wcol ^ (((wrow + WROWS * i) & 1) << 5))]) = wv[i];
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = tid + NT * i, row = idx >> 4, col = (idx & 15) * 4;
+      if (idx < FK * 16)
+        *reinterpret_cast<floatx4*>(&Ws[buf * FK * WS_LD + row * WS_LD + (col ^ ((row & 1) << 5))]) = wv[i];
+    }
   };
 
   int tile = blockIdx.x;
@@ -195,33 +197,39 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const S
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+    // Per plane: 25 k-steps over the 7 x 7 taps flattened (f = dh*7 + dw; step q takes f = 2q + h).  The lane's
+    // address is base0 + dh*PW + dw: both halves share dh except when f = 2q is the last tap of a row (dw = 6),
+    // where the h = 1 half starts the next row — two per-lane offsets (lo / lw) cover the two cases, dh*PW + dw
+    // of the even tap is uniform.  The last step pairs tap 48 with the zero weight row 49 (both halves read tap 48).
+    const int base0 = base - h;
+    const int lo = h, lw = h ? p.PW - 6 : 0;
     for (int ch = 0; ch < NCH; ++ch, u ^= 1) {
       load_w(ch + 1 < NCH ? ch + 1 : 0);      // cyclic: the last chunk of a tile fetches chunk 0 of the next
-      const float* Wb = Ws + u * FWD_CH * 8 * WS_LD + l31;
-      // operands of kernel row rr+1 are fetched before the 8 MFMAs of row rr issue (pinned with sched_barrier:
-      // the compiler otherwise puts every ds_read right in front of its MFMA and exposes the LDS latency 16
-      // times per chunk); rows past R read valid LDS and multiply by the zero-filled weight rows
-      float af[2][4], b0f[2][4], b1f[2][4];
-      auto frag = [&](int rr, int buf) {
-        const int row = min(ch * FWD_CH + rr, R - 1);
-        const int dh = row % 7, pl = row / 7;
-        const float* Pr = P + pl * plane + dh * p.PW + base;
+      const float* Wb = Ws + u * FK * WS_LD + l31;
+      const float* Pp = P + ch * plane + base0;
+      // operands of the next group of 5 k-steps are fetched before the 10 MFMAs of the current one issue (pinned
+      // with sched_barrier: the compiler otherwise puts every ds_read right in front of its MFMA)
+      float af[2][5], b0f[2][5], b1f[2][5];
+      auto frag = [&](int grp, int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          af[buf][q] = Pr[2 * q];
-          b0f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD + 32 * h];          // row parity == h: swapped halves
-          b1f[buf][q] = Wb[(rr * 8 + 2 * q + h) * WS_LD + 32 - 32 * h];
+        for (int s5 = 0; s5 < 5; ++s5) {
+          const int q = grp * 5 + s5, f0 = 2 * q;
+          const int dh = f0 / 7, dw = f0 - dh * 7;          // compile-time after unrolling
+          const int lane_off = q == 24 ? 0 : (dw == 6 ? lw : lo);
+          af[buf][s5] = Pp[dh * p.PW + dw + lane_off];
+          b0f[buf][s5] = Wb[(2 * q + h) * WS_LD + 32 * h];          // row parity == h: swapped halves
+          b1f[buf][s5] = Wb[(2 * q + h) * WS_LD + 32 - 32 * h];
         }
       };
       frag(0, 0);
 #pragma unroll
-      for (int rr = 0; rr < FWD_CH; ++rr) {
-        if (rr + 1 < FWD_CH) frag(rr + 1, (rr + 1) & 1);
+      for (int grp = 0; grp < 5; ++grp) {
+        if (grp + 1 < 5) frag(grp + 1, (grp + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rr & 1][q], b0f[rr & 1][q], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rr & 1][q], b1f[rr & 1][q], acc[1], 0, 0, 0);
+        for (int s5 = 0; s5 < 5; ++s5) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[grp & 1][s5], b0f[grp & 1][s5], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[grp & 1][s5], b1f[grp & 1][s5], acc[1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -513,12 +521,12 @@ size_t stem_patch_floats(const avid_conv_desc* d, int tile) {
 }
 
 static size_t stem_fwd_lds(const avid_conv_desc* d, int tile) {
-  return sizeof(float) * (2 * FWD_CH * 8 * WS_LD + stem_patch_floats(d, tile));
+  return sizeof(float) * (2 * FK * WS_LD + stem_patch_floats(d, tile));
 }
 // forward tile: 128 pixels x 2 workgroups per CU when that fits, else 256 pixels x 1; 0 = neither
 static int stem_fwd_tile(const avid_conv_desc* d) {
-  // 16 float4 patch items per thread (the kernel's register prefetch)
-  if (stem_fwd_lds(d, 128) <= 80 * 1024 && stem_patch_floats(d, 128) <= 16 * 256 * 4) return 128;
+  // 14 / 16 float4 patch items per thread (the kernel's register prefetch)
+  if (stem_fwd_lds(d, 128) <= 80 * 1024 && stem_patch_floats(d, 128) <= 14 * 256 * 4) return 128;
   if (stem_fwd_lds(d, 256) <= 160 * 1024 && stem_patch_floats(d, 256) <= 16 * 512 * 4) return 256;
   return 0;
 }
@@ -536,7 +544,7 @@ bool stem_wgrad_supported(const avid_conv_desc* d) {
          d->Wi % 4 == 0 && (long long)d->Cin * d->Ti * d->Hi * d->Wi * 4 < (1ll << 31);
 }
 
-size_t stem_fwd_ws_bytes(const avid_conv_desc* d) { return sizeof(float) * (size_t)d->Cin * d->kt * 7 * 8 * 64; }
+size_t stem_fwd_ws_bytes(const avid_conv_desc* d) { return sizeof(float) * (size_t)d->Cin * d->kt * FK * 64; }
 int stem_wgrad_groups() { return 256; }
 size_t stem_wgrad_ws_bytes(const avid_conv_desc* d) {
   return sizeof(float) * (size_t)stem_wgrad_groups() * 64 * d->Cin * d->kt * 7 * 8;
@@ -548,8 +556,7 @@ static int stem_fwd_launch(const avid_conv_desc* d, const float* x, const float*
   StemArgs a{};
   stem_geometry(d, a, WAVES * 32);
   a.x = x; a.w = w; a.y = y; a.wt = static_cast<float*>(ws); a.stats = stats;
-  constexpr int R = CIN * KT * 7;
-  hipLaunchKernelGGL((stem_repack_kernel<CIN, KT>), dim3((R * 8 * 64 + 255) / 256), dim3(256), 0, s, w,
+  hipLaunchKernelGGL((stem_repack_kernel<CIN, KT>), dim3((CIN * KT * FK * 64 + 255) / 256), dim3(256), 0, s, w,
                      static_cast<float*>(ws));
   const size_t lds = stem_fwd_lds(d, WAVES * 32);
   static bool set = false;
