@@ -265,6 +265,45 @@ def test_avid_cma_vs_reference_golden(golden, gpu_device):
     np.testing.assert_allclose(na.view2_mem[y].cpu().numpy(), g["cma_v2rows"], rtol=2e-6, atol=2e-7)
 
 
+def test_avid_cma_all_four_terms_vs_reference_golden(golden, gpu_device):
+    """All four score groups active (tests/golden/cma_all.npz, generated from the reference): two steps, six loss
+    terms, carried Z, bank rows — the HIP criterion against the reference's own numbers."""
+    import criterions
+    from criterions.avid_cma import AVIDSimilarityPositiveExpansion
+    from criterions.nce import NCECriterion
+    g, gc = golden("cma_all"), golden("cma")
+    N, Pk, K, Kw, bs = 500, 32, 64, 16, 4
+    crit = criterions.AVID_CMA.__new__(criterions.AVID_CMA)
+    torch.nn.Module.__init__(crit)
+    na = AVIDSimilarityPositiveExpansion(memory_size=N, embedding_dim=128, num_negatives=K, num_negatives_within=Kw,
+                                         xModalInst=True, wModalInst=True, xModalPos=True, wModalPos=True,
+                                         sampling_args={"type": "consensus", "pos_k": Pk}, momentum=0.5,
+                                         device=gpu_device.index)
+    na.view1_mem.copy_(det_bank("cma:v1", N))
+    na.view2_mem.copy_(det_bank("cma:v2", N))
+    na.register_buffer("positive_set", T(gc["topk_consensus"]).int().to(gpu_device))
+    crit.nce_average = na
+    crit.xModalInstCoeff, crit.wModalInstCoeff, crit.xModalPosCoeff, crit.wModalPosCoeff = (float(c) for c in g["coeffs"])
+    crit.criterion = NCECriterion(N).to(gpu_device)
+    for step in range(2):
+        y = T(g[f"y{step}"]).to(gpu_device)
+        rand_idx = T(g[f"rand{step}"]).to(gpu_device)
+        na.multinomial.draw = lambda n, _r=rand_idx: _r.reshape(-1)
+        v = T(detgen.det_normalish(f"cma_all:v{step}", (bs, 128))).to(gpu_device).requires_grad_(True)
+        a = T(detgen.det_normalish(f"cma_all:a{step}", (bs, 128))).to(gpu_device).requires_grad_(True)
+        loss, tb = crit(v, a, y)
+        loss.backward()
+        assert sorted(tb.keys()) == list(g[f"tb_keys{step}"])
+        np.testing.assert_allclose(loss.item(), g[f"loss{step}"], rtol=5e-6)
+        np.testing.assert_allclose(float(crit.criterion.avg_exp_score), g[f"Z{step}"], rtol=5e-6)
+        for k in tb:
+            np.testing.assert_allclose(float(tb[k]), g[f"tb{step}_{k.replace('/', '_')}"], rtol=5e-6)
+        np.testing.assert_allclose(v.grad.cpu().numpy(), g[f"gv{step}"], rtol=2e-4, atol=2e-7)
+        np.testing.assert_allclose(a.grad.cpu().numpy(), g[f"ga{step}"], rtol=2e-4, atol=2e-7)
+        np.testing.assert_allclose(na.view1_mem[y].cpu().numpy(), g[f"v1rows{step}"], rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(na.view2_mem[y].cpu().numpy(), g[f"v2rows{step}"], rtol=2e-6, atol=2e-7)
+
+
 def test_full_step_vs_oracle_bs4(gpu_device):
     """BASELINE config 2 parity shape (bs=4, 3x8x112x112 + 1x40x100, K=1024) against the oracle:
     model fwd -> AVID (injected idx) -> bwd.  Loss to 1e-5, selected gradients to 2e-3 of scale."""
