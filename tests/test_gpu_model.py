@@ -304,6 +304,42 @@ def test_avid_cma_all_four_terms_vs_reference_golden(golden, gpu_device):
         np.testing.assert_allclose(na.view2_mem[y].cpu().numpy(), g[f"v2rows{step}"], rtol=2e-6, atol=2e-7)
 
 
+def test_criterion_checkpoint_restore(tmp_path, gpu_device):
+    """criterions/avid.py:187-200 / avid_cma.py:308-319: banks and the partition function are restored from the
+    'train_criterion' entry of an AVID checkpoint; Z is the MEAN of every '*avg_exp_score' entry and the reference
+    stores it with shape (1,) after the first step (the nce.py:35 quirk)."""
+    import criterions
+    N = 300
+    gen = torch.Generator().manual_seed(9)
+    v1 = torch.nn.functional.normalize(torch.randn(N, 128, generator=gen), dim=1)
+    v2 = torch.nn.functional.normalize(torch.randn(N, 128, generator=gen), dim=1)
+    ckp = {"train_criterion": {"nce_average.view1_mem": v1, "nce_average.view2_mem": v2,
+                               "criterion.avg_exp_score": torch.tensor([0.25]),
+                               "criterion_extra.avg_exp_score": torch.tensor([0.75])}}
+    path = str(tmp_path / "avid.pth.tar")
+    torch.save(ckp, path)
+    crit = criterions.AVID(num_data=N, embedding_dim=128, num_negatives=32, momentum=0.5, checkpoint=path,
+                           device=gpu_device.index)
+    assert torch.equal(crit.nce_average.view1_mem.cpu(), v1) and torch.equal(crit.nce_average.view2_mem.cpu(), v2)
+    np.testing.assert_allclose(float(crit.criterion.avg_exp_score), 0.5, rtol=1e-7)
+    cma = criterions.AVID_CMA(num_data=N, embedding_dim=128, num_negatives=32, num_negatives_within=8, momentum=0.5,
+                              sampling_args={"type": "consensus", "pos_k": 8}, checkpoint=path,
+                              device=gpu_device.index)
+    assert torch.equal(cma.nce_average.view1_mem.cpu(), v1)
+    np.testing.assert_allclose(float(cma.criterion.avg_exp_score), 0.5, rtol=1e-7)
+    want = O.cma_topk(v1, v2, 8, "consensus")                     # the constructor searched the RESTORED banks
+    got = cma.nce_average.positive_set.cpu().numpy()
+    assert np.mean([set(got[i]) == set(want[i]) for i in range(N)]) > 0.99
+    # a step with the restored Z does not re-estimate it
+    v = torch.randn(4, 128, device=gpu_device, requires_grad=True)
+    a = torch.randn(4, 128, device=gpu_device, requires_grad=True)
+    loss, _ = crit(v, a, torch.tensor([1, 5, 9, 200], device=gpu_device))
+    loss.backward()
+    np.testing.assert_allclose(float(crit.criterion.avg_exp_score), 0.5, rtol=1e-7)
+    sd = crit.state_dict()
+    assert sorted(sd) == ["criterion.avg_exp_score", "nce_average.view1_mem", "nce_average.view2_mem"]
+
+
 def test_full_step_vs_oracle_bs4(gpu_device):
     """BASELINE config 2 parity shape (bs=4, 3x8x112x112 + 1x40x100, K=1024) against the oracle:
     model fwd -> AVID (injected idx) -> bwd.  Loss to 1e-5, selected gradients to 2e-3 of scale."""

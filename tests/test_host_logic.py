@@ -114,3 +114,33 @@ def test_reference_factories_resolve_build_classes():
         sys.path.remove(ref)
         for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
             del sys.modules[k]
+
+
+def test_model_checkpoint_interchange(tmp_path):
+    """a reference-format checkpoint ('module.'-prefixed keys from the DataParallel wrapper,
+    plain-contiguous NCDHW fp32 tensors; models/av_wrapper.py:72-74, utils/main_utils.py:265-323) loads into the
+    build's channels-last parameters through ``av_wrapper(checkpoint=...)`` and saves back to tensors of the
+    reference's logical shapes and values."""
+    import models
+    from avid_hip import ops
+    src = models.av_wrapper("R2Plus1D", {"depth": 18}, "Conv2D", {"depth": 10}, proj_dim=[512, 512, 128])
+    gen = torch.Generator().manual_seed(5)
+    ref_sd = {}
+    for k, v in src.state_dict().items():      # what the reference would have saved: logical shape, plain contiguous
+        t = torch.randn(v.shape, generator=gen) if v.dtype.is_floating_point else torch.tensor(7, dtype=v.dtype)
+        ref_sd["module." + k] = t.contiguous()
+    path = str(tmp_path / "checkpoint.pth.tar")
+    torch.save({"epoch": 3, "model": ref_sd}, path)
+    m = models.av_wrapper("R2Plus1D", {"depth": 18}, "Conv2D", {"depth": 10}, proj_dim=[512, 512, 128],
+                          checkpoint=path)
+    back = m.state_dict()
+    assert ["module." + k for k in back] == list(ref_sd)
+    for k, v in back.items():
+        assert v.shape == ref_sd["module." + k].shape and torch.equal(v, ref_sd["module." + k]), k
+    for n, p in m.named_parameters():
+        if p.dim() == 5:
+            assert ops.weight_layout_ok(p), n                      # internal layout [Cout][kt][kh][kw][Cin] kept
+    # and the other way round: what this build saves loads into plain (reference-layout) tensors bit-exactly
+    torch.save({"model": {"module." + k: v for k, v in back.items()}}, path)
+    again = torch.load(path, map_location="cpu")["model"]
+    assert all(torch.equal(again["module." + k].contiguous(), ref_sd["module." + k]) for k in back)
