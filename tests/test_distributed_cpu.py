@@ -142,3 +142,33 @@ def test_cma_search_shards_query_rows_and_allgathers_in_rank_order():
     assert res[0][1] == [(0, 19)] and res[1][1] == [(19, 37)]
     for rank in range(2):
         assert res[rank][0].shape == (37, 4) and (res[rank][0] == want).all()
+
+
+def _broadcast_job(rank, world):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avid-cma_amd"))
+    from avid_hip.parallel import TrainStep
+    torch.manual_seed(1000 + rank)                              # ranks start from DIFFERENT weights / buffers
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.Linear(16, 4))
+    m[1].running_mean.fill_(float(rank + 1))
+    eng = TrainStep(m, criterion=None)
+    views_ok = all(p.data_ptr() == eng.flat.flat.data_ptr() + 4 * o for p, o in zip(eng.flat.params, eng.flat.offsets))
+    return eng.flat.flat.clone().numpy(), m[1].running_mean.clone().numpy(), views_ok, eng.buckets.world
+
+
+def test_trainstep_broadcasts_rank0_parameters_and_buffers():
+    """DDP's construction-time broadcast (utils/main_utils.py:112): every rank starts from rank 0's parameters and
+    buffers; the parameters are views of the flat buffer afterwards; the 1/world gradient scale is the group size."""
+    res = run2(_broadcast_job)
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
+    assert (res[1][1] == 1.0).all()                             # rank 0's buffer value
+    torch.manual_seed(1000)
+    ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.Linear(16, 4))
+    want = torch.cat([p.detach().reshape(-1) for p in reversed(list(ref.parameters()))])
+    got = torch.from_numpy(res[1][0])
+    assert got.numel() >= want.numel() and res[0][2] and res[1][2] and res[0][3] == 2
+    # flat layout: reverse registration order, every slice padded to 4 floats
+    off = 0
+    for p in reversed(list(ref.parameters())):
+        assert torch.equal(got[off:off + p.numel()], p.detach().reshape(-1))
+        off += (p.numel() + 3) // 4 * 4
