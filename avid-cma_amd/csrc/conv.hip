@@ -33,7 +33,8 @@ typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
   const float* __restrict__ src;     // [B,Ts,Hs,Ws,Cs] channels-last (vector path) or strided (gather path)
-  const float* __restrict__ wk;      // [Cd][ntaps][Cs]
+  const float* __restrict__ wk;      // [Cd][ntaps][Cs], rows w_row floats apart (a trimmed tap range of a wider row)
+  int w_row, w_nrec;                 // floats per weight row; bytes addressable from wk
   const float* __restrict__ addend;  // [M][Cd] or null
   const float* __restrict__ bias;    // [Cd] or null
   float* __restrict__ dst;           // [M][Cd]
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
   const __amdgpu_buffer_rsrc_t rsA =
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + a_base), 0, (int)a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.wk, 0, (int)((long long)p.Cd * ntaps * p.Cs * 4), 0x00020000);
+      (void*)p.wk, 0, p.w_nrec, 0x00020000);
 
   // ---- per-thread row bookkeeping (rows are fixed for the whole K loop)
   int a_t0[PA], a_h0[PA], a_w0[PA];
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(512) void igemm_kernel(const ConvArgs p) {
   }
   unsigned b_off[PB];
 #pragma unroll
-  for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + 32 * i) * ntaps * p.Cs + lcol) * 4;
+  for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + 32 * i) * p.w_row + lcol) * 4;
 
   floatx4 va[PA], vb[PB];
 
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   const int pix_per_b = p.Ts * p.Hs * p.Ws;
   const int pix_d = p.Td * p.Hd * p.Wd;
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.wk, 0, (int)((long long)p.Cd * ntaps * p.Cs * 4), 0x00020000);
+      (void*)p.wk, 0, p.w_nrec, 0x00020000);
 
   // ---- this workgroup's segments: whole tiles slot, slot+G, ... below pk_full, then at most one
   // (tile, K-range) piece of the split tail
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       a_base[i] = (unsigned)((((b - b_lo) * p.Ts + t0) * p.Hs + h0) * p.Ws + w0) * cs4 + lcol * 4;
     }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + RPP * i) * ntaps * p.Cs + lcol) * 4;
+    for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + RPP * i) * p.w_row + lcol) * 4;
     retap();
   };
   auto issue_loads = [&]() {   // k-tile (loader tile; tap, channel block) -> registers: PA + PB loads
@@ -1525,6 +1526,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// wgrad of a layer whose dead temporal taps were trimmed (trim_taps): the slabs hold [Cd][Kp] (the live taps), dw is
+// [Cd][K]: live columns [koff, koff + Kp) get the slab sums in split order, the dead taps' columns exact zeros.
+__global__ __launch_bounds__(256) void wgrad_reduce_scatter_kernel(const float* __restrict__ part,
+                                                                   float* __restrict__ dw, int Cd, int Kp, int K,
+                                                                   int koff, int nsplit) {
+  const long long n4 = (long long)Cd * K / 4, slab4 = (long long)Cd * Kp / 4;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int k4 = K / 4, kp4 = Kp / 4, ko4 = koff / 4;
+  const int n = (int)(i / k4), c = (int)(i - (long long)n * k4);
+  floatx4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c >= ko4 && c < ko4 + kp4) {
+    const long long j = (long long)n * kp4 + (c - ko4);
+    for (int k = 0; k < nsplit; ++k) s += reinterpret_cast<const floatx4*>(part)[(long long)k * slab4 + j];
+  }
+  reinterpret_cast<floatx4*>(dw)[i] = s;
+}
+
 // w[co][tap][ci] -> wT[ci][tap][co]
 __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int ntaps, int Ci) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2135,6 +2154,39 @@ static int launch_gather(const ConvArgs& a, hipStream_t s) {
   return check_launch("igemm_gather");
 }
 
+// Dead temporal taps.  conv5x of R(2+1)D-18 sees T = 1: of its (3,1,1) kernels' three taps two only ever meet the
+// zero padding (67 % of those layers' MFMAs multiplied zeros).  A tap dt is live if some output frame reads a real
+// input frame through it; the live range [dt0, dt0 + kt') is computed on the host and the layer runs as a
+// (kt',kh,kw) convolution with pad pt - dt0 whose weight rows are a window of the full rows (pitch = full row,
+// base offset = dt0 taps).  Vector (channels-last) layers on the persistent kernel only.
+struct Trim {
+  avid_conv_desc d;   // kt / pt replaced; everything downstream plans and launches from this
+  int dt0;            // first live temporal tap
+  int kt_full;        // the real kernel depth
+  bool on;
+};
+static Trim trim_taps(const avid_conv_desc* d) {
+  Trim t{*d, 0, d->kt, false};
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("AVID_TRIM_TAPS");
+    on = e ? atoi(e) != 0 : 1;
+  }
+  if (!on || !pk_enabled() || d->x_channel_first || d->kt <= 1 || d->Cin % 64 || d->Cout % 64) return t;
+  int lo = d->kt, hi = -1;
+  for (int dt = 0; dt < d->kt; ++dt)
+    for (int to = 0; to < d->To; ++to) {
+      const int ti = to * d->st + dt - d->pt;
+      if (ti >= 0 && ti < d->Ti) { lo = dt < lo ? dt : lo; hi = dt > hi ? dt : hi; break; }
+    }
+  if (hi < 0 || (lo == 0 && hi == d->kt - 1)) return t;
+  t.dt0 = lo;
+  t.d.kt = hi - lo + 1;
+  t.d.pt = d->pt - lo;
+  t.on = true;
+  return t;
+}
+
 static void fill_common(ConvArgs& a, const avid_conv_desc* d) {
   a.kt = d->kt; a.kh = d->kh; a.kw = d->kw;
   a.st = d->st; a.sh = d->sh; a.sw = d->sw;
@@ -2167,6 +2219,7 @@ int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin,
   a.Td = 1; a.Hd = 1; a.Wd = (int)M; a.Cd = N;
   a.M = (int)M;
   a.src = A; a.wk = Bq; a.addend = Cin; a.bias = nullptr; a.dst = Cout_;
+  a.w_row = K; a.w_nrec = (int)((long long)N * K * 4);
   a.mode = 0; a.relu = 0; a.epi_op = op;
   a.nsplit = 1; a.ksteps_per_split = 1 << 30; a.part = nullptr; a.ncls = 1; a.cls_ptiles_total = 0;
   a.mt2_begin = 0; a.mt2_count = (int)((((long long)M + 127) / 128 + 1) / 2); a.part_row_begin = 0;
@@ -2189,7 +2242,8 @@ extern "C" size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d) {
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
   if (!vec) return stem_fwd_supported(d) ? stem_fwd_ws_bytes(d) : 0;
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
-  const int nk = d->kt * d->kh * d->kw * (d->Cin / BK);
+  const Trim tr = trim_taps(d);
+  const int nk = tr.d.kt * d->kh * d->kw * (d->Cin / BK);
   return sizeof(float) * igemm_ws_floats(M, d->Cout, nk);
 }
 
@@ -2199,7 +2253,7 @@ extern "C" int avid_conv_fwd_stats_rows(const avid_conv_desc* d) {
   if (!vec) return stem_fwd_supported(d) ? stem_fwd_grid(d) : 0;     // LDS-patch stems: one row per workgroup
   if (!pk_enabled() || d->Cout > 1024 || (256 % (d->Cout / 4)) != 0) return 0;
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
-  const PkPlan pk = plan_pk(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK));
+  const PkPlan pk = plan_pk(M, d->Cout, trim_taps(d).d.kt * d->kh * d->kw * (d->Cin / BK));
   return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cout)) : 0);
 }
 
@@ -2211,9 +2265,16 @@ extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const floa
   AVID_REQUIRE(x && w && y, AVID_E_BADARG, "conv_fwd: null pointer");
   if (stem_fwd_supported(d) && !addend && !bias && !relu && ws && ws_bytes >= stem_fwd_ws_bytes(d))
     return stem_fwd(d, x, w, y, bn_partials, ws, (hipStream_t)stream);
+  const Trim tr = trim_taps(d);
   ConvArgs a;
-  fill_common(a, d);
-  a.src = x; a.wk = w; a.addend = addend; a.bias = bias; a.dst = y;
+  fill_common(a, &tr.d);
+  a.src = x; a.addend = addend; a.bias = bias; a.dst = y;
+  {   // weights: the live temporal taps of every [kt][kh][kw][Cin] row
+    const long long tapsz = (long long)d->kh * d->kw * d->Cin, off = tr.dt0 * tapsz;
+    a.wk = w + off;
+    a.w_row = (int)(tr.kt_full * tapsz);
+    a.w_nrec = (int)(((long long)d->Cout * a.w_row - off) * 4);
+  }
   a.Ts = d->Ti; a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Cin;
   a.Td = d->To; a.Hd = d->Ho; a.Wd = d->Wo; a.Cd = d->Cout;
   a.M = d->B * d->To * d->Ho * d->Wo;
@@ -2237,7 +2298,7 @@ static size_t dgrad_wt_bytes(const avid_conv_desc* d) {
 extern "C" size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
-  const int nk = d->kt * d->kh * d->kw * (d->Cout / BK);
+  const int nk = trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK);
   size_t fl = igemm_ws_floats(M, d->Cin, nk);
   if (d->st > 1 || d->sh > 1 || d->sw > 1) {   // strided: K pieces of the parity-class tiles (dispatch_igemm<1>)
     const int ntn = d->Cin % 128 == 0 ? d->Cin / 128 : d->Cin / 64;
@@ -2269,8 +2330,9 @@ extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
   if (d->st > 1 || d->sh > 1 || d->sw > 1) {   // strided: the plan of dispatch_igemm<1>'s parity-class branch
     if (M * d->Cin * 4 >= (1ll << 31)) return 0;
+    const Trim tr = trim_taps(d);
     ConvArgs a;
-    fill_common(a, d);
+    fill_common(a, &tr.d);
     a.Td = d->Ti; a.Hd = d->Hi; a.Wd = d->Wi; a.Cd = d->Cin;
     const int BN = d->Cin % 128 == 0 ? 128 : 64;
     const int total = build_classes_pk(a, 128, d->Cin / BN);
@@ -2278,7 +2340,7 @@ extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
     if (f > 1) return (int)ceil_div(M, stats_rpb(M, d->Cin));
     return total < 2 * device_cus() ? total : 2 * device_cus();
   }
-  const PkPlan pk = plan_pk(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK));
+  const PkPlan pk = plan_pk(M, d->Cin, trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK));
   return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cin)) : 0);
 }
 
@@ -2316,9 +2378,16 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
     if (rc) return rc;
     wt = wt_ws;
   }
+  const Trim tr = trim_taps(d);
   ConvArgs a;
-  fill_common(a, d);
-  a.src = dy; a.wk = wt; a.addend = addend; a.bias = nullptr; a.dst = dx;
+  fill_common(a, &tr.d);
+  a.src = dy; a.addend = addend; a.bias = nullptr; a.dst = dx;
+  {   // transposed weights [Cin][kt][kh][kw][Cout]: the live temporal taps of every row
+    const long long tapsz = (long long)d->kh * d->kw * d->Cout, off = tr.dt0 * tapsz;
+    a.wk = wt + off;
+    a.w_row = (int)(tr.kt_full * tapsz);
+    a.w_nrec = (int)(((long long)d->Cin * a.w_row - off) * 4);
+  }
   a.Ts = d->To; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
   a.Td = d->Ti; a.Hd = d->Hi; a.Wd = d->Wi; a.Cd = d->Cin;
   a.M = d->B * d->Ti * d->Hi * d->Wi;
@@ -2374,8 +2443,9 @@ static WgradPlan wgrad_plan(const avid_conv_desc* d) {
 
 extern "C" size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
-  WgradPlan pl = wgrad_plan(d);
-  size_t nb = sizeof(float) * (size_t)pl.nsplit * d->Cout * d->kt * d->kh * d->kw * d->Cin;
+  const Trim tr = trim_taps(d);      // (a trimmed layer always goes through slabs: the reduce scatters them into dw)
+  WgradPlan pl = wgrad_plan(&tr.d);
+  size_t nb = sizeof(float) * (size_t)pl.nsplit * d->Cout * tr.d.kt * d->kh * d->kw * d->Cin;
   if (stem_wgrad_supported(d) && stem_wgrad_ws_bytes(d) > nb) nb = stem_wgrad_ws_bytes(d);
   return nb;
 }
@@ -2387,13 +2457,17 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
   AVID_REQUIRE(x && dy && dw, AVID_E_BADARG, "conv_wgrad: null pointer");
   if (stem_wgrad_supported(d) && ws && ws_bytes >= stem_wgrad_ws_bytes(d))
     return stem_wgrad(d, x, dy, dw, ws, (hipStream_t)stream);
+  Trim tr = trim_taps(d);
+  if (tr.on && !(ws && ws_bytes >= avid_conv_wgrad_workspace_bytes(d))) tr = Trim{*d, 0, d->kt, false};   // no scratch
+  const avid_conv_desc* dfull = d;
+  d = &tr.d;                         // from here on: the (possibly trimmed) layer
   WgradPlan pl = wgrad_plan(d);
-  AVID_REQUIRE(pl.nsplit == 1 || (ws && ws_bytes >= avid_conv_wgrad_workspace_bytes(d)), AVID_E_BADARG,
+  AVID_REQUIRE(pl.nsplit == 1 || (ws && ws_bytes >= avid_conv_wgrad_workspace_bytes(dfull)), AVID_E_BADARG,
                "conv_wgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   WgradArgs a;
   a.src = x; a.dy = dy;
-  a.out = pl.nsplit == 1 ? dw : static_cast<float*>(ws);
+  a.out = (pl.nsplit == 1 && !tr.on) ? dw : static_cast<float*>(ws);
   a.B = d->B; a.Ts = d->Ti; a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Cin;
   a.Td = d->To; a.Hd = d->Ho; a.Wd = d->Wo; a.Cd = d->Cout;
   a.kt = d->kt; a.kh = d->kh; a.kw = d->kw;
@@ -2438,6 +2512,14 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
   }
   rc = check_launch("wgrad");
   if (rc) return rc;
+  if (tr.on) {   // live taps' slabs -> their columns of dw, zeros for the dead taps
+    const int tap = d->kh * d->kw * d->Cin, Kp = d->kt * tap, K = tr.kt_full * tap, koff = tr.dt0 * tap;
+    const long long n4 = (long long)d->Cout * K / 4;
+    ScopedTimer t(s, "wgrad_reduce_kernel", 0.0, 4.0 * ((double)d->Cout * Kp * pl.nsplit + (double)d->Cout * K));
+    hipLaunchKernelGGL(wgrad_reduce_scatter_kernel, dim3((unsigned)ceil_div(n4, 256)), dim3(256), 0, s,
+                       static_cast<const float*>(ws), dw, d->Cout, Kp, K, koff, pl.nsplit);
+    return check_launch("wgrad_reduce_scatter");
+  }
   if (pl.nsplit > 1) {
     const long long n = (long long)d->Cout * d->kt * d->kh * d->kw * d->Cin;
     ScopedTimer t(s, "wgrad_reduce_kernel", 0.0, 4.0 * n * (pl.nsplit + 1));
@@ -2453,6 +2535,8 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
   if (rc) return rc;
   AVID_REQUIRE(buf && len > 0 && which >= 0 && which <= 2, AVID_E_BADARG, "conv_kernel_name: bad argument");
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
+  const Trim tr = trim_taps(d);
+  const int ktl = tr.d.kt;           // live temporal taps
   auto pk_name = [&](long long M, int Cd, int nk, int mode) {
     const PkPlan pk = plan_pk(M, Cd, nk);
     static const char* kPk[] = {"2,2,2,2", "4,1,1,2", "4,2,2,2", "4,2,2,1"};
@@ -2466,7 +2550,7 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
       else
         snprintf(buf, len, "igemm_gather_kernel<%s>", ((M + 127) / 128) * (d->Cout / 64) >= 256 ? "4,1,1,2" : "2,2,1,1");
     } else if (pk_enabled()) {
-      pk_name(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK), 0);
+      pk_name(M, d->Cout, ktl * d->kh * d->kw * (d->Cin / BK), 0);
     } else {
       IgemmPlan pl = plan_igemm(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK), true);
       snprintf(buf, len, "igemm_kernel<%s,0> splitk=%d", kTileName[pl.tile], pl.nsplit);
@@ -2477,13 +2561,13 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
     if (pk_enabled() && strided) {
       snprintf(buf, len, "igemm_pk_kernel<%s,1>s2 (stride-parity classes)", d->Cin % 128 == 0 ? "2,2,2,2" : "4,1,1,2");
     } else if (pk_enabled()) {
-      pk_name(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK), 1);
+      pk_name(M, d->Cin, ktl * d->kh * d->kw * (d->Cout / BK), 1);
     } else {
       IgemmPlan pl = plan_igemm(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK), true);
       snprintf(buf, len, "igemm_kernel<%s,1> splitk=%d", kTileName[pl.tile], pl.nsplit);
     }
   } else {
-    WgradPlan pl = wgrad_plan(d);
+    WgradPlan pl = wgrad_plan(&tr.d);
     if (!pl.vec)
       snprintf(buf, len, stem_wgrad_supported(d) ? "stem_wgrad_kernel splits=%d" : "wgrad_gather_kernel splits=%d", pl.nsplit);
     else

@@ -46,6 +46,11 @@ CONV_CASES = [
     ("big_ragged_333", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (5, 7, 45, 47)),
     # persistent kernel alone, last round 80 % full and ragged (run unbalanced)
     ("big_unbalanced", 64, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (7, 8, 45, 47)),
+    # dead temporal taps (conv5x of R(2+1)D-18): T = 1 with a (3,1,1) kernel -> only the centre tap is live;
+    # T = 2 -> 1 at stride 2 -> the first tap is dead; (3,3,3) on T = 1; the trimmed layers run as narrower kernels
+    ("dead_taps_T1", 512, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (16, 1, 4, 4)),
+    ("dead_taps_T2_s2", 128, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0), (8, 2, 4, 4)),
+    ("dead_taps_333_T1", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (4, 1, 6, 7)),
 ]
 
 
