@@ -8,7 +8,8 @@
 // in LDS, and feeds the fp32 MFMA straight from it:
 //     A[pixel i][k'] = patch[plane(c,dt)][2*(ho_i - ho_lo) + dh][2*wo_i + dw]
 // so a lane reads patch[base_i + dh*PW + dw] — one ds_read_b32 per MFMA pair, no address tables.
-// wgrad:   k' = ((c*kt + dt)*7 + dh)*8 + dw   (dw padded 7 -> 8: k' tiles of 32 = 4 kernel rows; 441 of 504 useful)
+// wgrad:   k' = (c*kt + dt)*49 + dh*7 + dw   (dense: k' is the GEMM-N dimension; 441 of 448; the audio stem keeps
+//          the older ((c*kt + dt)*7 + dh)*8 + dw with dw padded 7 -> 8)
 // forward: k' = (c*kt + dt)*50 + dh*7 + dw    (the 49 taps of a plane flattened, padded to 50: 441 of 450 useful);
 //          weights repacked once per call to Wt[k'][64] and streamed through a double-buffered LDS stage, one
 //          plane (25 k-steps) per chunk.
@@ -281,12 +282,17 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const S
 //   A[i = n][k = pixel] = dyS[pixel][n]         (LDS, [256][64+4])
 //   B[k = pixel][j = k'] = patch[pixbase[pixel] + koff(k'_j)]
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int KT>
+// DENSE (the video stem, 441 taps): k' = (c*kt+dt)*49 + dh*7 + dw without the 7 -> 8 padding: 14 k' tiles instead of
+// 16.  14 x 2 (n-tiles) = 28 accumulator tiles do not split evenly over 8 identical waves, so the waves take two
+// roles: waves 0-3 own 2 n-tiles x 2 k'-tiles (k' tiles 0-7), waves 4-7 own 1 n-tile x 3 k'-tiles (k' tiles 8-13);
+// waves w and w + 4 share a SIMD, which then issues 7 MFMAs per k-step instead of 8 (12.5 % fewer).
+template <int CIN, int KT, bool DENSE>
 __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
   constexpr int R = CIN * KT * 7;
-  constexpr int KP = R * 8;                       // padded k' count
+  constexpr int KP = DENSE ? (CIN * KT * 49 + 31) / 32 * 32 : R * 8;   // k' columns of a slab
   constexpr int NKT_ALL = (KP + 31) / 32;         // k' tiles of 32
-  constexpr int NKT = (NKT_ALL + 7) / 8;          // k' tiles per wave
+  constexpr int NKT = DENSE ? 3 : (NKT_ALL + 7) / 8;   // k' tiles per wave (DENSE: 2 or 3 by role)
+  static_assert(!DENSE || NKT_ALL == 14, "the two-role split is laid out for 14 k' tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ds = smem;                               // [256][WS_LD]
   int* pixbase = reinterpret_cast<int*>(smem + STEM_TILE * WS_LD);   // [256]
@@ -295,23 +301,29 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
   const int h = lane >> 5, l31 = lane & 31;
   const int npix = p.Ho * p.Wo;
 
-  // this lane's k' columns: tile kt = wave + 8*j -> k' = kt*32 + l31 ; koff = patch offset of that tap
+  // this lane's k' columns: k' = tile*32 + l31 ; koff = patch offset of that tap
+  const bool big = !DENSE || wave < 4;            // role (wave-uniform)
+  const int nb = DENSE ? (big ? 2 : 3) : NKT;     // k' tiles of this wave
+  const int nsel = DENSE && !big ? ((wave - 4) & 1) : 0;   // the one n-tile of a small wave
+  auto tile_of = [&](int j) {
+    if (!DENSE) return wave + 8 * j;
+    return big ? 2 * wave + j : 8 + 3 * ((wave - 4) >> 1) + j;
+  };
   int koff[NKT];
   bool kok[NKT];
 #pragma unroll
   for (int j = 0; j < NKT; ++j) {
-    const int kp = (wave + 8 * j) * 32 + l31;
-    kok[j] = kp < KP && (kp & 7) < 7;
+    const int kp = tile_of(j) * 32 + l31;
+    kok[j] = j < nb && (DENSE ? kp < CIN * KT * 49 : (kp < KP && (kp & 7) < 7));
     koff[j] = 0;
   }
 
-  floatx16 acc[2][NKT];
+  constexpr int NACC = DENSE ? 4 : 2 * NKT;       // accumulator tiles per wave: [n-tile][k'-tile] (big) / [k'-tile] (small)
+  floatx16 acc[NACC];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
-    for (int j = 0; j < NKT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   // The next tile's patch and dy rows are fetched into registers while the current tile is multiplied and
   // written to LDS between the two barriers that separate tiles: the global-load phase (a quarter of this
@@ -388,9 +400,19 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < NKT; ++j) {
-      const int kp = (wave + 8 * j) * 32 + l31;
-      const int dw = kp & 7, row = kp >> 3;
-      const int dh = row % 7, pl = row / 7;
+      const int kp = tile_of(j) * 32 + l31;
+      int dw, dh, pl;
+      if (DENSE) {
+        pl = kp / 49;
+        const int f = kp - pl * 49;
+        dh = f / 7;
+        dw = f - dh * 7;
+      } else {
+        dw = kp & 7;
+        const int row = kp >> 3;
+        dh = row % 7;
+        pl = row / 7;
+      }
       koff[j] = kok[j] ? pl * plane + dh * p.PW + dw : 0;
     }
     __syncthreads();
@@ -400,64 +422,74 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
     // two k-steps per trip so the register sets ping-pong without copies).  Lanes of the padded / out-of-range
     // k' columns read patch word pb + 0: their accumulator columns are never read (stem_wgrad_reduce_kernel
     // skips dw == 7, the slab write skips k' >= KP), so no select is spent on them.
-    float a0[2], a1[2], bv[2][NKT];
     const float* dsp = Ds + h * WS_LD + l31;        // this lane's dy column, row 2*kk + h (odd rows: halves swapped)
     const int c0 = 32 * h, c1 = 32 - 32 * h;
     const int* pbp = pixbase + h;
     const int nkk = (p.tile_px + 3) / 4 * 2;      // k-steps (pixel pairs), even; rows past the tile are zero dy rows
-    int pbn;
-    {
-      const int pb0 = pbp[0];
-      a0[0] = dsp[c0];
-      a1[0] = dsp[c1];
+    auto kloop = [&](auto BIG) {
+      constexpr bool B_ = decltype(BIG)::value;
+      constexpr int NBv = DENSE ? (B_ ? 2 : 3) : NKT;    // patch operands per k-step
+      const int cs = (DENSE && !B_) ? (nsel ? c1 : c0) : c0;   // small wave: its one dy column block
+      float a0[2], a1[2], bv[2][NBv];
+      int pbn;
+      {
+        const int pb0 = pbp[0];
+        a0[0] = dsp[cs];
+        if (B_) a1[0] = dsp[c1];
 #pragma unroll
-      for (int j = 0; j < NKT; ++j) bv[0][j] = P[pb0 + koff[j]];
-      pbn = pbp[2];
-    }
-    auto step = [&](int kk, int cur) {   // MFMAs of k-step kk from set `cur`; operands of kk+1 into the other set
-      const int nx = cur ^ 1;
-      const int r1 = 2 * min(kk + 1, nkk - 1), r2 = 2 * min(kk + 2, nkk - 1);
-      a0[nx] = dsp[r1 * WS_LD + c0];
-      a1[nx] = dsp[r1 * WS_LD + c1];
-#pragma unroll
-      for (int j = 0; j < NKT; ++j) bv[nx][j] = P[pbn + koff[j]];
-      pbn = pbp[r2];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < NKT; ++j) {
-        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], bv[cur][j], acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], bv[cur][j], acc[1][j], 0, 0, 0);
+        for (int j = 0; j < NBv; ++j) bv[0][j] = P[pb0 + koff[j]];
+        pbn = pbp[2];
       }
-      __builtin_amdgcn_sched_barrier(0);
+      auto step = [&](int kk, int cur) {   // MFMAs of k-step kk from set `cur`; operands of kk+1 into the other set
+        const int nx = cur ^ 1;
+        const int r1 = 2 * min(kk + 1, nkk - 1), r2 = 2 * min(kk + 2, nkk - 1);
+        a0[nx] = dsp[r1 * WS_LD + cs];
+        if (B_) a1[nx] = dsp[r1 * WS_LD + c1];
+#pragma unroll
+        for (int j = 0; j < NBv; ++j) bv[nx][j] = P[pbn + koff[j]];
+        pbn = pbp[r2];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NBv; ++j) {
+          if (B_) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], bv[cur][j], acc[j], 0, 0, 0);
+            acc[NBv + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[cur], bv[cur][j], acc[NBv + j], 0, 0, 0);
+          } else {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[cur], bv[cur][j], acc[j], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      for (int kk = 0; kk < nkk; kk += 2) {
+        step(kk, 0);
+        step(kk + 1, 1);
+      }
     };
-    for (int kk = 0; kk < nkk; kk += 2) {
-      step(kk, 0);
-      step(kk + 1, 1);
-    }
+    if (big) kloop(std::true_type{}); else kloop(std::false_type{});
   }
-  // partial slab [blockIdx.x][n][k']
+  // partial slab [blockIdx.x][n][k']   (accumulator tile a: big wave -> n-tile a / nb, k' tile a % nb; small -> nsel, a)
   float* o = p.part + (long long)blockIdx.x * 64 * KP;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int a = 0; a < NACC; ++a) {
+    const int t = big ? a / (DENSE ? 2 : NKT) : nsel, j = big ? a % (DENSE ? 2 : NKT) : a;
+    if (!big && a >= 3) continue;
+    const int kp = tile_of(j) * 32 + l31;
+    if (kp < KP) {
 #pragma unroll
-    for (int j = 0; j < NKT; ++j) {
-      const int kp = (wave + 8 * j) * 32 + l31;
-      if (kp < KP) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          o[(long long)n * KP + kp] = acc[t][j][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int n = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        o[(long long)n * KP + kp] = acc[a][r];
       }
     }
+  }
 }
 
 // dw[n][dt][dh][dw][c] = sum_g part[g][n][k'(c,dt,dh,dw)] — block = 32 elements x 8 slices of the G partials,
 // 4 independent streams per thread (a single chain of G = 256 loads per thread took 111 us); fixed order.
-template <int CIN, int KT>
+template <int CIN, int KT, bool DENSE>
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                 int G) {
-  constexpr int R = CIN * KT * 7, KP = R * 8;
+  constexpr int R = CIN * KT * 7, KP = DENSE ? (CIN * KT * 49 + 31) / 32 * 32 : R * 8;
   __shared__ float sh[8][32];
   const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + e;     // over n * K (K = R*7)
@@ -470,7 +502,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
     const int dh = r % 7; r /= 7;
     const int dt = r % KT;
     const int n = r / KT;
-    const int kp = (((c * KT + dt) * 7 + dh) * 8) + dwi;
+    const int kp = DENSE ? (c * KT + dt) * 49 + dh * 7 + dwi : (((c * KT + dt) * 7 + dh) * 8) + dwi;
     const float* q = part + (long long)n * KP + kp;
     const long long st = 64ll * KP;
     int g = sl;
@@ -585,7 +617,7 @@ static int stem_wgrad_launch(const avid_conv_desc* d, const float* x, const floa
   const size_t lds = stem_wgrad_lds(d);
   static bool set = false;
   if (!set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_kernel<CIN, KT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_kernel<CIN, KT, (CIN * KT * 49 > 64)>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     set = true;
   }
@@ -593,12 +625,12 @@ static int stem_wgrad_launch(const avid_conv_desc* d, const float* x, const floa
   {
     ScopedTimer t(s, CIN == 3 ? "stem_wgrad_kernel<3,3>" : "stem_wgrad_kernel<1,1>", 2.0 * M * 64 * K,
                   4.0 * ((double)d->B * CIN * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
-    hipLaunchKernelGGL((stem_wgrad_kernel<CIN, KT>), dim3(G), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((stem_wgrad_kernel<CIN, KT, (CIN * KT * 49 > 64)>), dim3(G), dim3(512), lds, s, a);
   }
   int rc = check_launch("stem_wgrad");
   if (rc) return rc;
   const int n = 64 * CIN * KT * 49;
-  hipLaunchKernelGGL((stem_wgrad_reduce_kernel<CIN, KT>), dim3((n + 31) / 32), dim3(256), 0, s,
+  hipLaunchKernelGGL((stem_wgrad_reduce_kernel<CIN, KT, (CIN * KT * 49 > 64)>), dim3((n + 31) / 32), dim3(256), 0, s,
                      static_cast<const float*>(ws), dw, G);
   return check_launch("stem_wgrad_reduce");
 }
