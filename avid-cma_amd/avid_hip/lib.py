@@ -88,8 +88,8 @@ SIGNATURES = {
     "avid_conv_kernel_name": (_i, [_dp, _i, C.c_char_p, _i]),
     "avid_bn_workspace_bytes": (_sz, [_i64, _i]),
     "avid_bn_fwd_train": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
-    "avid_bn_fwd_eval": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
-    "avid_bn_bwd": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "avid_bn_fwd_eval": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "avid_bn_bwd": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "avid_bn_relu_maxpool_fwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _i, _vp, _sz, _vp]),
     "avid_bn_relu_maxpool_bwd": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
@@ -109,17 +109,17 @@ SIGNATURES = {
     "avid_l2norm_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "avid_alias_draw": (_i, [_i64, _i64, _vp, _vp, _i, _u64, _u64, _vp, _vp, _i64, _vp, _vp]),
     "avid_counter_add": (_i, [_vp, _u64, _vp]),
-    "avid_bank_scores_fwd": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "avid_bank_scores_fwd": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "avid_bank_scores_bwd": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
     "avid_mean_exp": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "avid_nce_workspace_bytes": (_sz, []),
     "avid_nce_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _i, _vp, _vp, _sz, _vp]),
     "avid_nce_bwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),
-    "avid_bank_update": (_i, [_i, _i, _i64, _vp, _vp, _vp, _f, _vp]),
-    "avid_cma_negatives": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "avid_bank_update": (_i, [_i, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp]),
+    "avid_cma_negatives": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avid_cma_topk_workspace_bytes": (_sz, [_i64, _i, _i]),
-    "avid_cma_topk": (_i, [_i64, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "avid_adam_flat": (_i, [_i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i64, _vp, _f, _vp]),
+    "avid_cma_topk": (_i, [_i64, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "avid_adam_flat": (_i, [_i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i64, _vp, _vp, _f, _vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -64,6 +64,74 @@ def workspace(device, nbytes):
 
 
 # ------------------------------------------------------------------------------------------------
+# device-side index errors (include/avid_hip.h AVID_DEVERR_*)
+# ------------------------------------------------------------------------------------------------
+class DeviceErrors:
+    """One int32 error word per device that the gather / scatter kernels OR a code into when they meet an id
+    outside [0, N) — where the reference's indexing raises (criterions/avid.py:57-62,124; avid_cma.py:199).
+
+    ``poll()`` never synchronises: it looks at the copy of the word that the PREVIOUS poll sent to pinned host
+    memory (if that copy has landed), raises ``IndexError`` if it is non-zero, and starts the next copy.  The
+    criterion polls at the start and at the end of every forward, so a corrupt ``index`` surfaces within about one
+    step (as soon as the host sees the copy that followed the offending kernels); ``check()`` is the blocking
+    form for callers that synchronise anyway (``loss.item()``)."""
+    _MSG = {1: "bank_scores: negative / positive index outside [0, num_data)",
+            2: "update_memory: sample index outside [0, num_data)",
+            4: "memory_sampling: sample index outside [0, num_data) (positive_set lookup)"}
+    _inst = {}
+
+    def __init__(self, device):
+        self.flag = torch.zeros((), dtype=torch.int32, device=device)
+        self.host = torch.zeros((), dtype=torch.int32).pin_memory()
+        self.event = None
+
+    @classmethod
+    def get(cls, device):
+        inst = cls._inst.get(device.index)
+        if inst is None:
+            inst = cls._inst[device.index] = cls(device)
+        return inst
+
+    def ptr(self):
+        return C.c_void_p(self.flag.data_ptr())
+
+    def _raise(self, code):
+        self.flag.zero_()
+        self.host.zero_()
+        self.event = None
+        what = "; ".join(m for b, m in self._MSG.items() if code & b) or f"code {code}"
+        raise IndexError(f"avid_hip: index out of range in a device kernel — {what}")
+
+    def poll(self):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self.event is not None:
+            if not self.event.query():
+                return                      # the previous copy is still in flight: look again next time
+            code = int(self.host)
+            if code:
+                self._raise(code)
+        self.host.copy_(self.flag, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def check(self):
+        code = int(self.flag.item())
+        if code:
+            self._raise(code)
+
+
+def poll_device_errors(device):
+    DeviceErrors.get(device).poll()
+
+
+def check_device_errors(device=None):
+    """Blocking check of the device error word (synchronises the current stream)."""
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    DeviceErrors.get(device).check()
+
+
+# ------------------------------------------------------------------------------------------------
 # weights
 # ------------------------------------------------------------------------------------------------
 def make_weight(cout, cin, *k):
@@ -249,10 +317,10 @@ class BnSource:
     output: the conv's input-gradient kernel then also produces the BatchNorm's backward partial sums (while the
     gradient is in registers) and leaves them here; the BatchNorm's backward, which autograd runs next, takes
     them instead of making its own pass over dy and x.  One object per forward call."""
-    __slots__ = ("x", "stats4", "relu", "partials")
+    __slots__ = ("x", "stats4", "relu", "partials", "dx_ptr")
 
     def __init__(self, x, stats4, relu):
-        self.x, self.stats4, self.relu, self.partials = x, stats4, relu, None
+        self.x, self.stats4, self.relu, self.partials, self.dx_ptr = x, stats4, relu, None, 0
 
 
 class _ConvCL(Function):
@@ -353,6 +421,7 @@ class _ConvCL(Function):
             if src is not None and FUSE_BN_BWD and d.bn_bwd_rows > 0 and src.x.shape == x.shape:
                 # dx is the whole gradient of the BatchNorm output x: its backward partial sums ride along
                 src.partials = torch.empty((d.bn_bwd_rows, 2, d.Cin), dtype=torch.float32, device=x.device)
+                src.dx_ptr = dx.data_ptr()       # the BatchNorm's backward verifies that THIS tensor is its dy
                 s4 = src.stats4
                 fuse = lib.BnBwdFuse(_p(src.x), _p(s4[2]), _p(s4[3]), _p(s4[0]), _p(s4[1]), int(src.relu),
                                      _p(src.partials))
@@ -425,16 +494,21 @@ class _BatchNormCL(Function):
             if src is not None:
                 src.x, src.stats4, src.relu = x, stats4, relu
         else:
+            # eval mode; when a gradient can flow (fine-tuning with frozen BatchNorm) the coefficients are kept
+            grad = any(ctx.needs_input_grad[:3])
+            stats4 = torch.empty((4, Cc), dtype=torch.float32, device=x.device) if grad else None
             lib.call("avid_bn_fwd_eval", M, Cc, _p(x), _p(gamma), _p(beta), _p(rm), _p(rv), float(eps), int(relu),
-                     _p(y), st)
-            ctx.save_for_backward()
+                     _p(y), _p(stats4), st)
+            if grad:
+                ctx.save_for_backward(x, gamma, stats4)
+                ctx.beta_ptr = beta.data_ptr()
+            else:
+                ctx.save_for_backward()
         ctx.training, ctx.relu, ctx.M, ctx.C = training, relu, M, Cc
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        if not ctx.training:
-            raise AvidHipError("bn: backward through eval-mode BatchNorm is not implemented")
         x, gamma, stats4 = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(x)
@@ -444,9 +518,15 @@ class _BatchNormCL(Function):
         part = None
         if ctx.src is not None:           # left by the dgrad kernel that produced dy (see BnSource)
             part, ctx.src.partials = ctx.src.partials, None
+            # The hand-over is only valid if that dgrad's output IS this BatchNorm's whole output gradient.  A
+            # second consumer of the activation (a hook, a custom block, an intermediate in the loss) makes
+            # autograd sum the gradients into a NEW tensor: then the partial sums cover one branch only and the
+            # unfused pass over dy and x runs instead.
+            if part is not None and dy.data_ptr() != ctx.src.dx_ptr:
+                part = None
         lib.call("avid_bn_bwd", ctx.M, ctx.C, _p(x), _p(dy), _p(gamma), _p(stats4[0]), _p(stats4[1]), _p(stats4[2]),
                  _p(stats4[3]), int(ctx.relu), _p(dx), _p(dgamma), _p(dbeta), _p(part),
-                 0 if part is None else part.shape[0], _p(ws), ws.numel(), _stream())
+                 0 if part is None else part.shape[0], 0 if ctx.training else 1, _p(ws), ws.numel(), _stream())
         if sg is not None:
             _grad_done(sg)
             dgamma = None
@@ -656,6 +736,7 @@ class _BankScores(Function):
     @staticmethod
     def forward(ctx, emb, bank, idx, inv_T):
         _need_cuda(emb, bank, idx)
+        need_rows = ctx.needs_input_grad[0]      # (decided before .contiguous(): its copy would not require grad)
         emb = emb.contiguous()
         idx = idx.contiguous()
         if idx.dtype != torch.int64 or not bank.is_contiguous():
@@ -665,9 +746,9 @@ class _BankScores(Function):
         s = torch.empty((bs, R), dtype=torch.float32, device=emb.device)
         # The reference's autograd keeps the PRE-update rows (the bank is EMA-updated inside forward,
         # criterions/avid.py:78, before backward runs): snapshot them while they stream through.
-        rows = torch.empty((bs, R, D), dtype=torch.float32, device=emb.device) if emb.requires_grad else None
+        rows = torch.empty((bs, R, D), dtype=torch.float32, device=emb.device) if need_rows else None
         lib.call("avid_bank_scores_fwd", bs, R, D, bank.shape[0], _p(idx), _p(bank), _p(emb), float(inv_T), _p(s),
-                 _p(rows), _stream())
+                 _p(rows), DeviceErrors.get(emb.device).ptr(), _stream())
         ctx.save_for_backward(rows)
         ctx.inv_T, ctx.dims = inv_T, (bs, R, D)
         return s
@@ -762,7 +843,7 @@ def alias_draw(n, K, prob, alias, uniform, seed, offset, y=None, per_row=1, devi
 def bank_update(bank, y, emb, momentum):
     _need_cuda(bank, y, emb)
     lib.call("avid_bank_update", y.shape[0], bank.shape[1], bank.shape[0], _p(bank), _p(y.contiguous()),
-             _p(emb.contiguous()), float(momentum), _stream())
+             _p(emb.contiguous()), float(momentum), DeviceErrors.get(bank.device).ptr(), _stream())
 
 
 def cma_negatives(positive_set, y, rand_idx):
@@ -771,17 +852,19 @@ def cma_negatives(positive_set, y, rand_idx):
     P = positive_set.shape[1]
     pos = torch.empty((bs, P), dtype=torch.int64, device=y.device)
     neg = torch.empty((bs, K), dtype=torch.int64, device=y.device)
-    lib.call("avid_cma_negatives", bs, K, P, _p(positive_set), _p(y.contiguous()), _p(rand_idx.contiguous()),
-             _p(pos), _p(neg), _stream())
+    lib.call("avid_cma_negatives", bs, K, P, positive_set.shape[0], _p(positive_set), _p(y.contiguous()),
+             _p(rand_idx.contiguous()), _p(pos), _p(neg), DeviceErrors.get(y.device).ptr(), _stream())
     return pos, neg
 
 
-def adam_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, step_dev=None):
+def adam_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, step_dev=None, lr_dev=None):
     """``step_dev`` (optional 0-d int64 device tensor): advanced by one on the stream, then read by the
-    kernel for the bias corrections (hipGraph-replay safe); otherwise ``step`` is used by value."""
+    kernel for the bias corrections (hipGraph-replay safe); otherwise ``step`` is used by value.
+    ``lr_dev`` (optional 0-d fp32 device tensor): the learning rate is read from it (a captured graph freezes
+    ``lr``; a scheduler writes the device word)."""
     _need_cuda(p, g, m, v)
     st = _stream()
     if step_dev is not None:
         lib.call("avid_counter_add", _p(step_dev), 1, st)
     lib.call("avid_adam_flat", p.numel(), _p(p), _p(g), _p(m), _p(v), float(lr), float(beta1), float(beta2),
-             float(eps), float(wd), int(step), _p(step_dev), float(grad_scale), st)
+             float(eps), float(wd), int(step), _p(step_dev), _p(lr_dev), float(grad_scale), st)

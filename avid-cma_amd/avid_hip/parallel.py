@@ -11,7 +11,11 @@ What the reference does with ``DistributedDataParallel`` + ``torch.optim.Adam``
                      as the bucket's last gradient is written, i.e. overlapped with the rest of
                      backward; ``finish()`` makes the compute stream wait.  The 1/world average is
                      folded into the optimizer kernel's ``grad_scale``.
-* ``TrainStep``    — fwd -> criterion -> bwd (+ overlapped all-reduce) -> one fused flat-Adam launch.
+* ``FlatBuffers``  — the BatchNorm running statistics as views of one flat buffer: DDP's buffer broadcast
+                     (``broadcast_buffers=True``, the default of utils/main_utils.py:112) is ONE 78 KB collective.
+* ``TrainStep``    — fwd -> criterion -> bwd (+ overlapped all-reduce) -> one fused flat-Adam launch;
+                     ``state_dict`` / ``load_state_dict`` in torch.optim.Adam's format (the reference's
+                     CheckpointManager saves ``optimizer.state_dict()``, main-avid.py:115,127,138).
 
 The comm layer is backend-agnostic (gloo on CPU in tests/test_distributed_cpu.py); only the Adam
 kernel needs the GPU.  BatchNorm statistics stay per-rank — the reference has no SyncBN.
@@ -60,6 +64,34 @@ class FlatParams:
         for p, o in zip(self.params, self.offsets):     # re-seat if something replaced .grad (set_to_none)
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad_views[self.offsets.index(o)]
+
+
+class FlatBuffers:
+    """The floating-point buffers of ``module`` (BatchNorm running_mean / running_var) re-seated as views of one
+    flat tensor, so that broadcasting rank 0's buffers — what DistributedDataParallel(broadcast_buffers=True)
+    does before every forward — is a single small collective.  ``num_batches_tracked`` (int64) advances by one
+    per step on every rank and is identical everywhere by construction."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.bufs = [b for b in module.buffers() if b.is_floating_point()]
+        self.offsets, off = [], 0
+        for b in self.bufs:
+            self.offsets.append(off)
+            off += (b.numel() + 3) // 4 * 4
+        self.numel = off
+        if not self.bufs:
+            self.flat = None
+            return
+        self.flat = torch.zeros(off, dtype=self.bufs[0].dtype, device=self.bufs[0].device)
+        for b, o in zip(self.bufs, self.offsets):
+            view = self.flat[o:o + b.numel()].view(b.shape)
+            view.copy_(b)
+            b.data = view
+
+    def broadcast(self, src=0, async_op=False):
+        if self.flat is None or not _dist_on():
+            return None
+        return dist.broadcast(self.flat, src, async_op=async_op)
 
 
 class GradBuckets:
@@ -159,16 +191,30 @@ class TrainStep:
     """
 
     def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5,
-                 bucket_bytes=16 << 20):
+                 bucket_bytes=16 << 20, broadcast_buffers="lazy"):
+        """``broadcast_buffers``: DistributedDataParallel broadcasts rank 0's BatchNorm buffers before EVERY
+        forward (utils/main_utils.py:112, default ``broadcast_buffers=True``).  A training-mode forward never
+        reads them (it normalises with the batch statistics), and rank 0's own buffers are never overwritten, so
+        the only observable effect is what a non-zero rank evaluates / saves with.  ``"lazy"`` (default) therefore
+        broadcasts at ``sync_buffers()`` only — call it before evaluation and before saving a checkpoint —
+        ``"step"`` reproduces DDP literally with one flat 78 KB broadcast per step, ``"off"`` never broadcasts."""
+        import os
         self.model, self.criterion = model, criterion
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        if broadcast_buffers not in ("lazy", "step", "off"):
+            raise ValueError("broadcast_buffers must be 'lazy', 'step' or 'off'")
+        self.broadcast_buffers = broadcast_buffers
         if _dist_on():                                   # DDP's construction-time parameter broadcast (C3)
             for p in model.parameters():
                 dist.broadcast(p.data, 0)
             for b in model.buffers():
                 dist.broadcast(b.data, 0)
         self.flat = FlatParams(model)
-        import os
+        self.flat_buffers = FlatBuffers(model)
+        # The audio tower runs on a side stream under the video tower (models/av_wrapper.py): on by default
+        # here, because GradBuckets below orders every bucket's collective after the streams that produced it.
+        if hasattr(model, "overlap_towers") and os.environ.get("AVID_OVERLAP_TOWERS", "1") == "1":
+            model.overlap_towers = True
         if os.environ.get("AVID_BUCKET_MB"):             # tuning knob: gradient all-reduce bucket size
             bucket_bytes = int(float(os.environ["AVID_BUCKET_MB"]) * (1 << 20))
         self.buckets = GradBuckets(self.flat, bucket_bytes)
@@ -176,6 +222,9 @@ class TrainStep:
         self.v = torch.zeros_like(self.flat.flat)
         self.t = 0
         self.t_dev = torch.zeros((), dtype=torch.int64, device=self.flat.flat.device) \
+            if self.flat.flat.is_cuda else None
+        # the learning rate lives in device memory as well: a captured graph freezes by-value arguments
+        self.lr_dev = torch.full((), float(lr), dtype=torch.float32, device=self.flat.flat.device) \
             if self.flat.flat.is_cuda else None
         self.graph = None
         self.twt = self.slots = None
@@ -185,7 +234,20 @@ class TrainStep:
             # backward kernels write parameter gradients straight into the flat buffer (no per-parameter add)
             self.slots = ops.GradSlots(self.flat.params, self.flat.grad_views, on_ready=self.buckets.ready)
 
+    def set_lr(self, lr):
+        """Change the learning rate (an LR scheduler's hook; also reaches a captured graph)."""
+        self.lr = float(lr)
+        if self.lr_dev is not None:
+            self.lr_dev.fill_(self.lr)
+
+    def sync_buffers(self):
+        """Every rank takes rank 0's BatchNorm running statistics (see ``broadcast_buffers``): call before
+        evaluating the model or saving it on a rank other than 0."""
+        self.flat_buffers.broadcast(0)
+
     def forward_backward(self, video, audio, index):
+        if self.broadcast_buffers == "step":
+            self.sync_buffers()
         self.flat.zero_grad()
         video_emb, audio_emb = self.model(video, audio)
         loss, _ = self.criterion(video_emb, audio_emb, index)
@@ -202,7 +264,58 @@ class TrainStep:
         from . import ops
         self.t += 1
         ops.adam_flat(self.flat.flat, self.flat.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.wd, self.t, grad_scale=1.0 / self.buckets.world, step_dev=self.t_dev)
+                      self.eps, self.wd, self.t, grad_scale=1.0 / self.buckets.world, step_dev=self.t_dev,
+                      lr_dev=self.lr_dev)
+
+    # ---- optimizer / sampler state in torch.optim.Adam's format (main-avid.py:115,127,138 save and restore
+    # ``optimizer.state_dict()``; utils/main_utils.py:250-261 builds Adam over model.parameters())
+    def _param_order(self):
+        """index in ``model.parameters()`` order -> (slot in the flat layout, parameter)."""
+        slot = {id(p): i for i, p in enumerate(self.flat.params)}
+        return [(slot[id(p)], p) for p in self.model.parameters() if id(p) in slot]
+
+    def _slice(self, flat_tensor, i):
+        p, o = self.flat.params[i], self.flat.offsets[i]
+        return flat_tensor[o:o + p.numel()].as_strided(p.shape, p.stride())
+
+    def state_dict(self):
+        order = self._param_order()
+        step = float(int(self.t_dev) if self.t_dev is not None else self.t)
+        state = {}
+        if step > 0:
+            for k, (i, _) in enumerate(order):
+                state[k] = {"step": torch.tensor(step), "exp_avg": self._slice(self.m, i).detach().clone(),
+                            "exp_avg_sq": self._slice(self.v, i).detach().clone()}
+        sd = {"state": state,
+              "param_groups": [{"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
+                                "amsgrad": False, "maximize": False, "params": list(range(len(order)))}]}
+        mult = getattr(getattr(self.criterion, "nce_average", None), "multinomial", None)
+        if mult is not None:       # the negative sampler's stream position (not part of the reference's checkpoint:
+            off = int(mult.offset_dev) if getattr(mult, "offset_dev", None) is not None else int(mult.offset)
+            sd["avid_sampler"] = {"seed": int(mult.seed), "offset": off}   # torch's global RNG is not saved either)
+        return sd
+
+    def load_state_dict(self, sd):
+        order = self._param_order()
+        g = sd["param_groups"][0]
+        self.betas, self.eps, self.wd = tuple(g["betas"]), g["eps"], g["weight_decay"]
+        self.set_lr(g["lr"])
+        self.m.zero_()
+        self.v.zero_()
+        step = 0
+        for k, (i, _) in enumerate(order):
+            st = sd["state"].get(k, sd["state"].get(str(k)))
+            if st is None:
+                continue
+            self._slice(self.m, i).copy_(st["exp_avg"])
+            self._slice(self.v, i).copy_(st["exp_avg_sq"])
+            step = max(step, int(float(st["step"])))
+        self.t = step
+        if self.t_dev is not None:
+            self.t_dev.fill_(step)
+        mult = getattr(getattr(self.criterion, "nce_average", None), "multinomial", None)
+        if mult is not None and "avid_sampler" in sd:
+            mult.reseed(sd["avid_sampler"]["seed"], sd["avid_sampler"]["offset"])
 
     def step(self, video, audio, index):
         loss = self.forward_backward(video, audio, index)
@@ -216,8 +329,14 @@ class TrainStep:
         self._sv, self._sa, self._si = video.clone(), audio.clone(), index.clone()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        t_host = self.t
+        mult = getattr(getattr(self.criterion, "nce_average", None), "multinomial", None)
+        off_host = mult.offset if mult is not None else None
         with torch.cuda.graph(self.graph):
             self._sloss = self.step(self._sv, self._sa, self._si)
+        self.t = t_host                              # the capture executed nothing: host counters stay where the
+        if mult is not None:                         # device counters are
+            mult.offset = off_host
         return self
 
     def replay(self, video=None, audio=None, index=None):
@@ -229,4 +348,7 @@ class TrainStep:
             self._si.copy_(index, non_blocking=True)
         self.graph.replay()
         self.t += 1
+        mult = getattr(getattr(self.criterion, "nce_average", None), "multinomial", None)
+        if mult is not None:
+            mult.offset += 1
         return self._sloss

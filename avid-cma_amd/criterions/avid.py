@@ -59,6 +59,7 @@ class AVIDSimilarityMemoryBank(nn.Module):
     def forward(self, video_emb, audio_emb, y):
         K = int(self.num_negatives)
         inv_T = 1.0 / self.temperature
+        ops.poll_device_errors(y.device)      # an out-of-range id of an earlier step raises IndexError here (no sync)
         video_emb = ops.l2_normalize(video_emb)
         audio_emb = ops.l2_normalize(audio_emb)
 
@@ -80,6 +81,7 @@ class AVIDSimilarityMemoryBank(nn.Module):
 
         # Update memory bank (scores above used the pre-update rows; their snapshot is kept for backward)
         self.update_memory(video_emb.detach(), audio_emb.detach(), y)
+        ops.poll_device_errors(y.device)      # starts the (asynchronous) read-back of this step's error word
         return scores
 
     def sample_negatives(self, y, K):

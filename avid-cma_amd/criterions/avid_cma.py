@@ -29,11 +29,13 @@ class CMASampler:
         self.sampling_args = sampling_args
         if sampling_args['type'] not in _KINDS:
             raise ValueError
+        # diagnostics: query batches whose candidate lists overflowed the threshold filter (exact scan redid them)
+        self.fallback_batches = torch.zeros((), dtype=torch.int32, device=video_mem.device) if video_mem.is_cuda else None
 
     def sample_range(self, q0, q1, batch=1024):
         from avid_hip import topk
         return topk.cma_topk(self.video_mem, self.audio_mem, q0, q1, self.sampling_args['pos_k'],
-                             _KINDS[self.sampling_args['type']], batch)
+                             _KINDS[self.sampling_args['type']], batch, fallbacks=self.fallback_batches)
 
     def sample(self):
         N = self.video_mem.shape[0]
@@ -72,6 +74,7 @@ class AVIDSimilarityPositiveExpansion(AVIDSimilarityMemoryBank):
         """avid_cma.py:150-194."""
         inv_T = 1.0 / self.temperature
         bs = y.shape[0]
+        ops.poll_device_errors(y.device)
         video_emb = ops.l2_normalize(video_emb)
         audio_emb = ops.l2_normalize(audio_emb)
 
@@ -105,6 +108,7 @@ class AVIDSimilarityPositiveExpansion(AVIDSimilarityMemoryBank):
             scores['pos-a2a'] = [s_a2a[:, :P], s_a2a[:, P:]]
 
         self.update_memory(video_emb.detach(), audio_emb.detach(), y)
+        ops.poll_device_errors(y.device)
         return scores
 
     def memory_sampling(self, y):
@@ -120,7 +124,12 @@ class AVIDSimilarityPositiveExpansion(AVIDSimilarityMemoryBank):
         if self.sampling_args['pos_k'] <= 0:
             return
         positive_set = CMASampler(self.view1_mem, self.view2_mem, self.sampling_args).sample()
-        self.register_buffer('positive_set', positive_set.int().to(self.view1_mem.device))
+        positive_set = positive_set.int().to(self.view1_mem.device)
+        old = getattr(self, 'positive_set', None)
+        if old is not None and old.shape == positive_set.shape and old.device == positive_set.device:
+            old.copy_(positive_set)      # in place: a captured hipGraph of the step keeps reading this buffer
+        else:
+            self.register_buffer('positive_set', positive_set)
         if self.distributed:
             dist.barrier()
 

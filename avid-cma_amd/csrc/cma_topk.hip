@@ -195,8 +195,10 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict_
 // sort the remaining indices ascending.
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
                                                          int P, int nq, int K, long long q0, long long N,
-                                                         int32_t* __restrict__ out, const int* __restrict__ flag) {
+                                                         int32_t* __restrict__ out, const int* __restrict__ flag,
+                                                         int32_t* __restrict__ fallbacks) {
   if (flag && *flag == 0) return;
+  if (flag && fallbacks && blockIdx.x == 0 && threadIdx.x == 0) *fallbacks += 1;   // this batch overflowed its filter
   __shared__ float sv[256];
   __shared__ int si[256], sp[256];
   __shared__ int chosen[TK_MAX];
@@ -282,7 +284,8 @@ extern "C" size_t avid_cma_topk_workspace_bytes(int64_t N, int nq, int pos_k) {
 }
 
 extern "C" int avid_cma_topk(int64_t N, int D, const float* view1, const float* view2, int64_t q0, int nq, int pos_k,
-                             int kind, int32_t* out, void* ws, size_t ws_bytes, avid_stream_t stream) {
+                             int kind, int32_t* out, int32_t* fallbacks, void* ws, size_t ws_bytes,
+                             avid_stream_t stream) {
   AVID_REQUIRE(N > 0 && view1 && view2 && out && ws, AVID_E_BADARG, "cma_topk: bad argument");
   AVID_REQUIRE(D % 32 == 0 && nq > 0 && nq % 64 == 0, AVID_E_UNSUPPORTED, "cma_topk: D %% 32 and nq %% 64 required");
   AVID_REQUIRE(pos_k > 0 && pos_k + 1 <= TK_MAX && pos_k < N, AVID_E_UNSUPPORTED, "cma_topk: pos_k must be in [1, %d]",
@@ -337,6 +340,6 @@ extern "C" int avid_cma_topk(int64_t N, int D, const float* view1, const float* 
   rc = check_launch("topk_scan");
   if (rc) return rc;
   hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(256), 0, s, pval, pidx, P, nq, K, (long long)q0, (long long)N,
-                     out, flag);
+                     out, flag, fallbacks);
   return check_launch("topk_merge");
 }

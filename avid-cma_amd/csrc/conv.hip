@@ -1700,7 +1700,8 @@ static int launch_igemm(const ConvArgs& a, hipStream_t s) {
   const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
   const double row_lo = (double)a.mt2_begin * 2 * BM, row_hi = fmin((double)a.M, row_lo + (double)a.mt2_count * 2 * BM);
   const double frac = STRIDED ? 1.0 : (row_hi - row_lo) / (double)a.M;
-  ScopedTimer t(s, name, frac * 2.0 * a.M * a.Cd * K,
+  // (input gradients are priced by their source pixels = the forward's output pixels: see launch_pk)
+  ScopedTimer t(s, name, frac * (MODE == 1 ? 2.0 * srcpix * a.Cd * K : 2.0 * a.M * a.Cd * K),
                 frac * 4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (a.addend ? 2 : 1)));
   const unsigned ptiles = STRIDED ? (unsigned)a.cls_ptiles_total : (unsigned)a.mt2_count;
   hipLaunchKernelGGL(kern, dim3(ptiles * ntn * a.nsplit), dim3(512), lds, s, a);
@@ -1834,9 +1835,14 @@ static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
   if (!name[0]) snprintf(name, sizeof(name), "igemm_pk_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, MODE, STRIDED ? "s2" : "");
   const double K = (double)a.kt * a.kh * a.kw * a.Cs;
   const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
-  // algorithmic work: 2*M*N*K flops; bytes = one read of src + weights, one write of dst (+ addend)
-  ScopedTimer t(s, name, 2.0 * a.M * a.Cd * K,
-                4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (a.addend ? 2 : 1)));
+  // algorithmic work = the multiply-adds of the FORWARD convolution this launch belongs to: 2 * (output pixels) *
+  // Cout * Cin * taps.  Forward: M output pixels.  Input gradient: the forward's output pixels are this kernel's
+  // SOURCE pixels (dy) — for a strided layer M (= dx pixels) is prod(stride) times more, and counting 2*M*N*K
+  // would price taps that the stride-parity classes never execute.  Bytes = one read of src + weights, one write
+  // of dst (+ addend) (+ the BatchNorm input x when the dgrad also makes that layer's backward partial sums).
+  const double flops = MODE == 1 ? 2.0 * srcpix * a.Cd * K : 2.0 * a.M * a.Cd * K;
+  ScopedTimer t(s, name, flops,
+                4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (1 + (a.addend ? 1 : 0) + (a.bnb_x ? 1 : 0))));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
   return check_launch("igemm_pk");
 }

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void bank_scores_fwd_kernel(const long long* _
                                                               const float* __restrict__ bank,
                                                               const float* __restrict__ emb, float inv_T,
                                                               float* __restrict__ scores,
-                                                              float* __restrict__ rows_out, int R, long long N) {
+                                                              float* __restrict__ rows_out, int R, long long N,
+                                                              int* __restrict__ err) {
   constexpr int D = 64 * DPL;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
@@ -111,7 +112,10 @@ __global__ __launch_bounds__(256) void bank_scores_fwd_kernel(const long long* _
   long long mine = 0;
   if (lane < RPW && jw + lane < j1) {
     mine = ib[jw + lane];
-    mine = mine < 0 ? 0 : (mine >= N ? N - 1 : mine);   // never read outside the bank
+    if (mine < 0 || mine >= N) {                        // the reference raises an index error (avid.py:57-62):
+      if (err) atomicOr(err, AVID_DEVERR_BANK_INDEX);   // flag it (raised by the host at its next poll) and
+      mine = mine < 0 ? 0 : N - 1;                      // never read outside the bank
+    }
   }
   float v[RPW][DPL];
 #pragma unroll
@@ -302,12 +306,15 @@ __global__ void nce_bwd_kernel(const float* __restrict__ spos, const float* __re
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bank_update_kernel(float* __restrict__ bank, const long long* __restrict__ y,
                                                           const float* __restrict__ emb, float mom, int B, int D,
-                                                          long long N) {
+                                                          long long N, int* __restrict__ err) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= B) return;
   const long long row = y[i];
-  if (row < 0 || row >= N) return;
+  if (row < 0 || row >= N) {   // index_copy_ would raise (avid.py:124): flag it, touch nothing
+    if (err && lane == 0) atomicOr(err, AVID_DEVERR_UPDATE_INDEX);
+    return;
+  }
   int dup = 0;
   for (int k = i + 1 + lane; k < B; k += 64) dup |= (y[k] == row);
   if (__any(dup)) return;  // a later sample owns this row
@@ -329,12 +336,18 @@ __global__ __launch_bounds__(256) void bank_update_kernel(float* __restrict__ ba
 // criterions/avid_cma.py:196-209
 __global__ void cma_negatives_kernel(const int32_t* __restrict__ pset, const long long* __restrict__ y,
                                      const long long* __restrict__ rnd, long long* __restrict__ pos_out,
-                                     long long* __restrict__ neg_out, int bs, int K, int P) {
+                                     long long* __restrict__ neg_out, int bs, int K, int P, long long N,
+                                     int* __restrict__ err) {
   const long long n = (long long)bs * K;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int b = (int)(i / K), k = (int)(i % K);
-    const int32_t* ps = pset + y[b] * (long long)P;
+    long long yb = y[b];
+    if (yb < 0 || yb >= N) {   // positive_set[y] would raise (avid_cma.py:199): flag it, stay inside the table
+      if (err && k == 0) atomicOr(err, AVID_DEVERR_CMA_INDEX);
+      yb = yb < 0 ? 0 : N - 1;
+    }
+    const int32_t* ps = pset + yb * (long long)P;
     const long long r = rnd[i];
     int cnt = 0;
     for (int j = 0; j < P; ++j) cnt += (r >= (long long)ps[j] - j) ? 1 : 0;
@@ -345,7 +358,9 @@ __global__ void cma_negatives_kernel(const int32_t* __restrict__ pset, const lon
   if (K < P)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)bs * P; i += stride) {
       const int b = (int)(i / P), k = (int)(i % P);
-      if (k >= K) pos_out[i] = pset[y[b] * (long long)P + k];
+      long long yb = y[b];
+      yb = yb < 0 ? 0 : (yb >= N ? N - 1 : yb);
+      if (k >= K) pos_out[i] = pset[yb * (long long)P + k];
     }
 }
 
@@ -391,7 +406,7 @@ extern "C" int avid_alias_draw(int64_t n, int64_t K, const float* prob, const in
 }
 
 extern "C" int avid_bank_scores_fwd(int bs, int R, int D, int64_t N, const int64_t* idx, const float* bank,
-                                    const float* emb, float inv_T, float* scores, float* rows_out,
+                                    const float* emb, float inv_T, float* scores, float* rows_out, int32_t* err,
                                     avid_stream_t stream) {
   AVID_REQUIRE(bs > 0 && R > 0 && N > 0 && idx && bank && emb && scores, AVID_E_BADARG, "bank_scores_fwd: bad argument");
   AVID_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, AVID_E_UNSUPPORTED, "bank_scores_fwd: D=%d unsupported", D);
@@ -400,10 +415,10 @@ extern "C" int avid_bank_scores_fwd(int bs, int R, int D, int64_t N, const int64
   const long long* ix = (const long long*)idx;
   ScopedTimer t(s, "bank_scores_fwd_kernel", 2.0 * bs * R * D, 4.0 * bs * R * ((double)D * (rows_out ? 2 : 1) + 3));
   switch (D / 64) {
-    case 1: hipLaunchKernelGGL(bank_scores_fwd_kernel<1>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N); break;
-    case 2: hipLaunchKernelGGL(bank_scores_fwd_kernel<2>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N); break;
-    case 4: hipLaunchKernelGGL(bank_scores_fwd_kernel<4>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N); break;
-    default: hipLaunchKernelGGL(bank_scores_fwd_kernel<8>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N); break;
+    case 1: hipLaunchKernelGGL(bank_scores_fwd_kernel<1>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N, err); break;
+    case 2: hipLaunchKernelGGL(bank_scores_fwd_kernel<2>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N, err); break;
+    case 4: hipLaunchKernelGGL(bank_scores_fwd_kernel<4>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N, err); break;
+    default: hipLaunchKernelGGL(bank_scores_fwd_kernel<8>, grid, dim3(256), 0, s, ix, bank, emb, inv_T, scores, rows_out, R, (long long)N, err); break;
   }
   return check_launch("bank_scores_fwd");
 }
@@ -462,22 +477,23 @@ extern "C" int avid_nce_bwd(int bs, int P, int K, const float* spos, int ld_pos,
 }
 
 extern "C" int avid_bank_update(int B, int D, int64_t N, float* bank, const int64_t* y, const float* emb,
-                                float momentum, avid_stream_t stream) {
+                                float momentum, int32_t* err, avid_stream_t stream) {
   AVID_REQUIRE(B > 0 && D > 0 && D <= 512 && N > 0 && bank && y && emb, AVID_E_BADARG, "bank_update: bad argument");
   hipLaunchKernelGGL(bank_update_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, bank,
-                     (const long long*)y, emb, momentum, B, D, (long long)N);
+                     (const long long*)y, emb, momentum, B, D, (long long)N, err);
   return check_launch("bank_update");
 }
 
-extern "C" int avid_cma_negatives(int bs, int K, int P, const int32_t* positive_set, const int64_t* y,
-                                  const int64_t* rand_idx, int64_t* pos_out, int64_t* neg_out, avid_stream_t stream) {
-  AVID_REQUIRE(bs > 0 && K > 0 && P > 0 && positive_set && y && rand_idx && pos_out && neg_out, AVID_E_BADARG,
+extern "C" int avid_cma_negatives(int bs, int K, int P, int64_t N, const int32_t* positive_set, const int64_t* y,
+                                  const int64_t* rand_idx, int64_t* pos_out, int64_t* neg_out, int32_t* err,
+                                  avid_stream_t stream) {
+  AVID_REQUIRE(bs > 0 && K > 0 && P > 0 && N > 0 && positive_set && y && rand_idx && pos_out && neg_out, AVID_E_BADARG,
                "cma_negatives: bad argument");
   const long long n = (long long)bs * (K > P ? K : P);
   long long g = ceil_div(n, 256);
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(cma_negatives_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, positive_set,
                      (const long long*)y, (const long long*)rand_idx, (long long*)pos_out, (long long*)neg_out, bs, K,
-                     P);
+                     P, (long long)N, err);
   return check_launch("cma_negatives");
 }

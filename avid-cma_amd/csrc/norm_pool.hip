@@ -165,11 +165,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 
 __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                     float* __restrict__ mean, float* __restrict__ invstd_out,
                                      float* __restrict__ scale, float* __restrict__ shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float invstd = 1.f / sqrtf(rv[c] + eps);
   const float sc = gamma[c] * invstd;
+  mean[c] = rm[c];
+  invstd_out[c] = invstd;
   scale[c] = sc;
   shift[c] = beta[c] - rm[c] * sc;
 }
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, long long M,
                                                                int C, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ k1,
-                                                               float* __restrict__ k2) {
+                                                               float* __restrict__ k2, int frozen) {
   __shared__ double sh[16][2][FIN_CH];
   const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
   double s, sx;
@@ -316,8 +319,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
   if (threadIdx.x >= FIN_CH || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)sx;
-  k1[c] = (float)(s / (double)M);
-  k2[c] = (float)(sx / (double)M);
+  // frozen (eval-mode) statistics are constants of the graph: dx = gamma * invstd * dy_m, no mean terms
+  k1[c] = frozen ? 0.f : (float)(s / (double)M);
+  k2[c] = frozen ? 0.f : (float)(sx / (double)M);
 }
 
 // dx = gamma*invstd * (dy_m - mean(dy_m) - xhat * mean(dy_m*xhat))
@@ -760,11 +764,19 @@ extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* 
 
 extern "C" int avid_bn_fwd_eval(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                                 const float* running_mean, const float* running_var, float eps, int relu, float* y,
-                                avid_stream_t stream) {
+                                float* save4, avid_stream_t stream) {
   int rc = bn_check(M, C, "bn_fwd_eval");
   if (rc) return rc;
   AVID_REQUIRE(x && gamma && beta && running_mean && running_var && y, AVID_E_BADARG, "bn_fwd_eval: null pointer");
   const long long n4 = (long long)M * (C / 4);
+  if (save4) {   // a backward will follow (fine-tuning with frozen BatchNorm): y = fma(x, scale, shift), the
+                 // expression avid_bn_bwd recomputes the ReLU mask with; mean / invstd / scale / shift are kept
+    hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, C,
+                       gamma, beta, running_mean, running_var, eps, save4, save4 + C, save4 + 2 * C, save4 + 3 * C);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, y, save4 + 2 * C,
+                       save4 + 3 * C, n4, C / 4, relu);
+    return check_launch("bn_fwd_eval");
+  }
   hipLaunchKernelGGL(bn_apply_eval_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta,
                      running_mean, running_var, eps, n4, C / 4, relu);
   return check_launch("bn_fwd_eval");
@@ -773,7 +785,8 @@ extern "C" int avid_bn_fwd_eval(int64_t M, int C, const float* x, const float* g
 extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, const float* gamma,
                            const float* save_mean, const float* save_invstd, const float* save_scale,
                            const float* save_shift, int relu, float* dx, float* dgamma, float* dbeta,
-                           const float* partials, int nparts, void* ws, size_t ws_bytes, avid_stream_t stream) {
+                           const float* partials, int nparts, int frozen, void* ws, size_t ws_bytes,
+                           avid_stream_t stream) {
   int rc = bn_check(M, C, "bn_bwd");
   if (rc) return rc;
   AVID_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, AVID_E_BADARG,
@@ -797,7 +810,7 @@ extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, co
                        (long long)M, C, p.G, p.rows_per_pass, p.rows_per_block, relu);
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, nblk,
-                     (long long)M, C, dgamma, dbeta, k1, k2);
+                     (long long)M, C, dgamma, dbeta, k1, k2, frozen);
   const long long n4 = (long long)M * p.G;
   {
     ScopedTimer t(s, "bn_bwd_apply_kernel", 0.0, 4.0 * M * C * 3);
@@ -875,7 +888,7 @@ extern "C" int avid_bn_relu_maxpool_bwd(int B, int T, int H, int W, int C, const
                        save_mean, save_invstd, part, cells, C, p.G, p.rows_per_pass, (int)cpb, H, W, Ho, Wo);
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, nblk,
-                     (long long)M, C, dgamma, dbeta, k1, k2);
+                     (long long)M, C, dgamma, dbeta, k1, k2, 0);
   const long long nc4 = cells * p.G;
   {
     ScopedTimer t(s, "bn_pool_bwd_apply_kernel", 0.0, 4.0 * M * C * 2.3);

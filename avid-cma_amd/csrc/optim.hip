@@ -11,7 +11,13 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
                                                         float* __restrict__ m, float* __restrict__ v, long long n4,
                                                         long long n, float b1, float b2, float eps, float wd,
                                                         float step_size, float inv_sqrt_bc2, float grad_scale,
-                                                        float lr, const long long* __restrict__ step_dev) {
+                                                        float lr, const long long* __restrict__ step_dev,
+                                                        const float* __restrict__ lr_dev) {
+  if (lr_dev) {   // graph-replay safe learning rate (scheduler writes the device word)
+    const float nl = *lr_dev;
+    step_size = lr != 0.f ? step_size * (nl / lr) : 0.f;   // (exact when step_dev is given: recomputed below)
+    lr = nl;
+  }
   if (step_dev) {  // graph-replay safe: bias corrections from the device-resident step counter
     const double t = (double)*step_dev;
     step_size = (float)((double)lr / (1.0 - pow((double)b1, t)));
@@ -51,7 +57,7 @@ using namespace avid;
 
 extern "C" int avid_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int64_t step, const int64_t* step_dev,
-                              float grad_scale, avid_stream_t stream) {
+                              const float* lr_dev, float grad_scale, avid_stream_t stream) {
   AVID_REQUIRE(n > 0 && p && g && m && v && (step >= 1 || step_dev), AVID_E_BADARG, "adam_flat: bad argument");
   if (step < 1) step = 1;
   AVID_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, AVID_E_BADARG,
@@ -66,6 +72,6 @@ extern "C" int avid_adam_flat(int64_t n, float* p, const float* g, float* m, flo
   ScopedTimer t((hipStream_t)stream, "adam_flat_kernel", 0.0, 28.0 * n);
   hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4,
                      (long long)n, beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale, lr,
-                     (const long long*)step_dev);
+                     (const long long*)step_dev, lr_dev);
   return check_launch("adam_flat");
 }

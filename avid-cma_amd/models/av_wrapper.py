@@ -67,7 +67,12 @@ class AV_Wrapper(nn.Module):
         else:
             self.out_dim = video_model.out_dim
 
-    overlap_towers = bool(int(__import__('os').environ.get('AVID_OVERLAP_TOWERS', '1')))    # run the (small) audio tower on a side stream under the video tower's tail waves
+    # Run the (small) audio tower on a side stream under the video tower's tail waves.  OFF unless the build's
+    # own engine drives the step (avid_hip.parallel.TrainStep switches it on): its gradient buckets know which
+    # stream produced each gradient.  torch's DistributedDataParallel reducer does not — it orders a bucket's
+    # all-reduce after the stream of the LAST gradient hook only, so a bucket mixing the two towers' parameters
+    # could be reduced before the other stream's gradient has landed.
+    overlap_towers = False
 
     def _audio(self, audio):
         audio_emb = self.audio_model(audio)

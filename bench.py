@@ -70,6 +70,64 @@ def cpu_baseline(steps=12, warmup=1):
                       f"median of {steps} steps ({sum(times):.1f} s CPU work), os.cpu_count()={os.cpu_count()}"}
 
 
+def extra_configs(engine, model, video, audio, dev, lib, steps=10, warmup=3):
+    """BASELINE configs 4 and 5 on this GPU, after the timed region (same model, same batch; only the criterion
+    changes): cfg5 = AVID on the AudioSet-scale 2M x 128 banks (step rate + achieved bank-gather bandwidth of
+    bank_scores_fwd from its HIP events), cfg4 = AVID_CMA InstX-N1024-PosW-N64-Top32 on the 240k banks (step rate +
+    one whole find_correspondences()).  Not part of `value`."""
+    import criterions
+    bs = video.shape[0]
+    res = {}
+
+    def rate(crit, N):
+        engine.criterion = crit
+        g = torch.Generator().manual_seed(4321)
+        ids = torch.stack([torch.randperm(N, generator=g)[:bs] for _ in range(warmup + steps)]).to(dev)
+        for i in range(warmup):
+            engine.step(video, audio, ids[i])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            engine.step(video, audio, ids[warmup + i])
+        torch.cuda.synchronize()
+        return bs * steps / (time.perf_counter() - t0), ids
+
+    # ---- config 5: configs/main/avid/audioset/Cross-N1024.yaml (num_data 1 784 108 -> 2M rows)
+    N5 = 2_000_000
+    crit5 = criterions.AVID(num_data=N5, embedding_dim=model.out_dim, num_negatives=1024, momentum=0.5,
+                            xModal_coeff=1., wModal_coeff=0., device=dev.index)
+    clips5, ids5 = rate(crit5, N5)
+    overlap, model.overlap_towers = model.overlap_towers, False
+    lib.timing_enable(True)
+    for i in range(3):
+        engine.step(video, audio, ids5[i])
+    torch.cuda.synchronize()
+    k = lib.timing_report()
+    lib.timing_enable(False)
+    model.overlap_towers = overlap
+    bsf = k.get("bank_scores_fwd_kernel")
+    res["cfg5"] = {"bank_rows": N5, "clips_s": round(clips5, 1),
+                   "bank_gather_GBs": round(bsf["bytes"] / (bsf["ms"] * 1e-3) / 1e9, 1) if bsf else None,
+                   "bank_scores_fwd_us": round(bsf["ms"] / bsf["launches"] * 1e3, 2) if bsf else None}
+    del crit5
+    torch.cuda.empty_cache()
+    # ---- config 4: configs/main/avid-cma/kinetics/InstX-N1024-PosW-N64-Top32.yaml:47-62
+    N4 = 240_000
+    crit4 = criterions.AVID_CMA(num_data=N4, embedding_dim=model.out_dim, num_negatives=1024, num_negatives_within=64,
+                                momentum=0.5, xModalInstCoeff=1., wModalInstCoeff=0., xModalPosCoeff=0.,
+                                wModalPosCoeff=1., sampling_args={"type": "consensus", "pos_k": 32}, resample_freq=-1,
+                                device=dev.index)          # (the constructor already searched once: warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    crit4.nce_average.find_correspondences()
+    torch.cuda.synchronize()
+    find_s = time.perf_counter() - t0
+    clips4, _ = rate(crit4, N4)
+    res["cfg4"] = {"bank_rows": N4, "clips_s": round(clips4, 1), "find_correspondences_s": round(find_s, 3),
+                   "search_TFLOPs": round(4.0 * N4 * N4 * 128 / find_s / 1e12, 1)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +137,7 @@ def main():
     ap.add_argument("--bank", type=int, default=240000)
     ap.add_argument("--negatives", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config 4 / config 5 side measurements")
     ap.add_argument("--graph", type=int, default=-1,
                     help="replay the whole step as one hipGraph (1/0; default 0: the eager path overlaps the two "
                          "towers on two streams and is GPU-bound — host issue ~10 ms vs ~20 ms of kernels)")
@@ -168,16 +227,20 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         clips = bs * world * args.steps / dt
-        mfma = {k: v for k, v in kern.items() if v["flops"] > 0 and ("igemm" in k or "wgrad" in k)}
+        # every MFMA kernel of the step: implicit-GEMM forward / dgrad, weight gradients, the two LDS-patch stems
+        mfma = {k: v for k, v in kern.items()
+                if v["flops"] > 0 and ("igemm" in k or "wgrad" in k or k.startswith("stem_"))}
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         d = mfma[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         # HBM traffic of the dominant kernel from the committed PMC passes (tools/pmc.sh + tools/pmc_traffic.py:
         # FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note, + WRITE_SIZE), bytes per launch
-        traffic = None
         tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(dom)
+        pmc = json.load(open(tf)) if os.path.exists(tf) else {}
+        if dom not in pmc:      # a renamed / new dominant kernel must not silently report a stale or missing figure
+            raise SystemExit(f"bench.py: profiles/pmc_traffic.json has no entry for the dominant kernel {dom!r}: "
+                             f"re-run tools/collect_profiles.sh on the GPU box and commit the regenerated file")
+        traffic = pmc[dom]
         conv_ms = sum(v["ms"] for v in mfma.values()) / kern_steps
         conv_tf = sum(v["flops"] for v in mfma.values()) / (sum(v["ms"] for v in mfma.values()) * 1e-3) / 1e12
         out = {
@@ -213,6 +276,8 @@ def main():
                 print(f"{k:34s} {v['launches'] / kern_steps:11.1f} {v['ms'] / kern_steps:9.3f} "
                       f"{100 * v['ms'] / tot:6.1f} {tf:9.2f} {gb:10.1f}", file=sys.stderr)
             print(f"timed kernels {tot / kern_steps:.3f} ms/step of {ms:.3f} ms wall", file=sys.stderr)
+        if world == 1 and not args.no_extra:
+            out["extra"] = extra_configs(engine, model, video, audio, dev, lib)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -136,18 +136,23 @@ int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* gamma, cons
                       float* y, float* save_mean, float* save_invstd, float* save_scale,
                       float* save_shift, int64_t* num_batches_tracked, const float* partials, int nparts,
                       void* ws, size_t ws_bytes, avid_stream_t stream);
-/* Eval: uses running stats. */
+/* Eval: uses running stats.  save4 (nullable, [4][C]): a backward will follow (frozen-BatchNorm fine-tuning) —
+ * mean (= running_mean) / invstd / scale / shift are written there and y = fma(x, scale, shift), the expression
+ * avid_bn_bwd(frozen = 1) recomputes the ReLU mask with. */
 int avid_bn_fwd_eval(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                      const float* running_mean, const float* running_var, float eps, int relu,
-                     float* y, avid_stream_t stream);
+                     float* y, float* save4, avid_stream_t stream);
 /* Backward of train-mode BN(+ReLU).  The ReLU mask is fma(x, scale, shift) > 0 recomputed from the conv
  * output x (the forward's exact expression), so the saved activation is not re-read: 2 + 3 passes.
  * partials / nparts: the partial sums the dgrad that produced dy already made (avid_conv_dgrad's `bn`), or
- * NULL / 0 — then the 2-read statistics pass runs here. */
+ * NULL / 0 — then the 2-read statistics pass runs here.
+ * frozen != 0: backward of an EVAL-mode BatchNorm (statistics are constants): dx = gamma * invstd * dy_m,
+ * dgamma = sum dy_m * xhat, dbeta = sum dy_m. */
 int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, const float* gamma,
                 const float* save_mean, const float* save_invstd, const float* save_scale,
                 const float* save_shift, int relu, float* dx, float* dgamma, float* dbeta,
-                const float* partials, int nparts, void* ws, size_t ws_bytes, avid_stream_t stream);
+                const float* partials, int nparts, int frozen, void* ws, size_t ws_bytes,
+                avid_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pooling.  MaxPool3d((1,3,3),(1,2,2),(0,1,1)) — models/video.py:23;  AdaptiveMaxPool{3,2}d(1) —
@@ -200,12 +205,21 @@ int avid_alias_draw(int64_t n, int64_t K, const float* prob, const int64_t* alia
  * counters so a captured hipGraph of the whole step advances its RNG stream / Adam step on replay. */
 int avid_counter_add(uint64_t* counter, uint64_t inc, avid_stream_t stream);
 
+/* Device-side index errors.  The reference's gathers / index_copy_ raise an IndexError for an id outside
+ * [0, N) (criterions/avid.py:57-62,124; avid_cma.py:199).  A kernel cannot raise: the three entry points below
+ * take `err` (nullable), one int32 word in device memory that they OR a code into while staying inside the
+ * table themselves (gathers clamp, the update skips the sample).  The host polls the word without a
+ * synchronisation (avid_hip/ops.py: DeviceErrors) and raises IndexError at most one step late. */
+#define AVID_DEVERR_BANK_INDEX 1   /* avid_bank_scores_fwd: idx outside [0, N) */
+#define AVID_DEVERR_UPDATE_INDEX 2 /* avid_bank_update: y outside [0, N) */
+#define AVID_DEVERR_CMA_INDEX 4    /* avid_cma_negatives: y outside [0, N) */
+
 /* scores[b][j] = <bank[idx[b][j]], emb[b]> * inv_T — the gather + bmm of criterions/avid.py:57-71.
  * idx [bs][R] int64, bank [N][D], emb [bs][D], D in {64,128,256,512}.  rows_out (nullable,
  * [bs][R][D]) receives a snapshot of the gathered rows: the reference's autograd keeps the
  * PRE-update rows for backward (the bank is updated inside forward, avid.py:78). */
 int avid_bank_scores_fwd(int bs, int R, int D, int64_t N, const int64_t* idx, const float* bank,
-                         const float* emb, float inv_T, float* scores, float* rows_out,
+                         const float* emb, float inv_T, float* scores, float* rows_out, int32_t* err,
                          avid_stream_t stream);
 /* demb[b] (+)= inv_T * sum_j dscores[b][j] * row(b,j)  (autograd of torch.bmm, avid.py:66), where
  * row(b,j) = rows[b][j] if rows != NULL (the snapshot) else bank[idx[b][j]]. */
@@ -232,29 +246,33 @@ int avid_nce_bwd(int bs, int P, int K, const float* spos, int ld_pos, const floa
 /* update_memory — criterions/avid.py:118-129: bank[y[i]] = normalize(m*bank[y[i]] + (1-m)*emb[i]).
  * Duplicate ids: the LAST occurrence wins (the reference's index_copy_ order is unspecified). */
 int avid_bank_update(int B, int D, int64_t N, float* bank, const int64_t* y, const float* emb,
-                     float momentum, avid_stream_t stream);
+                     float momentum, int32_t* err, avid_stream_t stream);
 
 /* memory_sampling remap — criterions/avid_cma.py:196-209.  positive_set int32 [N][P] (rows sorted);
  * pos_out [bs][P] = positive_set[y];  neg_out[b][k] = r + #{j : r >= pos_j - j}, r = rand_idx[b][k]. */
-int avid_cma_negatives(int bs, int K, int P, const int32_t* positive_set, const int64_t* y,
-                       const int64_t* rand_idx, int64_t* pos_out, int64_t* neg_out,
+int avid_cma_negatives(int bs, int K, int P, int64_t N, const int32_t* positive_set, const int64_t* y,
+                       const int64_t* rand_idx, int64_t* pos_out, int64_t* neg_out, int32_t* err,
                        avid_stream_t stream);
 
 /* CMA correspondence search — criterions/avid_cma.py:42-73: for queries q in [q0, q0+nq):
  * sim = combine(V V[q]^T, A A[q]^T) (kind 0 consensus=min, 1 union=max, 2 video, 3 audio);
  * top-(pos_k+1) by similarity, drop the best (self), sort ascending -> out [nq][pos_k] int32. */
 size_t avid_cma_topk_workspace_bytes(int64_t N, int nq, int pos_k);
+/* fallbacks (nullable): device int32 counter, += 1 when this batch overflowed the threshold filter's candidate
+ * lists (heavy score ties) and was redone by the exact scan — diagnostics, the result is exact either way. */
 int avid_cma_topk(int64_t N, int D, const float* view1, const float* view2, int64_t q0, int nq,
-                  int pos_k, int kind, int32_t* out, void* ws, size_t ws_bytes,
+                  int pos_k, int kind, int32_t* out, int32_t* fallbacks, void* ws, size_t ws_bytes,
                   avid_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam semantics (L2 weight decay folded into the gradient; bias-corrected)
  * over one flat fp32 buffer — utils/main_utils.py:250-261.
  * ---------------------------------------------------------------------------------------------- */
+/* lr_dev (nullable): the learning rate is read from this device float instead of `lr` — a captured hipGraph
+ * freezes by-value arguments, a scheduler then writes the device word (utils/main_utils.py:258 MultiStepLR). */
 int avid_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int64_t step, const int64_t* step_dev,
-                   float grad_scale, avid_stream_t stream);
+                   const float* lr_dev, float grad_scale, avid_stream_t stream);
 
 /* Video clip front end: frames [B][T][H][W][3] uint8 (what the decoder / augmentation hands over)
  * -> out [B][3][T][H][W] fp32 = ((u / 255) - mean[c]) / std[c], the reference's ClipToTensor + Normalize

@@ -26,3 +26,25 @@ def capture_relu_masks(model):
         elif isinstance(mod, LinearCL) and not name.endswith(".4"):
             handles.append(mod.register_forward_hook(lin_hook(name)))
     return masks, lambda: [h.remove() for h in handles]
+
+
+def relu_flip_report(device_masks, oracle_preact):
+    """Device ReLU pattern vs the FREE-running oracle's pre-activations, layer by layer.
+
+    Returns (flips, elements, worst) with ``worst`` = the largest |oracle pre-activation| / (layer RMS) over all
+    positions whose sign the two implementations disagree on (0 when there is none).  A legitimate disagreement is
+    a pre-activation within fp32 summation noise of zero; a wrong mask in a fused epilogue shows up as many flips
+    and / or flips at pre-activations of ordinary size."""
+    flips = elements = 0
+    worst = 0.0
+    for name, mask in device_masks.items():
+        pre = oracle_preact[name]
+        assert tuple(pre.shape) == tuple(mask.shape), (name, tuple(pre.shape), tuple(mask.shape))
+        diff = mask != (pre > 0)
+        n = int(diff.sum())
+        flips += n
+        elements += mask.numel()
+        if n:
+            rms = float(pre.double().pow(2).mean().sqrt()) + 1e-30
+            worst = max(worst, float(pre[diff].abs().max()) / rms)
+    return flips, elements, worst

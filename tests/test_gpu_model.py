@@ -76,7 +76,7 @@ def test_blocks_vs_reference_golden(tag, golden, gpu_device):
         close(b.cpu().numpy(), g[f"{tag}_buf_{n}"], 1e-5)
 
 
-from oracle.hooks import capture_relu_masks  # noqa: E402
+from oracle.hooks import capture_relu_masks, relu_flip_report  # noqa: E402
 
 
 def _build_model(gpu_device, tag="w"):
@@ -368,11 +368,19 @@ def test_full_step_vs_oracle_bs4(gpu_device):
     pn = [n for n in P if not ("running" in n or "num_batches" in n)]
     for n in pn:
         P[n].requires_grad_(True)
-    # (a) free-running oracle: forward quantities agree to fp32 round-off, ReLU patterns differ only on near-ties
-    with torch.no_grad():
-        ve0, ae0 = O.av_forward(video, audio, {k: v.detach().clone() for k, v in P.items()}, 18, True)
+    # (a) free-running oracle: forward quantities agree to fp32 round-off, and the device's ReLU pattern (the one
+    # pinned in (b)) differs from the oracle's OWN pattern on at most 2e-6 of the ~4e7 signs, every one of them a
+    # pre-activation within 1e-4 of its layer's RMS of zero — a wrong mask in a fused epilogue cannot hide in (b)
+    O.PREACT = {}
+    try:
+        with torch.no_grad():
+            ve0, ae0 = O.av_forward(video, audio, {k: v.detach().clone() for k, v in P.items()}, 18, True)
+        flips, elements, worst = relu_flip_report(masks, O.PREACT)
+    finally:
+        O.PREACT = None
     assert float((e1.detach().cpu() - ve0).abs().max() / ve0.abs().max()) < 2e-4
     assert float((e2.detach().cpu() - ae0).abs().max() / ae0.abs().max()) < 2e-4
+    assert elements > 3e7 and flips <= 2e-6 * elements and worst < 1e-4, (flips, elements, worst)
     # (b) oracle with the device's ReLU pattern pinned: loss and ALL 141 parameter gradients to 5e-4 of scale
     O.RELU_MASKS = masks
     try:
@@ -585,6 +593,14 @@ def test_real_dataset_shapes_vs_oracle(gpu_device):
     for n in P:
         if not ("running" in n or "num_batches" in n):
             P[n].requires_grad_(True)
+    O.PREACT = {}
+    try:         # free-running oracle first: the pinned pattern differs from its own only on near-zero pre-activations
+        with torch.no_grad():
+            O.av_forward(video, audio, {k: v.detach().clone() for k, v in P.items()}, 18, True)
+        flips, elements, worst = relu_flip_report(masks, O.PREACT)
+    finally:
+        O.PREACT = None
+    assert flips <= 2e-6 * elements and worst < 1e-4, (flips, elements, worst)
     O.RELU_MASKS = masks
     try:
         ve, ae = O.av_forward(video, audio, P, 18, True)
