@@ -317,10 +317,10 @@ class BnSource:
     output: the conv's input-gradient kernel then also produces the BatchNorm's backward partial sums (while the
     gradient is in registers) and leaves them here; the BatchNorm's backward, which autograd runs next, takes
     them instead of making its own pass over dy and x.  One object per forward call."""
-    __slots__ = ("x", "stats4", "relu", "partials", "dx_ptr")
+    __slots__ = ("x", "stats4", "relu", "partials", "dx_ptr", "dx_ver")
 
     def __init__(self, x, stats4, relu):
-        self.x, self.stats4, self.relu, self.partials, self.dx_ptr = x, stats4, relu, None, 0
+        self.x, self.stats4, self.relu, self.partials, self.dx_ptr, self.dx_ver = x, stats4, relu, None, 0, 0
 
 
 class _ConvCL(Function):
@@ -421,7 +421,8 @@ class _ConvCL(Function):
             if src is not None and FUSE_BN_BWD and d.bn_bwd_rows > 0 and src.x.shape == x.shape:
                 # dx is the whole gradient of the BatchNorm output x: its backward partial sums ride along
                 src.partials = torch.empty((d.bn_bwd_rows, 2, d.Cin), dtype=torch.float32, device=x.device)
-                src.dx_ptr = dx.data_ptr()       # the BatchNorm's backward verifies that THIS tensor is its dy
+                # the BatchNorm's backward verifies that THIS tensor, unmodified, is its dy
+                src.dx_ptr, src.dx_ver = dx.data_ptr(), dx._version
                 s4 = src.stats4
                 fuse = lib.BnBwdFuse(_p(src.x), _p(s4[2]), _p(s4[3]), _p(s4[0]), _p(s4[1]), int(src.relu),
                                      _p(src.partials))
@@ -520,9 +521,10 @@ class _BatchNormCL(Function):
             part, ctx.src.partials = ctx.src.partials, None
             # The hand-over is only valid if that dgrad's output IS this BatchNorm's whole output gradient.  A
             # second consumer of the activation (a hook, a custom block, an intermediate in the loss) makes
-            # autograd sum the gradients into a NEW tensor: then the partial sums cover one branch only and the
-            # unfused pass over dy and x runs instead.
-            if part is not None and dy.data_ptr() != ctx.src.dx_ptr:
+            # autograd sum the gradients — into a new tensor, or IN PLACE into the dgrad's output (which bumps its
+            # version counter): then the partial sums cover one branch only and the unfused pass over dy and x
+            # runs instead.
+            if part is not None and (dy.data_ptr() != ctx.src.dx_ptr or dy._version != ctx.src.dx_ver):
                 part = None
         lib.call("avid_bn_bwd", ctx.M, ctx.C, _p(x), _p(dy), _p(gamma), _p(stats4[0]), _p(stats4[1]), _p(stats4[2]),
                  _p(stats4[3]), int(ctx.relu), _p(dx), _p(dgamma), _p(dbeta), _p(part),

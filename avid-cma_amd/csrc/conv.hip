@@ -66,6 +66,8 @@ struct ConvArgs {
   int pk_full, pk_tail_units, pk_f, pk_kps;
   unsigned cls_mg[8][3];   // igemm_pk_kernel<STRIDED>: multiply-shift division by a class's (T,H,W) extents
   int cls_shf[8][3];
+  int cls_f[8];            // igemm_pk_kernel<STRIDED>: K pieces per tile of class c (1: tiles written directly)
+  int cls_ubegin[9];       // ... and the first work unit (tile, piece) of class c (prefix sums; [ncls] = total)
   float* stats;    // BatchNorm partial sums [rows][2][Cd] of the output (igemm_pk_kernel forward), or null
   // dgrad whose output is the gradient of a BatchNorm(+ReLU) output: the BN's backward partial sums
   // (sum dy_m, sum dy_m * xhat; dy_m = dy masked by the recomputed ReLU) go to `stats` from the epilogue
@@ -451,16 +453,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     return c;
   };
   auto seg_info = [&](int j, int& tile, int& k0, int& k1, int& split) {
-    if (STRIDED) {   // units = (tile, piece of its own K range), all dealt round-robin
+    if (STRIDED) {   // units = (tile, piece of its own K range), all dealt round-robin; pieces per tile vary by class
       const int u = slot + j * G;
-      tile = u / p.pk_f;
-      const int piece = u - tile * p.pk_f;
-      const int c = cls_of(tile);
+      int c = 0;
+      while (c + 1 < p.ncls && u >= p.cls_ubegin[c + 1]) ++c;
+      const int fc = p.cls_f[c];
+      const int local = u - p.cls_ubegin[c];
+      const int lt = local / fc;
+      const int piece = local - lt * fc;
+      tile = p.cls_begin[c] + lt;
       const int nkc = p.cls_nd[c][0] * p.cls_nd[c][1] * p.cls_nd[c][2] * cpt;
-      const int kps = (nkc + p.pk_f - 1) / p.pk_f;
+      const int kps = (nkc + fc - 1) / fc;
       k0 = piece * kps < nkc ? piece * kps : nkc;
       k1 = k0 + kps < nkc ? k0 + kps : nkc;
-      split = p.pk_f > 1 ? piece : -1;
+      split = fc > 1 ? piece : -1;
     } else if (j < n_full) {
       tile = slot + j * G; k0 = 0; k1 = nk; split = -1;
     } else {
@@ -1002,6 +1008,85 @@ __global__ __launch_bounds__(256) void splitk_reduce_bnb_kernel(const float* __r
     s += v;
     q += v * ((xv - mu) * is);
   }
+  sh[0][tid] = s;
+  sh[1][tid] = q;
+  __syncthreads();
+  if (r == 0) {
+    for (int k = 1; k < rpp; ++k) {
+      s += sh[0][k * G + g];
+      q += sh[1][k * G + g];
+    }
+    float* o = stats + (long long)blockIdx.x * 2 * C;
+    *reinterpret_cast<floatx4*>(o + g * 4) = s;
+    *reinterpret_cast<floatx4*>(o + C + g * 4) = q;
+  }
+}
+
+// Reduce of a strided dgrad whose stride-parity classes were K-split to different degrees (dispatch_igemm<1>):
+// the slabs are destination-shaped [f][M][C]; a row belongs to the class of its (t, h, w) parities and only rows
+// of classes with f > 1 pieces went through slabs (the others were written by the conv kernel directly, with
+// their BatchNorm-backward sums in its workgroup rows).  Same block shape as splitk_reduce_bnb_kernel; one
+// partial row [2][C] per block (zeros when the block owns no split row).
+struct ClsReduce {
+  int Td, Hd, Wd;
+  unsigned mgW, mgH, mgT;
+  int shW, shH, shT;
+  int pt, ph, pw;          // parity of (coordinate + pad) along a strided axis picks the class
+  int s2t, s2h, s2w;       // 1: the axis is strided
+  int f_by_par[8];         // pieces of the class with parity bits (t << 2 | h << 1 | w); 0 / 1: not split
+};
+
+template <bool BNB>
+__global__ __launch_bounds__(256) void splitk_reduce_cls_kernel(const float* __restrict__ part, float* __restrict__ dst,
+                                                                const float* __restrict__ addend, long long rows, int C,
+                                                                int rows_per_block, const ClsReduce cr,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int relu,
+                                                                float* __restrict__ stats) {
+  __shared__ floatx4 sh[2][256];
+  const int G = C >> 2, tid = threadIdx.x;
+  const int g = tid % G, r = tid / G, rpp = 256 / G;
+  const long long n4 = rows * G;
+  const long long row0 = (long long)blockIdx.x * rows_per_block;
+  floatx4 sc = {0, 0, 0, 0}, sf = sc, mu = sc, is = sc;
+  if (BNB) {
+    sc = reinterpret_cast<const floatx4*>(scale)[g]; sf = reinterpret_cast<const floatx4*>(shift)[g];
+    mu = reinterpret_cast<const floatx4*>(mean)[g]; is = reinterpret_cast<const floatx4*>(invstd)[g];
+  }
+  floatx4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  for (int k = r; k < rows_per_block; k += rpp) {
+    const long long row = row0 + k;
+    if (row >= rows) break;
+    const unsigned m = (unsigned)row;
+    const unsigned q1 = magic_div(m, cr.mgW, cr.shW);
+    const int wd = m - q1 * cr.Wd;
+    const unsigned q2 = magic_div(q1, cr.mgH, cr.shH);
+    const int hd = q1 - q2 * cr.Hd;
+    const unsigned b = magic_div(q2, cr.mgT, cr.shT);
+    const int td = q2 - b * cr.Td;
+    const int par = (cr.s2t ? ((td + cr.pt) & 1) << 2 : 0) | (cr.s2h ? ((hd + cr.ph) & 1) << 1 : 0) |
+                    (cr.s2w ? ((wd + cr.pw) & 1) : 0);
+    const int f = cr.f_by_par[par];
+    if (f <= 1) continue;
+    const long long i = row * G + g;
+    floatx4 v = reinterpret_cast<const floatx4*>(part)[i];
+    for (int j = 1; j < f; ++j) v += reinterpret_cast<const floatx4*>(part)[(long long)j * n4 + i];
+    if (addend) v += reinterpret_cast<const floatx4*>(addend)[i];
+    reinterpret_cast<floatx4*>(dst)[i] = v;
+    if (BNB) {
+      const floatx4 xv = reinterpret_cast<const floatx4*>(x)[i];
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(xv[j], sc[j], sf[j]) > 0.f ? v[j] : 0.f;
+      }
+      s += v;
+      q += v * ((xv - mu) * is);
+    }
+  }
+  if (!BNB) return;
   sh[0][tid] = s;
   sh[1][tid] = q;
   __syncthreads();
@@ -1906,13 +1991,6 @@ static void build_classes(ConvArgs& a, int BM) {
   a.cls_ptiles_total = begin;
 }
 
-// K pieces per tile of a strided dgrad: few (heavy, uneven) tiles are cut so that ~1000+ units can be dealt
-static int strided_splits(int total_tiles) {
-  if (total_tiles >= 768) return 1;
-  int f = (1024 + total_tiles - 1) / total_tiles;
-  return f > 8 ? 8 : f;
-}
-
 // Parity classes of a strided dgrad for the persistent kernel: tile-unit prefix sums, classes ordered by
 // decreasing tap count (the round-robin deal then gives every workgroup a similar mix), class extents'
 // division magics.  Classes without taps are kept: their pixels still have to be written (zeros / addend).
@@ -1961,49 +2039,129 @@ static int build_classes_pk(ConvArgs& a, int BM, int ntn) {
   return begin;
 }
 
+// K pieces per class of a strided dgrad.  The classes differ in K (a (1,3,3) / (1,2,2) layer has classes of 4, 2, 2
+// and 1 taps; a 1x1x1 / (2,2,2) residual convolution one class with its single tap and seven with none), so
+// cutting every tile into the same number of pieces (the first version: up to 8, every class through destination-
+// shaped slabs and one reduce over all of dx) made the tap-less classes pay slab traffic for nothing.  Here a piece
+// is ~L k-tiles whatever its class: f_c = ceil(nk_c / L), classes with f_c = 1 are written directly (addend,
+// BatchNorm-backward sums in the epilogue), only the rows of classes with f_c > 1 go through slabs.  L is the
+// candidate that minimises (rounds of units per CU) x (piece + per-unit overhead) + the slab pass.
+struct StridedPlan {
+  int f[8];
+  int units, grid;
+  bool any_split, any_direct;
+  int fmax;
+};
+static StridedPlan plan_strided(ConvArgs& k, int BM, int BN, size_t ws_floats) {
+  const int ntn = k.Cd / BN, cus = device_cus(), cpt = k.Cs / BK;
+  build_classes_pk(k, BM, ntn);
+  StridedPlan pl{};
+  int nk[8], tiles[8], nkmax = 0;
+  long long rows[8];
+  for (int c = 0; c < k.ncls; ++c) {
+    nk[c] = k.cls_nd[c][0] * k.cls_nd[c][1] * k.cls_nd[c][2] * cpt;
+    tiles[c] = k.cls_begin[c + 1] - k.cls_begin[c];
+    rows[c] = (long long)k.B * k.cls_n[c][0] * k.cls_n[c][1] * k.cls_n[c][2];
+    nkmax = nk[c] > nkmax ? nk[c] : nkmax;
+  }
+  const double ovh = 2.0;                                   // k-tiles of prologue / epilogue per unit
+  const double ktile_us = (BN == 128 ? 1.9 : 1.0);          // one k-tile of a CU at full MFMA rate
+  double best = 1e300;
+  for (int div = 1; div <= 8; ++div) {
+    const int L = nkmax > 0 ? (nkmax + div - 1) / div : 1;
+    if (div > 1 && L < 2) break;
+    int f[8], fmax = 1;
+    long long units = 0;
+    double piece = 0, slab_bytes = 0;
+    for (int c = 0; c < k.ncls; ++c) {
+      f[c] = nk[c] > 0 ? (nk[c] + L - 1) / L : 1;
+      if (f[c] > 8) f[c] = 8;
+      fmax = f[c] > fmax ? f[c] : fmax;
+      units += (long long)tiles[c] * f[c];
+      const double pc = nk[c] > 0 ? (double)((nk[c] + f[c] - 1) / f[c]) : 0.0;
+      piece = pc > piece ? pc : piece;
+      if (f[c] > 1) slab_bytes += 4.0 * rows[c] * k.Cd * (2.0 * f[c] + 2.0);
+    }
+    if (fmax > 1 && (size_t)fmax * (size_t)k.M * k.Cd > ws_floats) continue;   // no room for the slabs
+    // a CU's load: its share of all the k-tiles (+ the per-unit overhead) + one piece of imbalance
+    double work = 0;
+    for (int c = 0; c < k.ncls; ++c) work += (double)tiles[c] * (nk[c] + f[c] * ovh);
+    double cost = (work / cus + piece) * ktile_us;
+    if (fmax > 1) cost += 4.0 + slab_bytes / 4.0e6;                            // reduce launch + slab traffic at ~4 TB/s (us)
+    if (cost < best - 1e-9) {
+      best = cost;
+      for (int c = 0; c < k.ncls; ++c) pl.f[c] = f[c];
+      pl.units = (int)units;
+      pl.fmax = fmax;
+    }
+  }
+  pl.any_split = pl.fmax > 1;
+  pl.any_direct = false;
+  int ub = 0;
+  for (int c = 0; c < k.ncls; ++c) {
+    k.cls_f[c] = pl.f[c];
+    k.cls_ubegin[c] = ub;
+    ub += tiles[c] * pl.f[c];
+    if (pl.f[c] == 1) pl.any_direct = true;
+  }
+  k.cls_ubegin[k.ncls] = ub;
+  pl.grid = pl.units < 2 * cus ? pl.units : 2 * cus;
+  return pl;
+}
+
 template <int MODE>
 static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s) {
   if (MODE == 1 && (a.st > 1 || a.sh > 1 || a.sw > 1) && pk_enabled() && (long long)a.M * a.Cd * 4 < (1ll << 31) &&
       a.st <= 2 && a.sh <= 2 && a.sw <= 2) {
-    // strided dgrad on the persistent kernel: every class tile is dealt whole, heavy classes first
+    // strided dgrad on the persistent kernel: (class tile, K piece) units dealt round-robin, heavy classes first
     ConvArgs k = a;
     const bool wide = a.Cd % 128 == 0;
-    const int BN = wide ? 128 : 64, ntn = a.Cd / BN;
-    const int total = build_classes_pk(k, 128, ntn);
-    const int cus = device_cus();
-    int f = strided_splits(total);
-    if (f > 1 && (ws == nullptr || ws_bytes < sizeof(float) * (size_t)f * a.M * a.Cd)) f = 1;
+    const int BN = wide ? 128 : 64;
+    const StridedPlan pl = plan_strided(k, 128, BN, ws ? ws_bytes / sizeof(float) : 0);
     k.nsplit = 1;
     k.part = static_cast<float*>(ws);
     k.part_row_begin = 0;
-    k.pk_full = total * f;      // units: (tile, piece of its K range)
+    k.pk_full = pl.units;
     k.pk_tail_units = 0;
-    k.pk_f = f;
+    k.pk_f = 1;
     k.pk_kps = 0;
     k.pk_rot = 0;
-    const int grid = k.pk_full < 2 * cus ? k.pk_full : 2 * cus;
+    const int cus = device_cus();
+    const int grid = pl.grid;
     k.pk_paired = (grid == 2 * cus && grid % 16 == 0) ? 1 : 0;
-    // BatchNorm-backward partials: from the epilogue when tiles are written directly (f == 1: one row per
-    // workgroup), from the reduce when every tile is K-split
-    k.stats = (a.bnb_x && f == 1) ? a.stats : nullptr;
-    if (f > 1) k.bnb_x = nullptr;
+    // BatchNorm-backward partials: directly written tiles leave theirs in the workgroup rows [0, grid), the rows
+    // of K-split classes get theirs from the reduce (rows [grid, grid + reduce blocks))
+    if (!a.bnb_x) k.stats = nullptr;
     int rc = wide ? launch_pk<2, 2, 2, 2, 1, true>(k, grid, s) : launch_pk<4, 1, 1, 2, 1, true>(k, grid, s);
-    if (rc || f == 1) return rc;
-    if (a.bnb_x && a.stats) {
-      ScopedTimer t(s, "splitk_reduce_bnb_kernel", 0.0, 4.0 * a.M * a.Cd * (f + 2 + (a.addend ? 1 : 0)));
-      const int rpb = stats_rpb(a.M, a.Cd);
-      hipLaunchKernelGGL(splitk_reduce_bnb_kernel, dim3((unsigned)ceil_div((long long)a.M, rpb)), dim3(256), 0, s, k.part,
-                         a.dst, a.addend, (long long)a.M, a.Cd, f, rpb, a.bnb_x, a.bnb_scale, a.bnb_shift, a.bnb_mean,
-                         a.bnb_invstd, a.bnb_relu, a.stats);
-      return check_launch("splitk_reduce_bnb");
+    if (rc || !pl.any_split) return rc;
+    ClsReduce cr{};
+    cr.Td = a.Td; cr.Hd = a.Hd; cr.Wd = a.Wd;
+    magic_for(a.Wd, cr.mgW, cr.shW);
+    magic_for(a.Hd, cr.mgH, cr.shH);
+    magic_for(a.Td, cr.mgT, cr.shT);
+    cr.pt = a.pt; cr.ph = a.ph; cr.pw = a.pw;
+    cr.s2t = a.st == 2; cr.s2h = a.sh == 2; cr.s2w = a.sw == 2;
+    for (int c = 0; c < k.ncls; ++c) {   // class -> its parity bits: positions p with (p + pad) & 1 == (cls_p0 + pad) & 1
+      const int par = (cr.s2t ? ((k.cls_p0[c][0] + a.pt) & 1) << 2 : 0) | (cr.s2h ? ((k.cls_p0[c][1] + a.ph) & 1) << 1 : 0) |
+                      (cr.s2w ? ((k.cls_p0[c][2] + a.pw) & 1) : 0);
+      cr.f_by_par[par] = k.cls_f[c];
     }
-    const long long n4 = (long long)a.M * a.Cd / 4;
-    long long rgrid = ceil_div(n4, 256);
-    if (rgrid > 2048) rgrid = 2048;
-    ScopedTimer t(s, "splitk_reduce_kernel", 0.0, 4.0 * a.M * a.Cd * (f + 1 + (a.addend ? 1 : 0)));
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, k.part, a.dst, a.addend, nullptr, n4,
-                       a.Cd / 4, f, 0);
-    return check_launch("splitk_reduce");
+    double split_rows = 0;
+    for (int c = 0; c < k.ncls; ++c)
+      if (k.cls_f[c] > 1) split_rows += (double)a.B * k.cls_n[c][0] * k.cls_n[c][1] * k.cls_n[c][2];
+    const int rpb = stats_rpb(a.M, a.Cd);
+    const unsigned rgrid = (unsigned)ceil_div((long long)a.M, rpb);
+    if (a.bnb_x && a.stats) {
+      ScopedTimer t(s, "splitk_reduce_bnb_kernel", 0.0, 4.0 * split_rows * a.Cd * (pl.fmax + 2 + (a.addend ? 1 : 0)));
+      hipLaunchKernelGGL(splitk_reduce_cls_kernel<true>, dim3(rgrid), dim3(256), 0, s, k.part, a.dst, a.addend,
+                         (long long)a.M, a.Cd, rpb, cr, a.bnb_x, a.bnb_scale, a.bnb_shift, a.bnb_mean, a.bnb_invstd,
+                         a.bnb_relu, a.stats + (long long)grid * 2 * a.Cd);
+      return check_launch("splitk_reduce_cls");
+    }
+    ScopedTimer t(s, "splitk_reduce_kernel", 0.0, 4.0 * split_rows * a.Cd * (pl.fmax + 1 + (a.addend ? 1 : 0)));
+    hipLaunchKernelGGL(splitk_reduce_cls_kernel<false>, dim3(rgrid), dim3(256), 0, s, k.part, a.dst, a.addend,
+                       (long long)a.M, a.Cd, rpb, cr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+    return check_launch("splitk_reduce_cls");
   }
   if (MODE == 1 && (a.st > 1 || a.sh > 1 || a.sw > 1)) {   // strided dgrad: per-parity-class dense sub-problems
     a.nsplit = 1;
@@ -2306,12 +2464,9 @@ extern "C" size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d) {
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
   const int nk = trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK);
   size_t fl = igemm_ws_floats(M, d->Cin, nk);
-  if (d->st > 1 || d->sh > 1 || d->sw > 1) {   // strided: K pieces of the parity-class tiles (dispatch_igemm<1>)
-    const int ntn = d->Cin % 128 == 0 ? d->Cin / 128 : d->Cin / 64;
-    // upper bound of the class tile count: every class rounds up separately (<= 8 classes)
-    const long long tiles_lo = (M + 127) / 128 * ntn;
-    const size_t f = (size_t)strided_splits((int)(tiles_lo < (1 << 30) ? tiles_lo : (1 << 30)));
-    if (f > 1 && f * (size_t)M * d->Cin > fl) fl = f * (size_t)M * d->Cin;
+  if (d->st > 1 || d->sh > 1 || d->sw > 1) {   // strided: destination-shaped slabs of the K-split classes (<= 8 pieces)
+    const size_t want = (size_t)8 * (size_t)M * d->Cin;
+    if (want > fl) fl = want;
   }
   return dgrad_wt_bytes(d) + sizeof(float) * fl;
 }
@@ -2341,10 +2496,10 @@ extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
     fill_common(a, &tr.d);
     a.Td = d->Ti; a.Hd = d->Hi; a.Wd = d->Wi; a.Cd = d->Cin;
     const int BN = d->Cin % 128 == 0 ? 128 : 64;
-    const int total = build_classes_pk(a, 128, d->Cin / BN);
-    const int f = strided_splits(total);
-    if (f > 1) return (int)ceil_div(M, stats_rpb(M, d->Cin));
-    return total < 2 * device_cus() ? total : 2 * device_cus();
+    a.Cs = d->Cout;
+    a.M = (int)M;
+    const StridedPlan pl = plan_strided(a, 128, BN, (size_t)8 * (size_t)M * d->Cin);
+    return pl.grid + (pl.any_split ? (int)ceil_div(M, stats_rpb(M, d->Cin)) : 0);
   }
   const PkPlan pk = plan_pk(M, d->Cin, trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK));
   return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cin)) : 0);

@@ -126,8 +126,9 @@ def test_bn_handover_checks_for_a_second_consumer(gpu_device):
     """ops.BnSource hands a BatchNorm's backward partial sums over from the next convolution's dgrad — valid only
     if that dgrad's output is the BatchNorm output's WHOLE gradient.  A forward hook that puts an intermediate
     activation into the loss gives it a second consumer: the hand-over must then be dropped for that layer (the
-    BatchNorm's backward sees a summed gradient tensor it did not get from the dgrad) and the gradients equal the
-    run with the hand-over disabled, bit for bit."""
+    BatchNorm's backward sees a summed gradient tensor it did not get from the dgrad).  The other BatchNorms of the
+    block keep their hand-over, so the comparison with a run that has it disabled everywhere is to fp32
+    summation-order noise (1e-5 of scale); partial sums that missed the hook's branch would be off by O(1)."""
     from avid_hip import ops
     from models.network_blocks import BasicR2P1DBlock
     blk = BasicR2P1DBlock(64, 64)
@@ -155,7 +156,7 @@ def test_bn_handover_checks_for_a_second_consumer(gpu_device):
         ops.FUSE_BN_BWD = saved
         hook.remove()
     for a, b in zip(with_handover, without):
-        assert torch.equal(a, b)
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
 
 
 @pytest.mark.parametrize("relu", [False, True])

@@ -369,7 +369,7 @@ def test_full_step_vs_oracle_bs4(gpu_device):
     for n in pn:
         P[n].requires_grad_(True)
     # (a) free-running oracle: forward quantities agree to fp32 round-off, and the device's ReLU pattern (the one
-    # pinned in (b)) differs from the oracle's OWN pattern on at most 2e-6 of the ~4e7 signs, every one of them a
+    # pinned in (b)) differs from the oracle's OWN pattern on at most 2e-6 of the ~1.8e7 signs, every one of them a
     # pre-activation within 1e-4 of its layer's RMS of zero — a wrong mask in a fused epilogue cannot hide in (b)
     O.PREACT = {}
     try:
@@ -380,7 +380,7 @@ def test_full_step_vs_oracle_bs4(gpu_device):
         O.PREACT = None
     assert float((e1.detach().cpu() - ve0).abs().max() / ve0.abs().max()) < 2e-4
     assert float((e2.detach().cpu() - ae0).abs().max() / ae0.abs().max()) < 2e-4
-    assert elements > 3e7 and flips <= 2e-6 * elements and worst < 1e-4, (flips, elements, worst)
+    assert elements > 1.5e7 and flips <= 2e-6 * elements and worst < 1e-4, (flips, elements, worst)
     # (b) oracle with the device's ReLU pattern pinned: loss and ALL 141 parameter gradients to 5e-4 of scale
     O.RELU_MASKS = masks
     try:

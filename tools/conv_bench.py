@@ -25,7 +25,17 @@ L = [
  ("c5.spt_s2", 256, 512, (1,3,3), (1,2,2), (0,1,1), (2,7,7)),
  ("c5.spt", 512, 512, (1,3,3), (1,1,1), (0,1,1), (1,4,4)),
  ("c5.tmp", 512, 512, (3,1,1), (1,1,1), (1,0,0), (1,4,4)),
+ ("c4.tmp_s2", 256, 256, (3,1,1), (2,1,1), (1,0,0), (4,7,7)),
+ ("c4.res", 128, 256, (1,1,1), (2,2,2), (0,0,0), (4,14,14)),
+ ("c5.tmp_s2", 512, 512, (3,1,1), (2,1,1), (1,0,0), (2,4,4)),
+ ("c5.res", 256, 512, (1,1,1), (2,2,2), (0,0,0), (2,7,7)),
+ ("a.b1_s2", 64, 64, (1,3,3), (1,2,2), (0,1,1), (1,20,50)),
  ("a.b1", 64, 64, (1,3,3), (1,1,1), (0,1,1), (1,10,25)),
+ ("a.b2_s2", 64, 128, (1,3,3), (1,2,2), (0,1,1), (1,10,25)),
+ ("a.b2", 128, 128, (1,3,3), (1,1,1), (0,1,1), (1,5,13)),
+ ("a.b3_s2", 128, 256, (1,3,3), (1,2,2), (0,1,1), (1,5,13)),
+ ("a.b3", 256, 256, (1,3,3), (1,1,1), (0,1,1), (1,3,7)),
+ ("a.b4a", 256, 512, (1,3,3), (1,1,1), (0,1,1), (1,3,7)),
  ("a.b4", 512, 512, (1,3,3), (1,1,1), (0,1,1), (1,3,7)),
  ("g576", 576, 64, (1,1,1), (1,1,1), (0,0,0), (8,28,28)),
  ("g1152", 1152, 128, (1,1,1), (1,1,1), (0,0,0), (4,14,14)),
