@@ -218,6 +218,16 @@ def main():
             loss = engine.step(video, audio, ids[args.warmup + i])
     sync()
     dt = time.perf_counter() - t0
+    # host issue time: how long the host needs to ENQUEUE a step (5 steps issued back to back, nothing waited for) —
+    # the margin between it and ms_per_step is what a slower host may eat before the GPU starves
+    t0 = time.perf_counter()
+    for i in range(min(5, args.steps)):
+        if use_graph:
+            engine.replay(index=ids[args.warmup + i])
+        else:
+            engine.step(video, audio, ids[args.warmup + i])
+    host_issue_ms = (time.perf_counter() - t0) / min(5, args.steps) * 1e3
+    sync()
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -252,7 +262,7 @@ def main():
                                    "3x8x112x112 video + 1x40x100 audio",
                        "per_gpu_batch": bs, "global_batch": bs * world, "bank_rows": args.bank,
                        "negatives": args.negatives, "parallelism": f"dp{world}", "optimizer": "adam(2e-4, wd 1e-5)",
-                       "hipgraph": use_graph,
+                       "hipgraph": use_graph, "host_issue_ms_per_step": round(host_issue_ms, 3),
                        "loss": round(loss_val, 5)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,

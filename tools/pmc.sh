@@ -4,7 +4,8 @@ set -u
 OUT=$1; shift
 export TMPDIR=/tmp
 R=$PWD
-mkdir -p $R/$OUT
+case $OUT in /*) ;; *) OUT=$R/$OUT;; esac      # absolute or relative to the caller's directory
+mkdir -p $OUT
 cd /tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES" \
@@ -12,7 +13,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "GRBM_GUI_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_UNALIGNED_STALL" \
            "FETCH_SIZE" "WRITE_SIZE TCC_HIT TCC_MISS"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$OUT/p$i -o p$i -- "$@" > $R/$OUT/p$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p$i -- "$@" > $OUT/p$i.log 2>&1
 done
 cd $R
 python - "$OUT" <<'PY'

@@ -17,8 +17,10 @@ for r in csv.DictReader(open(summary)):
     short = m.group(1)
     if m.group(2):
         args = [a.strip() for a in m.group(2).split(",")]
-        strided = args[-1] == "true" if args[-1] in ("true", "false") else False
-        if args[-1] in ("true", "false"): args = args[:-1]
+        strided = False
+        if short.startswith(("igemm", "stem")) and args[-1] in ("true", "false"):   # trailing bool = STRIDED
+            strided = args[-1] == "true"
+            args = args[:-1]
         short += "<" + ",".join(args) + ">" + ("s2" if strided else "")
     res[short] = round((2 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024 / n)
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
