@@ -364,7 +364,16 @@ __device__ __forceinline__ unsigned magic_div(unsigned n, unsigned magic, int sh
   return (unsigned)(((unsigned long long)n * magic) >> shift);
 }
 
-template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
+// EPI: the epilogue of directly written tiles, fixed at compile time (one variant per instantiation):
+//   forward  0 plain   1 + addend   2 + bias   3 + bias, ReLU   4 min(., addend)   5 max(., addend)
+//   dgrad    0 plain   1 + addend   8 BatchNorm-backward sums   9 + addend and those sums
+//   15       any other combination, told apart at run time (the pre-specialisation code)
+// With several LOADING variants in one kernel the compiler hoisted their common loads above the variant branch;
+// on the paths that do not consume them they stayed "pending" into the k-loop header, and the waitcnt pass then
+// put `s_waitcnt vmcnt(1)` in front of the first MFMA of EVERY k-tile (the tile loads were supposed to be
+// waited for one by one, behind the first six MFMAs): 2-7 % of every dense kernel.
+constexpr int EPI_ANY = 15;
+template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false, int EPI = EPI_ANY>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArgs p) {
   static_assert(!STRIDED || MODE == 1, "parity classes are a dgrad construct");
   constexpr int NT = WM * WN * 64;
@@ -834,8 +843,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       };
       constexpr std::true_type Y{};
       constexpr std::false_type N{};
-      if (direct && p.bnb_x) { if (p.addend) emit(Y, Y); else emit(N, Y); }
-      else if (direct && p.addend) emit(Y, N);
+      if (!direct) emit(N, N);
+      else if (EPI == 9) emit(Y, Y);
+      else if (EPI == 8) emit(N, Y);
+      else if (EPI == 1) emit(Y, N);
+      else if (EPI == 0) emit(N, N);
+      else if (p.bnb_x) { if (p.addend) emit(Y, Y); else emit(N, Y); }
+      else if (p.addend) emit(Y, N);
       else emit(N, N);
       continue;
     }
@@ -854,7 +868,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
         (void*)(p.bnb_x ? p.bnb_x + d_base : p.dst + d_base), 0, rows * row_bytes, 0x00020000);
     // The uniform cases are told apart once per tile, not per element: the element loops below are straight
     // lines of (load,) VALU, store.
-    auto emit = [&](auto DIRECT, auto HAS_ADD, auto RELU, auto OP, auto BNB) {   // OP: addend combines by 0 add, 1 min, 2 max
+    auto emit = [&](auto DIRECT, auto HAS_ADD, auto RELU, auto OP, auto BNB, auto BIAS) {   // OP: addend combines by 0 add, 1 min, 2 max; BIAS: 0 none, 1 yes, 2 if p.bias
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -868,7 +882,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
               ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                     rsE, voff, ((r & 3) + 8 * (r >> 2)) * row_bytes, 0));
           }
-          const float bv = (DIRECT && p.bias) ? p.bias[col] : 0.f;
+          const float bv = (DIRECT && decltype(BIAS)::value != 0 && (decltype(BIAS)::value == 1 || p.bias)) ? p.bias[col] : 0.f;
           float xb[16], bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
           if (BNB) {   // the BatchNorm input at the positions of this tile + this column's saved coefficients
 #pragma unroll
@@ -900,16 +914,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     constexpr std::true_type Y{};
     constexpr std::false_type N{};
     constexpr std::integral_constant<int, 0> ADD{};
-    if (!direct) emit(N, N, N, ADD, N);
-    else if (MODE == 1 && p.bnb_x) {
-      if (p.addend) emit(Y, Y, N, ADD, Y); else emit(Y, N, N, ADD, Y);
+    constexpr std::integral_constant<int, 0> B0{};
+    constexpr std::integral_constant<int, 1> B1{};
+    constexpr std::integral_constant<int, 2> BQ{};
+    if (!direct) emit(N, N, N, ADD, N, B0);
+    else if (EPI == 0) emit(Y, N, N, ADD, N, B0);
+    else if (EPI == 1) emit(Y, Y, N, ADD, N, B0);
+    else if (MODE == 0 && EPI == 2) emit(Y, N, N, ADD, N, B1);
+    else if (MODE == 0 && EPI == 3) emit(Y, N, Y, ADD, N, B1);
+    else if (MODE == 0 && EPI == 4) emit(Y, Y, N, std::integral_constant<int, 1>{}, N, B0);      // CMA agreement scores
+    else if (MODE == 0 && EPI == 5) emit(Y, Y, N, std::integral_constant<int, 2>{}, N, B0);
+    else if (MODE == 1 && EPI == 8) emit(Y, N, N, ADD, Y, B0);
+    else if (MODE == 1 && EPI == 9) emit(Y, Y, N, ADD, Y, B0);
+    else if (MODE == 1 && p.bnb_x) {      // EPI_ANY: every combination, at run time
+      if (p.addend) emit(Y, Y, N, ADD, Y, BQ); else emit(Y, N, N, ADD, Y, BQ);
     } else if (p.addend) {
-      if (MODE == 0 && p.epi_op == 1) emit(Y, Y, N, std::integral_constant<int, 1>{}, N);        // CMA agreement scores
-      else if (MODE == 0 && p.epi_op == 2) emit(Y, Y, N, std::integral_constant<int, 2>{}, N);
-      else if (p.relu) emit(Y, Y, Y, ADD, N);
-      else emit(Y, Y, N, ADD, N);
+      if (MODE == 0 && p.epi_op == 1) emit(Y, Y, N, std::integral_constant<int, 1>{}, N, BQ);
+      else if (MODE == 0 && p.epi_op == 2) emit(Y, Y, N, std::integral_constant<int, 2>{}, N, BQ);
+      else if (p.relu) emit(Y, Y, Y, ADD, N, BQ);
+      else emit(Y, Y, N, ADD, N, BQ);
     } else {
-      if (p.relu) emit(Y, N, Y, ADD, N); else emit(Y, N, N, ADD, N);
+      if (p.relu) emit(Y, N, Y, ADD, N, BQ); else emit(Y, N, N, ADD, N, BQ);
     }
   }
   write_stats();
@@ -1906,16 +1931,36 @@ static void magic_for(int d, unsigned& magic, int& shift) {
   magic = (unsigned)(((1ull << shift) + (unsigned)d - 1) / (unsigned)d);
 }
 
-template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
-static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + (STRIDED ? sizeof(int) * BM : 0);
+// the epilogue variant (igemm_pk_kernel's EPI) of a launch
+template <int MODE>
+static int epi_code(const ConvArgs& a) {
+  if (MODE == 1) {
+    if (a.bias || a.relu || a.epi_op) return EPI_ANY;
+    return (a.bnb_x ? 8 : 0) | (a.addend ? 1 : 0);
+  }
+  if (a.addend) {
+    if (a.bias || a.relu) return EPI_ANY;
+    return a.epi_op == 0 ? 1 : (a.epi_op == 1 ? 4 : 5);
+  }
+  if (a.bias) return a.relu ? 3 : 2;
+  return a.relu ? EPI_ANY : 0;
+}
+
+template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED, int EPI>
+static void launch_pk_e(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = igemm_pk_kernel<WM, WN, TM, TN, MODE, STRIDED>;
+  auto kern = igemm_pk_kernel<WM, WN, TM, TN, MODE, STRIDED, EPI>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
+}
+
+template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
+static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + (STRIDED ? sizeof(int) * BM : 0);
   static char name[64] = "";
   if (!name[0]) snprintf(name, sizeof(name), "igemm_pk_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, MODE, STRIDED ? "s2" : "");
   const double K = (double)a.kt * a.kh * a.kw * a.Cs;
@@ -1928,7 +1973,19 @@ static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
   const double flops = MODE == 1 ? 2.0 * srcpix * a.Cd * K : 2.0 * a.M * a.Cd * K;
   ScopedTimer t(s, name, flops,
                 4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (1 + (a.addend ? 1 : 0) + (a.bnb_x ? 1 : 0))));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
+  constexpr bool MAIN = (WM * WN == 4);   // the 4-wave tiles every layer runs on; the 8-wave A/B tiles keep the generic epilogue
+  const int epi = MAIN ? epi_code<MODE>(a) : EPI_ANY;
+  switch (epi) {
+    case 0: launch_pk_e<WM, WN, TM, TN, MODE, STRIDED, MAIN ? 0 : EPI_ANY>(a, grid, lds, s); break;
+    case 1: launch_pk_e<WM, WN, TM, TN, MODE, STRIDED, MAIN ? 1 : EPI_ANY>(a, grid, lds, s); break;
+    case 2: launch_pk_e<WM, WN, TM, TN, MODE, STRIDED, (MAIN && MODE == 0 && !STRIDED) ? 2 : EPI_ANY>(a, grid, lds, s); break;
+    case 3: launch_pk_e<WM, WN, TM, TN, MODE, STRIDED, (MAIN && MODE == 0 && !STRIDED) ? 3 : EPI_ANY>(a, grid, lds, s); break;
+    case 4: launch_pk_e<WM, WN, TM, TN, MODE, STRIDED, (MAIN && MODE == 0 && !STRIDED) ? 4 : EPI_ANY>(a, grid, lds, s); break;
+    case 5: launch_pk_e<WM, WN, TM, TN, MODE, STRIDED, (MAIN && MODE == 0 && !STRIDED) ? 5 : EPI_ANY>(a, grid, lds, s); break;
+    case 8: launch_pk_e<WM, WN, TM, TN, MODE, STRIDED, (MAIN && MODE == 1) ? 8 : EPI_ANY>(a, grid, lds, s); break;
+    case 9: launch_pk_e<WM, WN, TM, TN, MODE, STRIDED, (MAIN && MODE == 1) ? 9 : EPI_ANY>(a, grid, lds, s); break;
+    default: launch_pk_e<WM, WN, TM, TN, MODE, STRIDED, EPI_ANY>(a, grid, lds, s); break;
+  }
   return check_launch("igemm_pk");
 }
 

@@ -1,27 +1,41 @@
 """profiles/<pmc_summary>.csv (+ the kernel trace of the same run for launch counts) -> profiles/pmc_traffic.json:
 HBM bytes per launch per kernel = (2 * FETCH_SIZE + WRITE_SIZE) KiB / launches  (FETCH_SIZE is doubled as
-MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is uncalibrated there and taken as is)."""
+MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is uncalibrated there and taken as is).
+Keys are the names the library's HIP-event timers (and bench.py) use: the epilogue variants of igemm_pk_kernel
+(its last template argument) are one kernel there, so their bytes and launches are pooled."""
 import csv, json, re, sys, collections
 summary, trace, out = sys.argv[1], sys.argv[2], sys.argv[3]
 calls = collections.Counter()
 for r in csv.DictReader(open(trace)):
     calls[r["Kernel_Name"].split("(")[0]] += 1
-res = {}
-for r in csv.DictReader(open(summary)):
-    name = r["kernel"].replace(";", ",")
-    key = next((k for k in calls if k.replace(" ", "")[:60] == name.replace(" ", "")[:60]), None)
-    n = calls.get(key, 0)
-    if not n: continue
+
+
+def short_name(name):
     m = re.match(r"(?:void )?avid::(\w+)(?:<(.*)>)?", name)
-    if not m: continue
+    if not m:
+        return None
     short = m.group(1)
     if m.group(2):
         args = [a.strip() for a in m.group(2).split(",")]
         strided = False
-        if short.startswith(("igemm", "stem")) and args[-1] in ("true", "false"):   # trailing bool = STRIDED
-            strided = args[-1] == "true"
-            args = args[:-1]
+        if short == "igemm_pk_kernel" and len(args) >= 7:          # <WM,WN,TM,TN,MODE,STRIDED,EPI>
+            strided, args = args[5] == "true", args[:5]
+        elif short.startswith(("igemm", "stem")) and args[-1] in ("true", "false"):   # trailing bool = STRIDED
+            strided, args = args[-1] == "true", args[:-1]
         short += "<" + ",".join(args) + ">" + ("s2" if strided else "")
-    res[short] = round((2 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024 / n)
+    return short
+
+
+tot_bytes, tot_calls = collections.Counter(), collections.Counter()
+for r in csv.DictReader(open(summary)):
+    name = r["kernel"].replace(";", ",")
+    key = next((k for k in calls if k.replace(" ", "")[:60] == name.replace(" ", "")[:60]), None)
+    n = calls.get(key, 0)
+    short = short_name(name)
+    if not n or short is None:
+        continue
+    tot_bytes[short] += (2 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024
+    tot_calls[short] += n
+res = {k: round(tot_bytes[k] / tot_calls[k]) for k in tot_bytes}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
