@@ -327,8 +327,9 @@ class _ConvCL(Function):
     """y = conv(x, w) [+ addend] [+ bias] [relu]  — avid_conv_fwd / avid_conv_dgrad / avid_conv_wgrad."""
 
     @staticmethod
-    def forward(ctx, x, w, addend, bias, stride, pad, relu, channel_first, want_stats=False, tap=False, bn_src=None):
-        _need_cuda(x, w, addend, bias)
+    def forward(ctx, x, w, addend, bias, stride, pad, relu, channel_first, want_stats=False, tap=False, bn_src=None,
+                res_w=None, res_stride=None):
+        _need_cuda(x, w, addend, bias, res_w)
         ctx.bn_src = bn_src
         if not x.is_contiguous():
             raise AvidHipError("conv: x must be contiguous (channels-last [B,T,H,W,C])")
@@ -359,7 +360,22 @@ class _ConvCL(Function):
         ctx.d, ctx.relu, ctx.channel_first = d, relu, channel_first
         ctx.has_addend, ctx.has_bias = addend is not None, bias is not None
         ctx.bias_ptr = bias.data_ptr() if bias is not None else 0
-        ctx.save_for_backward(x, w, y if relu else None)
+        # The block's 1x1x1 strided residual convolution on the same input (models/network_blocks.py:47-51): computed
+        # here so that its input gradient can stay COMPACT (the sub-sampled grid it reads) and ride in this op's
+        # dgrad as a sparse addend, instead of being scattered into an x-shaped tensor of mostly zeros first.
+        ctx.has_res = res_w is not None
+        y_res = None
+        if ctx.has_res:
+            if tap or channel_first or _kdims(res_w) != (1, 1, 1) or res_w.shape[1] != cin or not weight_layout_ok(res_w):
+                raise AvidHipError("conv: the fused residual convolution must be 1x1x1 over the same channels-last input")
+            rs = tuple(int(v) for v in res_stride)
+            dr, nbr, _, ctx.nb_wgrad_r, _ = _desc_cached((B, Ti, Hi, Wi), cin, res_w.shape[0], (1, 1, 1), rs, (0, 0, 0), False)
+            y_res = torch.empty((B, dr.To, dr.Ho, dr.Wo, res_w.shape[0]), dtype=torch.float32, device=x.device)
+            wsr = workspace(x.device, nbr) if nbr else None
+            lib.call("avid_conv_fwd", C.byref(dr), _p(x), _p(res_w), None, None, 0, _p(y_res), None, _p(wsr),
+                     wsr.numel() if wsr is not None else 0, _stream())
+            ctx.dr, ctx.res_stride = dr, rs
+        ctx.save_for_backward(x, w, y if relu else None, res_w)
         ctx.want_stats, ctx.tap = want_stats, tap
         ctx.set_materialize_grads(False)   # no zero-fill kernel for the outputs that get no gradient
         outs = [y]
@@ -372,15 +388,20 @@ class _ConvCL(Function):
             # an alias of the input for a second consumer (the residual branch): its gradient comes back into
             # THIS backward and rides in the dgrad kernel's addend — no separate accumulate kernel
             outs.append(x.view(x.shape))
+        if ctx.has_res:
+            outs.append(y_res)
         return outs[0] if len(outs) == 1 else tuple(outs)
 
     @staticmethod
     def backward(ctx, dy, *more):
-        x, w, y = ctx.saved_tensors
+        x, w, y, res_w = ctx.saved_tensors
         d = ctx.d
         d_tap = more[-1] if (ctx.tap and more) else None
-        if dy is None:                     # only the tap carried a gradient
-            return d_tap, None, None, None, None, None, None, None, None, None, None
+        d_res = more[-1] if (ctx.has_res and more) else None
+        if dy is None and d_res is None:   # only the tap carried a gradient
+            return d_tap, None, None, None, None, None, None, None, None, None, None, None, None
+        if dy is None:
+            raise AvidHipError("conv: the main output of a convolution with a fused residual branch got no gradient")
         dy = dy.contiguous()
         if d_tap is not None:
             d_tap = d_tap.contiguous()
@@ -413,6 +434,28 @@ class _ConvCL(Function):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 dw = run_wgrad()
+        add, add_stride, dw_res = d_tap, None, None
+        if d_res is not None:
+            d_res = d_res.contiguous()
+            dr = ctx.dr
+            if need_dx:
+                # compact input gradient of the residual convolution: a dense 1x1x1 dgrad over the sub-sampled grid
+                dc, _, nbc, _, _ = _desc_cached((d.B, dr.To, dr.Ho, dr.Wo), d.Cin, dr.Cout, (1, 1, 1), (1, 1, 1), (0, 0, 0),
+                                                False)
+                add = torch.empty((d.B, dr.To, dr.Ho, dr.Wo, d.Cin), dtype=torch.float32, device=x.device)
+                wsc = workspace(x.device, nbc)
+                lib.call("avid_conv_dgrad", C.byref(dc), _p(d_res), _p(res_w), _p(_wt_for(res_w)), None, None, _p(add), None,
+                         _p(wsc), wsc.numel(), st)
+                if any(v != 1 for v in ctx.res_stride):
+                    add_stride = (C.c_int32 * 3)(*ctx.res_stride)
+            if ctx.needs_input_grad[11]:
+                wsr = workspace(x.device, ctx.nb_wgrad_r)
+                g, slot = _grad_dst(res_w.data_ptr(), like=res_w)
+                lib.call("avid_conv_wgrad", C.byref(dr), _p(x), _p(d_res), _p(g), _p(wsr), wsr.numel(), st)
+                if slot is not None:
+                    _grad_done(slot)
+                else:
+                    dw_res = g
         if need_dx:
             ws = workspace(x.device, ctx.nb_dgrad)
             dx = torch.empty_like(x)
@@ -426,7 +469,7 @@ class _ConvCL(Function):
                 s4 = src.stats4
                 fuse = lib.BnBwdFuse(_p(src.x), _p(s4[2]), _p(s4[3]), _p(s4[0]), _p(s4[1]), int(src.relu),
                                      _p(src.partials))
-            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_wt_for(w)), _p(d_tap), _p(dx),
+            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_wt_for(w)), _p(add), add_stride, _p(dx),
                      C.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), st)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
@@ -446,16 +489,21 @@ class _ConvCL(Function):
                 dbias = None
         if d_tap is not None and not need_dx:
             dx = d_tap
-        return dx, dw, dadd, dbias, None, None, None, None, None, None, None
+        return dx, dw, dadd, dbias, None, None, None, None, None, None, None, dw_res, None
 
 
 def conv_cl(x, w, stride=(1, 1, 1), pad=(0, 0, 0), addend=None, bias=None, relu=False, channel_first=False,
-            bn_stats=False, tap=False, bn_src=None):
+            bn_stats=False, tap=False, bn_src=None, res=None):
     """``bn_stats=True`` adds ``partials`` to the result: y's BatchNorm partial sums from the conv epilogue (pass
     them to ``batch_norm_cl``), or an empty tensor when the layer cannot produce them.  ``tap=True`` adds an
     alias of ``x`` for a second consumer whose gradient is then summed inside this op's dgrad kernel.
     ``bn_src`` (a ``BnSource``): x is the output of that BatchNorm and this conv (with its tap, if any) is the
-    only consumer — the BatchNorm's backward partial sums are then produced by this op's dgrad kernel."""
+    only consumer — the BatchNorm's backward partial sums are then produced by this op's dgrad kernel.
+    ``res = (res_weight, res_stride)``: the block's 1x1x1 strided residual convolution of the same x is computed
+    too (last element of the result); its input gradient stays compact and is added inside this op's dgrad."""
+    if res is not None:      # ``res = (weight, stride)``: also return the 1x1x1 strided residual convolution of x
+        return _ConvCL.apply(x, w, addend, bias, tuple(stride), tuple(pad), bool(relu), bool(channel_first),
+                             bool(bn_stats), bool(tap), bn_src, res[0], tuple(res[1]))
     if bn_stats or tap or bn_src is not None:
         return _ConvCL.apply(x, w, addend, bias, tuple(stride), tuple(pad), bool(relu), bool(channel_first),
                              bool(bn_stats), bool(tap), bn_src)

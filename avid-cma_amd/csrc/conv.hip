@@ -66,6 +66,10 @@ struct ConvArgs {
   int pk_full, pk_tail_units, pk_f, pk_kps;
   unsigned cls_mg[8][3];   // igemm_pk_kernel<STRIDED>: multiply-shift division by a class's (T,H,W) extents
   int cls_shf[8][3];
+  // Strided dgrad: `addend` may be COMPACT — the gradient of a sub-sampled view x[:, ::add_s[0], ::add_s[1], ::add_s[2]]
+  // (the input gradient of the block's 1x1x1 strided residual convolution), shape [B][add_n[0]][add_n[1]][add_n[2]][Cd]:
+  // it contributes only at positions divisible by the strides.  add_s = {1,1,1}: the usual dx-shaped addend.
+  int add_s[3], add_n[3];
   int cls_f[8];            // igemm_pk_kernel<STRIDED>: K pieces per tile of class c (1: tiles written directly)
   int cls_ubegin[9];       // ... and the first work unit (tile, piece) of class c (prefix sums; [ncls] = total)
   float* stats;    // BatchNorm partial sums [rows][2][Cd] of the output (igemm_pk_kernel forward), or null
@@ -783,6 +787,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       // class-local rows -> destination pixels are not an affine map: one decode per tile row into LDS, then
       // buffer stores through the looked-up row offsets (rows past the class fall off num_records)
       int* drow = reinterpret_cast<int*>(smem + 2 * STAGE);
+      int* arow = drow + BM;               // row offsets into the addend (== drow unless the addend is compact)
+      const bool sparse_add = p.add_s[0] * p.add_s[1] * p.add_s[2] > 1;
       const int c = cls_of(tile);
       const int lt = tile - p.cls_begin[c];
       const int mt = lt / ntn, nt = lt - mt * ntn;
@@ -802,13 +808,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
         const int dst = ((b * p.Td + p.cls_p0[c][0] + td * p.st) * p.Hd + p.cls_p0[c][1] + hd * p.sh) * p.Wd +
                         p.cls_p0[c][2] + wd * p.sw;
         drow[tid] = ok ? dst * row_bytes : (int)OOB;
+        if (sparse_add) {   // strides are 1 or 2: position -> compact position where every strided coordinate is even
+          const int t = p.cls_p0[c][0] + td * p.st, hh = p.cls_p0[c][1] + hd * p.sh, w = p.cls_p0[c][2] + wd * p.sw;
+          const bool on = ok && (t & (p.add_s[0] - 1)) == 0 && (hh & (p.add_s[1] - 1)) == 0 && (w & (p.add_s[2] - 1)) == 0;
+          const int ar = ((b * p.add_n[0] + (t >> (p.add_s[0] - 1))) * p.add_n[1] + (hh >> (p.add_s[1] - 1))) * p.add_n[2] +
+                         (w >> (p.add_s[2] - 1));
+          arow[tid] = on ? ar * row_bytes : (int)OOB;
+        } else {
+          arow[tid] = ok ? dst * row_bytes : (int)OOB;
+        }
       }
       __syncthreads();
       const bool direct = split < 0;   // K-split pieces write raw sums to their slab, in destination row order
       const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(direct ? p.dst : p.part + (long long)split * p.M * p.Cd), 0, (int)((long long)p.M * row_bytes), 0x00020000);
+      const long long add_rows = sparse_add ? (long long)p.B * p.add_n[0] * p.add_n[1] * p.add_n[2] : (long long)p.M;
       const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.addend ? p.addend : p.dst), 0, (int)((long long)p.M * row_bytes), 0x00020000);
+          (void*)(p.addend ? p.addend : p.dst), 0, (int)(add_rows * row_bytes), 0x00020000);
       const __amdgpu_buffer_rsrc_t rsXb = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(p.bnb_x ? p.bnb_x : p.dst), 0, (int)((long long)p.M * row_bytes), 0x00020000);
       auto emit = [&](auto HAS_ADD, auto BNB) {
@@ -822,8 +838,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
             float ad[16], xb[16], bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              voff[r] = (unsigned)drow[(wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] + col4;
-              if (HAS_ADD) ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, voff[r], 0, 0));
+              const int trow = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+              voff[r] = (unsigned)drow[trow] + col4;
+              if (HAS_ADD)    // (a row the compact addend does not cover is out of range: the load returns 0)
+                ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, (unsigned)arow[trow] + col4, 0, 0));
               if (BNB) xb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsXb, voff[r], 0, 0));
             }
             if (BNB) { bsc = p.bnb_scale[col]; bsh = p.bnb_shift[col]; bmu = p.bnb_mean[col]; bis = p.bnb_invstd[col]; }
@@ -1059,6 +1077,7 @@ struct ClsReduce {
   int pt, ph, pw;          // parity of (coordinate + pad) along a strided axis picks the class
   int s2t, s2h, s2w;       // 1: the axis is strided
   int f_by_par[8];         // pieces of the class with parity bits (t << 2 | h << 1 | w); 0 / 1: not split
+  int add_s[3], add_n[3];  // compact addend (ConvArgs::add_s / add_n); {1,1,1}: dx-shaped
 };
 
 template <bool BNB>
@@ -1099,7 +1118,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_cls_kernel(const float* __r
     const long long i = row * G + g;
     floatx4 v = reinterpret_cast<const floatx4*>(part)[i];
     for (int j = 1; j < f; ++j) v += reinterpret_cast<const floatx4*>(part)[(long long)j * n4 + i];
-    if (addend) v += reinterpret_cast<const floatx4*>(addend)[i];
+    if (addend) {
+      if (cr.add_s[0] * cr.add_s[1] * cr.add_s[2] > 1) {
+        if (((td & (cr.add_s[0] - 1)) | (hd & (cr.add_s[1] - 1)) | (wd & (cr.add_s[2] - 1))) == 0) {
+          const long long ar = (((long long)b * cr.add_n[0] + (td >> (cr.add_s[0] - 1))) * cr.add_n[1] + (hd >> (cr.add_s[1] - 1))) *
+                                   cr.add_n[2] + (wd >> (cr.add_s[2] - 1));
+          v += reinterpret_cast<const floatx4*>(addend)[ar * G + g];
+        }
+      } else {
+        v += reinterpret_cast<const floatx4*>(addend)[i];
+      }
+    }
     reinterpret_cast<floatx4*>(dst)[i] = v;
     if (BNB) {
       const floatx4 xv = reinterpret_cast<const floatx4*>(x)[i];
@@ -1960,7 +1989,7 @@ static void launch_pk_e(const ConvArgs& a, int grid, size_t lds, hipStream_t s) 
 template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
 static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + (STRIDED ? sizeof(int) * BM : 0);
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + (STRIDED ? sizeof(int) * 2 * BM : 0);
   static char name[64] = "";
   if (!name[0]) snprintf(name, sizeof(name), "igemm_pk_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, MODE, STRIDED ? "s2" : "");
   const double K = (double)a.kt * a.kh * a.kw * a.Cs;
@@ -2198,6 +2227,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     magic_for(a.Td, cr.mgT, cr.shT);
     cr.pt = a.pt; cr.ph = a.ph; cr.pw = a.pw;
     cr.s2t = a.st == 2; cr.s2h = a.sh == 2; cr.s2w = a.sw == 2;
+    for (int x = 0; x < 3; ++x) { cr.add_s[x] = a.add_s[x]; cr.add_n[x] = a.add_n[x]; }
     for (int c = 0; c < k.ncls; ++c) {   // class -> its parity bits: positions p with (p + pad) & 1 == (cls_p0 + pad) & 1
       const int par = (cr.s2t ? ((k.cls_p0[c][0] + a.pt) & 1) << 2 : 0) | (cr.s2h ? ((k.cls_p0[c][1] + a.ph) & 1) << 1 : 0) |
                       (cr.s2w ? ((k.cls_p0[c][2] + a.pw) & 1) : 0);
@@ -2426,6 +2456,8 @@ static void fill_common(ConvArgs& a, const avid_conv_desc* d) {
   a.mt2_begin = 0;
   a.mt2_count = 0;
   a.part_row_begin = 0;
+  a.add_s[0] = a.add_s[1] = a.add_s[2] = 1;
+  a.add_n[0] = a.add_n[1] = a.add_n[2] = 0;
 }
 
 // C[M][N] = A[M][K] . Bq[N][K]^T, optionally combined with Cin by min / max — the similarity GEMMs of
@@ -2449,6 +2481,8 @@ int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin,
   a.bnb_x = a.bnb_scale = a.bnb_shift = a.bnb_mean = a.bnb_invstd = nullptr;
   a.bnb_relu = 0;
   a.mgW = a.mgH = a.mgT = 0; a.shW = a.shH = a.shT = 0;
+  a.add_s[0] = a.add_s[1] = a.add_s[2] = 1;
+  a.add_n[0] = a.add_n[1] = a.add_n[2] = 0;
   // persistent kernel, no K-split (K = 128: 4 k-tiles per tile, thousands of tiles): 54 -> ~90 TFLOP/s
   if (pk_enabled()) return dispatch_igemm<0>(a, nullptr, 0, s);
   return launch_igemm<4, 1, 1, 2, 0>(a, s);
@@ -2563,11 +2597,21 @@ extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
 }
 
 extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* wt_in,
-                               const float* addend, float* dx, const avid_bn_bwd_fuse* bn, void* ws, size_t ws_bytes,
-                               avid_stream_t stream) {
+                               const float* addend, const int32_t* addend_stride, float* dx, const avid_bn_bwd_fuse* bn,
+                               void* ws, size_t ws_bytes, avid_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
   AVID_REQUIRE(dy && w && dx && ws, AVID_E_BADARG, "conv_dgrad: null pointer");
+  bool sparse_add = false;
+  if (addend && addend_stride) {
+    for (int x = 0; x < 3; ++x) {
+      AVID_REQUIRE(addend_stride[x] == 1 || addend_stride[x] == 2, AVID_E_UNSUPPORTED, "conv_dgrad: addend strides must be 1 or 2");
+      sparse_add |= addend_stride[x] == 2;
+    }
+    AVID_REQUIRE(!sparse_add || (pk_enabled() && (d->st > 1 || d->sh > 1 || d->sw > 1) &&
+                                 (long long)d->B * d->Ti * d->Hi * d->Wi * d->Cin * 4 < (1ll << 31)),
+                 AVID_E_UNSUPPORTED, "conv_dgrad: a compact addend needs a strided layer on the persistent kernel");
+  }
   if (bn) {
     AVID_REQUIRE(bn->x && bn->scale && bn->shift && bn->mean && bn->invstd && bn->partials, AVID_E_BADARG,
                  "conv_dgrad: incomplete BatchNorm descriptor");
@@ -2612,6 +2656,13 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
   a.mode = 1;
   a.relu = 0;
   a.ssB = a.ssT = a.ssH = a.ssW = a.ssC = 0;
+  if (sparse_add) {
+    const int D[3] = {d->Ti, d->Hi, d->Wi};
+    for (int x = 0; x < 3; ++x) {
+      a.add_s[x] = addend_stride[x];
+      a.add_n[x] = (D[x] + addend_stride[x] - 1) / addend_stride[x];
+    }
+  }
   if (bn) {
     a.bnb_x = bn->x; a.bnb_scale = bn->scale; a.bnb_shift = bn->shift; a.bnb_mean = bn->mean;
     a.bnb_invstd = bn->invstd; a.bnb_relu = bn->relu;

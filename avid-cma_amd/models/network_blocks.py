@@ -35,11 +35,11 @@ class ConvCL(nn.Module):
         self.weight = nn.Parameter(ops.make_weight(out_planes, in_planes, *self.kernel_size))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
 
-    def forward(self, x, addend=None, bn_stats=False, tap=False, bn_src=None):
+    def forward(self, x, addend=None, bn_stats=False, tap=False, bn_src=None, res=None):
         """``bn_stats=True``: also return the BatchNorm partial sums of the output (for the BN that follows);
-        ``tap=True``: also return an alias of ``x`` for a second consumer; ``bn_src``: see ``ops.conv_cl``."""
+        ``tap=True``: also return an alias of ``x`` for a second consumer; ``bn_src`` / ``res``: see ``ops.conv_cl``."""
         return ops.conv_cl(x, self.weight, self.stride3, self.padding3, addend=addend,
-                           channel_first=self.channel_first, bn_stats=bn_stats, tap=tap, bn_src=bn_src)
+                           channel_first=self.channel_first, bn_stats=bn_stats, tap=tap, bn_src=bn_src, res=res)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
@@ -89,7 +89,10 @@ class no_bn_handover:
         _HANDOVER[0] = self.prev
 
 
-def _conv_bn(conv, bn, x, addend=None, tap=False, sole=True):
+_FUSE_RES = os.environ.get("AVID_FUSE_RES", "1") == "1"
+
+
+def _conv_bn(conv, bn, x, addend=None, tap=False, sole=True, res=None):
     """ReLU(bn(conv(x) [+ addend])).  In training the conv epilogue hands the BatchNorm its batch statistics
     as partial sums, so the BN does not re-read the activation for them.  ``tap``: also return an alias of x
     whose gradient is folded into this conv's input-gradient kernel (the residual branch).
@@ -98,15 +101,15 @@ def _conv_bn(conv, bn, x, addend=None, tap=False, sole=True):
     train = bn.training and x.is_cuda
     fuse = train and _FUSE_BN_STATS
     src_in = getattr(x, "_avid_bn_src", None) if (sole and train and torch.is_grad_enabled()) else None
-    out = conv(x, addend=addend, bn_stats=fuse, tap=tap, bn_src=src_in)
+    out = conv(x, addend=addend, bn_stats=fuse, tap=tap, bn_src=src_in, res=res)
     src_out = ops.BnSource(None, None, True) if (train and torch.is_grad_enabled() and _HANDOVER[0]) else None
-    if not (fuse or tap):
+    if not (fuse or tap or res is not None):
         h = bn(out, relu=True, src=src_out)
     else:
         h = bn(out[0], relu=True, partials=out[1] if fuse else None, src=src_out)
     if src_out is not None:
         h._avid_bn_src = src_out          # read by the next _conv_bn that takes h as its input
-    return (h, out[-1]) if tap else h
+    return (h, out[-1]) if (tap or res is not None) else h
 
 
 class Basic2DBlock(nn.Module):
@@ -154,8 +157,22 @@ class BasicR2P1DBlock(nn.Module):
         else:
             self.res = False
 
+    def _res_fusable(self, x):
+        """The residual convolution can ride inside spt_conv1's op (its input gradient stays on the sub-sampled grid
+        and is added in spt_conv1's strided dgrad): strides of 1 / 2, spt_conv1 itself strided, 32-bit offsets."""
+        if not self.res:
+            return False
+        rs, ss = self.res_conv.stride3, self.spt_conv1.stride3
+        return (_FUSE_RES and any(v == 2 for v in rs) and all(v in (1, 2) for v in rs)
+                and any(v == 2 for v in ss) and all(v in (1, 2) for v in ss) and x.numel() * 4 < (1 << 31))
+
     def forward(self, x):
         tap = x.is_cuda and x.requires_grad and torch.is_grad_enabled()
+        if tap and self._res_fusable(x):
+            h, x_res = _conv_bn(self.spt_conv1, self.spt_bn1, x, res=(self.res_conv.weight, self.res_conv.stride3))
+            h = _conv_bn(self.tmp_conv1, self.tmp_bn1, h)
+            h = _conv_bn(self.spt_conv2, self.spt_bn2, h)
+            return _conv_bn(self.tmp_conv2, self.out_bn, h, addend=x_res)
         if tap:     # the residual branch reads an alias of x: its gradient is added inside spt_conv1's dgrad
             h, x = _conv_bn(self.spt_conv1, self.spt_bn1, x, tap=True)
         else:       # (x also feeds the residual branch directly: spt_conv1 is not its only consumer)

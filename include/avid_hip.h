@@ -96,9 +96,14 @@ typedef struct {
   float* partials;
 } avid_bn_bwd_fuse;
 int avid_conv_dgrad_bn_rows(const avid_conv_desc* d);
+/* addend_stride (nullable = {1,1,1}): strides (1 or 2 per axis) of a COMPACT addend — the gradient of the
+ * sub-sampled view x[:, ::st, ::sh, ::sw] that a block's 1x1x1 strided residual convolution reads
+ * (models/network_blocks.py:47-51,58), shape [B][ceil(Ti/st)][ceil(Hi/sh)][ceil(Wi/sw)][Cin]: it is added at the
+ * positions divisible by the strides only, instead of being scattered into a dx-shaped tensor of mostly zeros
+ * first.  Strided layers on the persistent kernel only. */
 int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* wt,
-                    const float* addend, float* dx, const avid_bn_bwd_fuse* bn, void* ws, size_t ws_bytes,
-                    avid_stream_t stream);
+                    const float* addend, const int32_t* addend_stride, float* dx, const avid_bn_bwd_fuse* bn,
+                    void* ws, size_t ws_bytes, avid_stream_t stream);
 
 /* One launch that repacks every conv / linear weight of a model for its input-gradient pass:
  * w[Cout][taps][Cin] -> wt[Cin][taps][Cout] for each descriptor.  descs_dev: n descriptors in DEVICE

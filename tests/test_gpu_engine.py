@@ -221,3 +221,39 @@ def test_out_of_range_index_raises(gpu_device):
             torch.cuda.synchronize()
     crit(v, a, good)
     ops.check_device_errors(gpu_device)
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(64, 128, (2, 4, 10, 12)), (64, 128, (3, 5, 9, 11)), (128, 256, (4, 4, 14, 14)),
+                                            (256, 512, (8, 2, 7, 7))])
+def test_residual_conv_compact_gradient(cin, cout, shape, gpu_device):
+    """Stage-transition blocks (models/network_blocks.py:47-51,58): the 1x1x1 / (2,2,2) residual convolution is
+    computed inside spt_conv1's op; its input gradient stays on the sub-sampled grid (a dense 1x1x1 dgrad) and is
+    added inside spt_conv1's strided dgrad as a compact addend — directly written parity classes and K-split ones
+    (the reduce) alike, odd extents included.  Same forward bit for bit, same gradients to fp32 summation order as the
+    path that scatters it into an x-shaped tensor first (which test_blocks_vs_reference_golden pins to the reference)."""
+    import models.network_blocks as nb
+    blk = nb.BasicR2P1DBlock(cin, cout, stride=(2, 2, 2))
+    sd = blk.state_dict()
+    blk.load_state_dict({k: T(detgen.det_param(f"rc:{k}", tuple(v.shape)).copy()).to(v.dtype) for k, v in sd.items()})
+    blk = blk.to(gpu_device).train()
+    B, Tt, H, W = shape
+    x = T(detgen.det_normalish(f"rc:x:{shape}:{cin}", (B, Tt, H, W, cin))).to(gpu_device)
+
+    def run(fused):
+        saved, nb._FUSE_RES = nb._FUSE_RES, fused
+        try:
+            for p in blk.parameters():
+                p.grad = None
+            xx = x.clone().requires_grad_(True)
+            y = blk(xx)
+            g = T(detgen.det_uniform(f"rc:g:{shape}:{cout}", tuple(y.shape))).to(gpu_device)
+            y.backward(g)
+            return y.detach().clone(), [xx.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+        finally:
+            nb._FUSE_RES = saved
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    assert torch.equal(y1, y0)
+    for a, b in zip(g1, g0):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, float((a - b).abs().max() / b.abs().max())
