@@ -172,3 +172,39 @@ def test_trainstep_broadcasts_rank0_parameters_and_buffers():
     for p in reversed(list(ref.parameters())):
         assert torch.equal(got[off:off + p.numel()], p.detach().reshape(-1))
         off += (p.numel() + 3) // 4 * 4
+
+
+def _buffers_job(rank, world):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avid-cma_amd"))
+    from avid_hip.parallel import TrainStep
+    torch.manual_seed(7)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.Linear(16, 8), torch.nn.BatchNorm1d(8))
+    eng = TrainStep(m, criterion=None)
+    flat_ok = all(b.data_ptr() == eng.flat_buffers.flat.data_ptr() + 4 * o
+                  for b, o in zip(eng.flat_buffers.bufs, eng.flat_buffers.offsets))
+    m.train()
+    torch.manual_seed(100 + rank)                       # per-rank batches -> per-rank running statistics (no SyncBN)
+    for _ in range(3):
+        m(torch.randn(32, 8) * (1 + rank) + rank)
+    before = [m[1].running_mean.clone(), m[3].running_var.clone(), m[1].num_batches_tracked.clone()]
+    eng.sync_buffers()                                  # DDP's buffer broadcast, on request: ONE flat collective
+    after = [m[1].running_mean.clone(), m[3].running_var.clone(), m[1].num_batches_tracked.clone()]
+    sd_keys = sorted(k for k in m.state_dict() if "running" in k or "num_batches" in k)
+    return [t.numpy() for t in before], [t.numpy() for t in after], flat_ok, sd_keys, eng.flat_buffers.numel
+
+
+def test_sync_buffers_broadcasts_rank0_running_statistics_in_one_flat_buffer():
+    """utils/main_utils.py:112 (DistributedDataParallel, broadcast_buffers=True): rank 0's BatchNorm running statistics
+    are what every rank evaluates / checkpoints with.  TrainStep keeps them in ONE flat buffer (views; state_dict keys
+    unchanged) and broadcasts on request; ranks differ before (per-rank statistics) and equal rank 0 after."""
+    res = run2(_buffers_job)
+    b0, a0, ok0, keys0, n0 = res[0]
+    b1, a1, ok1, keys1, n1 = res[1]
+    assert ok0 and ok1 and n0 == n1 == 16 * 2 + 8 * 2
+    assert keys0 == ["1.num_batches_tracked", "1.running_mean", "1.running_var", "3.num_batches_tracked", "3.running_mean",
+                     "3.running_var"]
+    assert not (b0[0] == b1[0]).all() and not (b0[1] == b1[1]).all()      # per-rank statistics before
+    for k in range(2):
+        assert (a0[k] == b0[k]).all() and (a1[k] == b0[k]).all()          # rank 0's values everywhere after
+    assert int(a0[2]) == int(a1[2]) == 3                                  # the step counter advances identically anyway
