@@ -269,6 +269,13 @@ def main():
                          "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                          "launches_per_step": d["launches"] / kern_steps,
                          "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                         # every MFMA kernel of the step (the dominant one is whichever has the most time: the forward
+                         # `...,0>` and the input-gradient `...,1>` instantiations of the 128x64 tile are within 2 % of
+                         # each other, the latter also carries the fused BatchNorm-backward sums)
+                         "mfma_kernels": {k: {"ms_per_step": round(v["ms"] / kern_steps, 3),
+                                              "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                              "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                                          for k, v in sorted(mfma.items(), key=lambda kv: -kv[1]["ms"])},
                          "all_conv_kernels": {"ms_per_step": round(conv_ms, 3), "achieved": round(conv_tf, 2),
                                               "frac": round(conv_tf / PEAK_F32_MFMA_TFLOPS, 4)},
                          "step_algorithmic": {"gflop_per_clip": STEP_GFLOP_PER_CLIP,
