@@ -549,8 +549,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       ld_phi = __builtin_amdgcn_readfirstlane((int)(unsigned)(ptr >> 32));
       ld_nrec = __builtin_amdgcn_readfirstlane((int)a_bytes);
     }
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
+    // The 8 lanes that stage one row (lcol = 0..28) used to decode each of their PA rows themselves: ~65 VALU per
+    // row, PA times per tile, all on the wave's critical path between two tiles.  Lane j of such a group now decodes
+    // ONE row (i = j mod PA) and the group exchanges the results with PA lane permutes.
+    static_assert(PA <= 8, "one decoded row per lane of an 8-lane staging group");
+    unsigned dec_base, dec_mask;
+    {
+      const int i = (tid & 7) % PA;
       const unsigned m = m0 + lrow + RPP * i;
       const bool ok = m < (unsigned)cM;
       const unsigned mm = ok ? m : 0u;
@@ -573,8 +578,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
         mh = range_mask(h0 - p.Hs + 1, h0, ndh);
         mw = range_mask(w0 - p.Ws + 1, w0, ndw);
       }
-      a_mask[i] = ok ? (mt_ | (mh << 8) | (mw << 16)) : 0u;
-      a_base[i] = (unsigned)((((b - b_lo) * p.Ts + t0) * p.Hs + h0) * p.Ws + w0) * cs4 + lcol * 4;
+      dec_mask = ok ? (mt_ | (mh << 8) | (mw << 16)) : 0u;
+      dec_base = (unsigned)((((b - b_lo) * p.Ts + t0) * p.Hs + h0) * p.Ws + w0) * cs4;
+    }
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int src = (lane & ~7) | i;             // the lane of this row's group that decoded row i
+      a_mask[i] = (unsigned)__shfl((int)dec_mask, src, 64);
+      a_base[i] = (unsigned)__shfl((int)dec_base, src, 64) + lcol * 4;
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + RPP * i) * p.w_row + lcol) * 4;
