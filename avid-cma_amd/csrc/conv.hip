@@ -377,6 +377,15 @@ __device__ __forceinline__ unsigned magic_div(unsigned n, unsigned magic, int sh
 // put `s_waitcnt vmcnt(1)` in front of the first MFMA of EVERY k-tile (the tile loads were supposed to be
 // waited for one by one, behind the first six MFMAs): 2-7 % of every dense kernel.
 constexpr int EPI_ANY = 15;
+#ifdef AVID_PK_TRACE
+__device__ long long g_pk_trace[1024 * 64];
+extern "C" int avid_debug_pk_trace(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pk_trace), sizeof(long long) * 1024 * 64);
+}
+#define PK_STAMP(idx) do { if (threadIdx.x == 0 && (idx) < 32) { g_pk_trace[blockIdx.x * 64 + (idx)] = wall_clock64(); g_pk_trace[blockIdx.x * 64 + 32 + (idx)] = clock64(); } } while (0)
+#else
+#define PK_STAMP(idx) do {} while (0)
+#endif
 template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false, int EPI = EPI_ANY>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArgs p) {
   static_assert(!STRIDED || MODE == 1, "parity classes are a dgrad construct");
@@ -391,6 +400,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   const int wm = wave / WN, wn = wave % WN;
   const int lrow = tid >> 3, lcol = (tid & 7) * 4;
   const int h = lane >> 5, l31 = lane & 31;
+  PK_STAMP(0);
 
   const int ntn = p.Cd / BN;
   const int G = gridDim.x;
@@ -422,9 +432,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   int tslot = slot - p.pk_rot;
   tslot += tslot < 0 ? G : 0;
   const int nseg = n_full + (tslot < p.pk_tail_units ? 1 : 0);
-  float cs[TN], cq[TN];   // running column sum / sum of squares of this wave's outputs (p.stats)
+  // running column sum / sum of squares of this wave's outputs (p.stats); two lanes of accumulation per column
+  // (accumulator registers r even / odd) so that the sums pair up as packed fp32 ops on adjacent registers
+  float cs[TN][2], cq[TN][2];
 #pragma unroll
-  for (int jj = 0; jj < TN; ++jj) cs[jj] = cq[jj] = 0.f;
+  for (int jj = 0; jj < TN; ++jj) cs[jj][0] = cs[jj][1] = cq[jj][0] = cq[jj][1] = 0.f;
   // BatchNorm statistics fused into the epilogue: every workgroup owns one partial row [2][Cd] (its tiles
   // all share one column block — the planner keeps full, rot and the grid multiples of Cd/BN); columns it
   // does not cover, and the rows of workgroups without direct tiles, are written as zeros.
@@ -434,7 +446,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     __syncthreads();
 #pragma unroll
     for (int jj = 0; jj < TN; ++jj) {
-      const float a = cs[jj] + __shfl_xor(cs[jj], 32, 64), b = cq[jj] + __shfl_xor(cq[jj], 32, 64);
+      const float a0 = cs[jj][0] + cs[jj][1], b0 = cq[jj][0] + cq[jj][1];
+      const float a = a0 + __shfl_xor(a0, 32, 64), b = b0 + __shfl_xor(b0, 32, 64);
       if (h == 0) {
         red[wm * BN + (wn * TN + jj) * 32 + l31] = a;
         red[WM * BN + wm * BN + (wn * TN + jj) * 32 + l31] = b;
@@ -589,7 +602,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + RPP * i) * p.w_row + lcol) * 4;
-    retap();
   };
   auto issue_loads = [&]() {   // k-tile (loader tile; tap, channel block) -> registers: PA + PB loads
     // The descriptor words and scalar offsets were prepared when they last changed (setup_tile / advance); here
@@ -643,12 +655,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     set_tap();
     setup_tile(tile);
   };
+  // (one retap() site for the new-tile and the new-tap case: the row offsets are updated in place instead of being
+  // merged from three branches, which cost 8 register copies per k-tile)
   auto advance = [&]() {
     ld_ks = sgpr(ld_ks + 1);
     ld_c0 = sgpr(ld_c0 + BK);
+    bool moved = false;
     if (ld_ks == ld_kend) {          // next segment of this workgroup
       ld_seg = sgpr(ld_seg + 1);
-      if (ld_seg < nseg) setup_seg(ld_seg);
+      if (ld_seg < nseg) {
+        setup_seg(ld_seg);
+        moved = ld_seg < nseg;
+      }
     } else if (ld_c0 != p.Cs) {      // next channel block of the same tap
       ld_soff_a = sgpr(ld_soff_a + BK * 4);
       ld_soff_b = sgpr(ld_soff_b + BK * 4);
@@ -661,8 +679,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       ld_dh = sgpr(dh);
       ld_dt = sgpr(dt);
       set_tap();
-      retap();
+      moved = true;
     }
+    if (moved) retap();
   };
   auto store_stage = [&](float* st) {
 #pragma unroll
@@ -674,6 +693,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   // ---- prologue: k-tile 0 -> LDS stage 0, k-tile 1 -> registers
   setup_seg(0);
   if (!STRIDED || ld_seg < nseg) {  // (a strided workgroup may own nothing but empty classes)
+    retap();
     issue_loads();
     advance();
     store_stage(smem);
@@ -683,6 +703,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     }
   }
   __syncthreads();
+  PK_STAMP(1);
 
   const int a_frag = (wm * TM * 32 + l31) * LDK + h * 4;
   const int b_frag = (BM + wn * TN * 32 + l31) * LDK + h * 4;
@@ -769,6 +790,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     // body; only the last two k-tiles of the workgroup's whole stream take the drain variants.
     int nst = left - 2 < nkj ? left - 2 : nkj;
     if (nst < 0) nst = 0;
+    PK_STAMP(2 + 3 * j);
     for (int ks = 0; ks < nst; ++ks, u ^= 1) {
       ktile(std::true_type{}, std::true_type{});
       advance();
@@ -791,6 +813,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       }
     }
 
+    PK_STAMP(3 + 3 * j);
     // ---- epilogue of this segment: buffer stores bounded by num_records (rows past M are dropped by the
     // hardware), the row step in soffset; they drain under the next tile's MFMAs.  A K-split piece writes
     // its raw partial sums to the slab of its split; splitk_reduce_kernel applies the epilogue.
@@ -862,8 +885,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
               if (HAS_ADD) v += ad[r];
               if (BNB) {       // BatchNorm-backward partial sums of the gradient being written (see the dense epilogue)
                 const float dm = (!p.bnb_relu || fmaf(xb[r], bsc, bsh) > 0.f) ? v : 0.f;
-                cs[jj] += dm;
-                cq[jj] = fmaf(dm, (xb[r] - bmu) * bis, cq[jj]);
+                cs[jj][r & 1] += dm;
+                cq[jj][r & 1] = fmaf(dm, (xb[r] - bmu) * bis, cq[jj][r & 1]);
               }
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff[r], 0, 0);
             }
@@ -925,14 +948,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
             const int soff = ((r & 3) + 8 * (r >> 2)) * row_bytes;
             float v = acc[i][jj][r];
             if (DIRECT) {
-              v += bv;
+              if (decltype(BIAS)::value != 0) v += bv;   // (x + 0.f is not a no-op the compiler may drop: -0.f)
               if (HAS_ADD) v = decltype(OP)::value == 0 ? v + ad[r] : (decltype(OP)::value == 1 ? fminf(v, ad[r]) : fmaxf(v, ad[r]));
               if (RELU) v = fmaxf(v, 0.f);
-              if (MODE == 0) { cs[jj] += v; cq[jj] = fmaf(v, v, cq[jj]); }   // rows past M are exact zeros
+              if (MODE == 0) { cs[jj][r & 1] += v; cq[jj][r & 1] = fmaf(v, v, cq[jj][r & 1]); }   // rows past M are exact zeros
               if (BNB) {       // bn_bwd_partial_kernel's sums, from the gradient while it is in registers
                 const float dm = (!p.bnb_relu || fmaf(xb[r], bsc, bsh) > 0.f) ? v : 0.f;
-                cs[jj] += dm;
-                cq[jj] = fmaf(dm, (xb[r] - bmu) * bis, cq[jj]);
+                cs[jj][r & 1] += dm;
+                cq[jj][r & 1] = fmaf(dm, (xb[r] - bmu) * bis, cq[jj][r & 1]);
               }
             }
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff, soff, 0);
@@ -965,8 +988,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     } else {
       if (p.relu) emit(Y, N, Y, ADD, N, BQ); else emit(Y, N, N, ADD, N, BQ);
     }
+    PK_STAMP(4 + 3 * j);
   }
   write_stats();
+  PK_STAMP(31);
 }
 
 // dst = sum_s part[s] (+ bias)(+ addend)(relu) — fixed summation order

@@ -43,7 +43,11 @@ L = [
 print(f"{'layer':10s} {'M':>8s} {'K':>5s} {'N':>4s} | {'fwd us':>8s} {'TF':>6s} | {'dgrad us':>8s} {'TF':>6s} | {'wgrad us':>8s} {'TF':>6s}  kernels")
 for name, cin, cout, k, st, pd, (T, H, W) in L:
     if only and only not in name: continue
-    x = torch.randn(B, T, H, W, cin, device=dev).requires_grad_(True)
+    x = torch.randn(B, T, H, W, cin, device=dev)
+    # CB_DATA: operand values change the matrix pipe's power and with it the clock the chip holds
+    if os.environ.get("CB_DATA") == "zero": x.zero_()
+    elif os.environ.get("CB_DATA") == "relu": x.relu_()
+    x.requires_grad_(True)
     w = ops.make_weight(cout, cin, *k).normal_().to(dev).requires_grad_(True)
     y = ops.conv_cl(x, w, st, pd)
     g = torch.randn_like(y)
