@@ -247,10 +247,11 @@ def main():
         # FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note, + WRITE_SIZE), bytes per launch
         tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
         pmc = json.load(open(tf)) if os.path.exists(tf) else {}
-        if dom not in pmc:      # a renamed / new dominant kernel must not silently report a stale or missing figure
-            raise SystemExit(f"bench.py: profiles/pmc_traffic.json has no entry for the dominant kernel {dom!r}: "
-                             f"re-run tools/collect_profiles.sh on the GPU box and commit the regenerated file")
-        traffic = pmc[dom]
+        traffic = pmc.get(dom)
+        if traffic is None:     # a renamed / new dominant kernel must not report a stale figure: null + a loud note
+            print(f"bench.py: profiles/pmc_traffic.json has no entry for the dominant kernel {dom!r}: roofline.traffic "
+                  f"is null; re-run tools/collect_profiles.sh on the GPU box and commit the regenerated file",
+                  file=sys.stderr)
         conv_ms = sum(v["ms"] for v in mfma.values()) / kern_steps
         conv_tf = sum(v["flops"] for v in mfma.values()) / (sum(v["ms"] for v in mfma.values()) * 1e-3) / 1e12
         out = {
