@@ -23,6 +23,51 @@ _WS = {}
 _SIDE = {}
 OVERLAP_IN_CAPTURE = bool(int(__import__('os').environ.get('AVID_OVERLAP_IN_CAPTURE', '1')))
 OVERLAP_WGRAD = bool(int(__import__('os').environ.get('AVID_OVERLAP_WGRAD', '0')))     # run wgrad on a side stream concurrently with dgrad (fills each other's tail waves)
+# Weight gradients on a trailing stream (eager steps driven by parallel.TrainStep only): nothing in the backward
+# chain consumes dw, so wgrad(L) is issued on a helper stream that only waits for its dy and is joined once, before
+# the optimizer — it then runs next to the small kernels of the chain (BatchNorm finalize / apply, split-K reduces)
+# instead of in front of them.  Needs the gradient to land in the flat buffer (GradSlots): a dw handed back to
+# autograd would be accumulated on the main stream before the helper stream has written it.
+DEFER_WGRAD = int(__import__('os').environ.get('AVID_DEFER_WGRAD', '1'))
+_DEFER_ON = False          # set by parallel.TrainStep around loss.backward()
+_DEFERRED = {}             # compute stream handle -> its trailing wgrad stream
+_DEFER_USED = set()
+
+
+def wgrad_stream(device):
+    """The trailing weight-gradient stream of the current compute stream (one per compute stream: the two towers'
+    backward passes run on two streams)."""
+    cur = torch.cuda.current_stream(device)
+    key = (device.index, cur.cuda_stream)
+    st = _DEFERRED.get(key)
+    if st is None:
+        st = _DEFERRED[key] = torch.cuda.Stream(device=device)    # (a high-priority helper stream measured 1 % slower)
+    return cur, st
+
+
+def join_deferred_wgrads():
+    """The current stream waits for every trailing weight-gradient stream used since the last join."""
+    if _DEFER_USED:
+        cur = torch.cuda.current_stream()
+        for st in _DEFER_USED:
+            cur.wait_stream(st)
+        _DEFER_USED.clear()
+
+
+class deferred_wgrads:
+    """``with ops.deferred_wgrads(): loss.backward()`` — weight gradients may trail on helper streams inside; they
+    are joined on exit."""
+
+    def __enter__(self):
+        global _DEFER_ON
+        self.prev, _DEFER_ON = _DEFER_ON, bool(DEFER_WGRAD)
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER_ON
+        _DEFER_ON = self.prev
+        join_deferred_wgrads()
+        return False
 
 
 def side_stream(device, slot=0):
@@ -206,6 +251,11 @@ class GradSlots:
         self.views = grad_views
         self.on_ready = on_ready
         self.used = set()
+
+    def has_slot(self, param_ptr):
+        """True if the gradient of the parameter at ``param_ptr`` would be written into the flat buffer now."""
+        i = self.index.get(param_ptr)
+        return i is not None and i not in self.used
 
     def armed(self):
         return _ArmSlots(self)
@@ -427,7 +477,18 @@ class _ConvCL(Function):
             return g
 
         side = None
-        if need_dw and need_dx and OVERLAP_WGRAD and (OVERLAP_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()):
+        deferred = False
+        if (need_dw and _DEFER_ON and _SLOTS is not None and not torch.cuda.is_current_stream_capturing()
+                and _SLOTS.has_slot(w.data_ptr())):
+            main, trail = wgrad_stream(x.device)
+            trail.wait_stream(main)            # dy (after the ReLU mask) is complete
+            with torch.cuda.stream(trail):
+                dw = run_wgrad()
+            x.record_stream(trail)
+            dy.record_stream(trail)
+            _DEFER_USED.add(trail)
+            deferred = True
+        elif need_dw and need_dx and OVERLAP_WGRAD and (OVERLAP_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()):
             # dgrad (this stream) and wgrad (side stream) are independent: issue both, join afterwards
             main = torch.cuda.current_stream()
             side = side_stream(x.device, 0)
@@ -449,13 +510,22 @@ class _ConvCL(Function):
                 if any(v != 1 for v in ctx.res_stride):
                     add_stride = (C.c_int32 * 3)(*ctx.res_stride)
             if ctx.needs_input_grad[11]:
-                wsr = workspace(x.device, ctx.nb_wgrad_r)
-                g, slot = _grad_dst(res_w.data_ptr(), like=res_w)
-                lib.call("avid_conv_wgrad", C.byref(dr), _p(x), _p(d_res), _p(g), _p(wsr), wsr.numel(), st)
-                if slot is not None:
-                    _grad_done(slot)
+                def run_wgrad_res():
+                    wsr = workspace(x.device, ctx.nb_wgrad_r)
+                    g, slot = _grad_dst(res_w.data_ptr(), like=res_w)
+                    lib.call("avid_conv_wgrad", C.byref(dr), _p(x), _p(d_res), _p(g), _p(wsr), wsr.numel(), _stream())
+                    if slot is not None:
+                        _grad_done(slot)
+                        return None
+                    return g
+                if deferred and _SLOTS.has_slot(res_w.data_ptr()):
+                    main, trail = wgrad_stream(x.device)
+                    trail.wait_stream(main)
+                    with torch.cuda.stream(trail):
+                        dw_res = run_wgrad_res()
+                    d_res.record_stream(trail)
                 else:
-                    dw_res = g
+                    dw_res = run_wgrad_res()
         if need_dx:
             ws = workspace(x.device, ctx.nb_dgrad)
             dx = torch.empty_like(x)
@@ -477,7 +547,7 @@ class _ConvCL(Function):
                 if dw is not None:
                     dw.record_stream(torch.cuda.current_stream())
                 dy.record_stream(side)
-        elif need_dw:
+        elif need_dw and not deferred:
             dw = run_wgrad()
         if ctx.has_addend and ctx.needs_input_grad[2]:
             dadd = dy

@@ -252,8 +252,9 @@ class TrainStep:
         video_emb, audio_emb = self.model(video, audio)
         loss, _ = self.criterion(video_emb, audio_emb, index)
         if self.twt is not None:
+            from . import ops
             self.twt.refresh()                       # after the forward: whatever the weights are now
-            with self.twt.armed(), self.slots.armed():
+            with self.twt.armed(), self.slots.armed(), ops.deferred_wgrads():
                 loss.backward()
         else:
             loss.backward()

@@ -257,3 +257,26 @@ def test_residual_conv_compact_gradient(cin, cout, shape, gpu_device):
     assert torch.equal(y1, y0)
     for a, b in zip(g1, g0):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, float((a - b).abs().max() / b.abs().max())
+
+
+def test_trailing_wgrad_streams_change_nothing(gpu_device):
+    """The weight gradients run on helper streams that trail the backward chain and are joined before Adam
+    (ops.deferred_wgrads, on by default under TrainStep): same kernels, same order of summation — three steps with
+    and without give identical losses, parameters and Adam moments, with the two towers on two streams as well."""
+    from avid_hip import ops
+    video, audio, ids = _data(gpu_device)
+    res = {}
+    keep = ops.DEFER_WGRAD
+    try:
+        for on in (0, 1):
+            ops.DEFER_WGRAD = on
+            m, c, e = _make(gpu_device)
+            losses = [float(e.step(video, audio, ids[i])) for i in range(3)]
+            torch.cuda.synchronize()
+            assert bool(ops._DEFERRED) or not on           # the helper streams were really used
+            res[on] = (losses, e.flat.flat.clone(), e.m.clone(), e.v.clone())
+    finally:
+        ops.DEFER_WGRAD = keep
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)
