@@ -162,8 +162,13 @@ def device_info(device: int = 0):
     return {"cu_count": cu.value, "lds_bytes": lds.value, "arch": buf.value.decode()}
 
 
+TIMING = False     # HIP-event timers on: one event pair per launch — the callers keep the step on ONE stream then
+
+
 def timing_enable(on: bool):
+    global TIMING
     check(_lib.avid_timing_enable(1 if on else 0), "avid_timing_enable")
+    TIMING = bool(on)
 
 
 def timing_report():

@@ -28,6 +28,9 @@ OVERLAP_WGRAD = bool(int(__import__('os').environ.get('AVID_OVERLAP_WGRAD', '0')
 # the optimizer — it then runs next to the small kernels of the chain (BatchNorm finalize / apply, split-K reduces)
 # instead of in front of them.  Needs the gradient to land in the flat buffer (GradSlots): a dw handed back to
 # autograd would be accumulated on the main stream before the helper stream has written it.
+# Single-process steps only: with a process group in the loop (even a one-rank RCCL group) the two extra streams
+# next to the collectives' own made the step slower (4320 -> 4220 clips/s; 2570 with GPU_MAX_HW_QUEUES=8), so
+# TrainStep keeps the weight gradients on the compute streams whenever gradients are all-reduced.
 DEFER_WGRAD = int(__import__('os').environ.get('AVID_DEFER_WGRAD', '1'))
 _DEFER_ON = False          # set by parallel.TrainStep around loss.backward()
 _DEFERRED = {}             # compute stream handle -> its trailing wgrad stream
@@ -58,9 +61,13 @@ class deferred_wgrads:
     """``with ops.deferred_wgrads(): loss.backward()`` — weight gradients may trail on helper streams inside; they
     are joined on exit."""
 
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
     def __enter__(self):
         global _DEFER_ON
-        self.prev, _DEFER_ON = _DEFER_ON, bool(DEFER_WGRAD)
+        # (timed launches stay on one stream)
+        self.prev, _DEFER_ON = _DEFER_ON, bool(DEFER_WGRAD) and self.enabled and not lib.TIMING
         return self
 
     def __exit__(self, *exc):
