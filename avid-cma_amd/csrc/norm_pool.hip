@@ -400,6 +400,172 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// Small layers (M*C <= 8 M elements, C % 16 == 0): the finalize folded into the apply launch.  Every block owns 16
+// channels x a slice of the rows and folds the partial rows of ITS 16 channels itself (<= ~512 rows x 128 B from
+// L2, the same fp64 fold in every block of a channel group, so all of them apply identical coefficients); the
+// blocks of slice 0 also publish the saved statistics / running statistics / parameter gradients.  One launch
+// (~6 us) instead of finalize (8-11 us, 4-32 blocks on an otherwise idle chip) + apply: conv4x / conv5x / audio
+// layers, 29 of the step's 42 BatchNorms, forward and backward.
+// ---------------------------------------------------------------------------------------------
+constexpr int FA_CH = 16;
+
+__device__ __forceinline__ void fold16(const float* __restrict__ part, int nblk, int C, int cg, double (*sh)[2][FA_CH],
+                                       double& s0, double& s1) {
+  const int tid = threadIdx.x, g = tid & 3, slice = tid >> 2;     // 4 float4 groups x 64 row slices
+  const int c0 = cg * FA_CH + g * 4;
+  const long long st = 2ll * C;
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = slice; k < nblk; k += 256) {                       // rows k, k+64, k+128, k+192 in flight
+    floatx4 x[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = k + u * 64;
+      const floatx4 z = {0.f, 0.f, 0.f, 0.f};
+      const float* q = part + (long long)(row < nblk ? row : k) * st + c0;
+      x[u] = row < nblk ? *reinterpret_cast<const floatx4*>(q) : z;
+      y[u] = row < nblk ? *reinterpret_cast<const floatx4*>(q + C) : z;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] += (double)x[u][j]; b[j] += (double)y[u][j]; }
+  }
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double sa = a[j], sb = b[j];
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) { sa += __shfl_xor(sa, m, 64); sb += __shfl_xor(sb, m, 64); }
+    if ((tid & 63) < 4) {
+      sh[wave][0][g * 4 + j] = sa;
+      sh[wave][1][g * 4 + j] = sb;
+    }
+  }
+  __syncthreads();
+  s0 = s1 = 0.0;
+  if (tid < FA_CH) {
+    s0 = (sh[0][0][tid] + sh[1][0][tid]) + (sh[2][0][tid] + sh[3][0][tid]);
+    s1 = (sh[0][1][tid] + sh[1][1][tid]) + (sh[2][1][tid] + sh[3][1][tid]);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_fin_apply_kernel(const float* __restrict__ part, int nblk, long long M, int C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float momentum, float eps, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd, float* __restrict__ scale,
+                                                           float* __restrict__ shift, long long* __restrict__ num_batches_tracked,
+                                                           const float* __restrict__ x, float* __restrict__ y, int relu) {
+  __shared__ double sh[4][2][FA_CH];
+  __shared__ float cf[2][FA_CH];
+  const int tid = threadIdx.x;
+  const int ncg = C / FA_CH, cg = blockIdx.x % ncg, slice = blockIdx.x / ncg, nsl = gridDim.x / ncg;
+  if (num_batches_tracked && blockIdx.x == 0 && tid == 0) *num_batches_tracked += 1;
+  double s, ss;
+  fold16(part, nblk, C, cg, sh, s, ss);
+  if (tid < FA_CH) {
+    const int c = cg * FA_CH + tid;
+    const double mean = s / (double)M;
+    double var = ss / (double)M - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    const float sf = beta[c] - (float)mean * sc;
+    cf[0][tid] = sc;
+    cf[1][tid] = sf;
+    if (slice == 0) {
+      save_mean[c] = (float)mean;
+      save_invstd[c] = invstd;
+      scale[c] = sc;
+      shift[c] = sf;
+      if (running_mean) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+      }
+    }
+  }
+  __syncthreads();
+  const int g = tid & 3, G = C >> 2;
+  const floatx4 sc = *reinterpret_cast<const floatx4*>(&cf[0][g * 4]);
+  const floatx4 sf = *reinterpret_cast<const floatx4*>(&cf[1][g * 4]);
+  const long long step = (long long)nsl * 64;
+  const long long col = cg * 4 + g;
+  auto one = [&](const floatx4& v) {
+    floatx4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = fmaf(v[j], sc[j], sf[j]);   // the same fma the backward kernels recompute for the ReLU mask
+      if (relu) o[j] = fmaxf(o[j], 0.f);
+    }
+    return o;
+  };
+  long long r = (long long)slice * 64 + (tid >> 2);
+  for (; r + 3 * step < M; r += 4 * step) {
+    floatx4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const floatx4*>(x)[(r + u * step) * G + col];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) reinterpret_cast<floatx4*>(y)[(r + u * step) * G + col] = one(v[u]);
+  }
+  for (; r < M; r += step) reinterpret_cast<floatx4*>(y)[r * G + col] = one(reinterpret_cast<const floatx4*>(x)[r * G + col]);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(const float* __restrict__ part, int nblk, long long M, int C,
+                                                               const float* __restrict__ x, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ dy,
+                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ dx, int relu,
+                                                               int frozen) {
+  __shared__ double sh[4][2][FA_CH];
+  __shared__ float cf[2][FA_CH];
+  const int tid = threadIdx.x;
+  const int ncg = C / FA_CH, cg = blockIdx.x % ncg, slice = blockIdx.x / ncg, nsl = gridDim.x / ncg;
+  double s, sx;
+  fold16(part, nblk, C, cg, sh, s, sx);
+  if (tid < FA_CH) {
+    const int c = cg * FA_CH + tid;
+    if (slice == 0) {
+      dbeta[c] = (float)s;
+      dgamma[c] = (float)sx;
+    }
+    cf[0][tid] = frozen ? 0.f : (float)(s / (double)M);
+    cf[1][tid] = frozen ? 0.f : (float)(sx / (double)M);
+  }
+  __syncthreads();
+  const int g = tid & 3, G = C >> 2;
+  const int cgi = cg * 4 + g;
+  const floatx4 a = *reinterpret_cast<const floatx4*>(&cf[0][g * 4]);
+  const floatx4 b = *reinterpret_cast<const floatx4*>(&cf[1][g * 4]);
+  const floatx4 mu = reinterpret_cast<const floatx4*>(mean)[cgi], is = reinterpret_cast<const floatx4*>(invstd)[cgi];
+  const floatx4 gis = reinterpret_cast<const floatx4*>(gamma)[cgi] * is;
+  floatx4 sc = {0.f, 0.f, 0.f, 0.f}, sf = {0.f, 0.f, 0.f, 0.f};
+  if (relu) { sc = reinterpret_cast<const floatx4*>(scale)[cgi]; sf = reinterpret_cast<const floatx4*>(shift)[cgi]; }
+  auto eval = [&](floatx4 d, const floatx4& xv) {
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = fmaf(xv[j], sc[j], sf[j]) > 0.f ? d[j] : 0.f;
+    }
+    const floatx4 xh = (xv - mu) * is;
+    return gis * (d - a - xh * b);
+  };
+  const long long step = (long long)nsl * 64;
+  long long r = (long long)slice * 64 + (tid >> 2);
+  for (; r + step < M; r += 2 * step) {
+    const long long i0 = r * G + cgi, i1 = (r + step) * G + cgi;
+    const floatx4 d0 = reinterpret_cast<const floatx4*>(dy)[i0], d1 = reinterpret_cast<const floatx4*>(dy)[i1];
+    const floatx4 x0 = reinterpret_cast<const floatx4*>(x)[i0], x1 = reinterpret_cast<const floatx4*>(x)[i1];
+    reinterpret_cast<floatx4*>(dx)[i0] = eval(d0, x0);
+    reinterpret_cast<floatx4*>(dx)[i1] = eval(d1, x1);
+  }
+  if (r < M) {
+    const long long i0 = r * G + cgi;
+    reinterpret_cast<floatx4*>(dx)[i0] = eval(reinterpret_cast<const floatx4*>(dy)[i0], reinterpret_cast<const floatx4*>(x)[i0]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // MaxPool (1,3,3) stride (1,2,2) pad (0,1,1), channels-last.  argmax = window slot (dh*3+dw) of the
 // FIRST maximum in scan order (ATen CPU: `val > max || isnan(val)`).
 // ---------------------------------------------------------------------------------------------
@@ -729,6 +895,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   if (wave == 0 && c < C) out[c] = sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane];
 }
 
+// the fused finalize + apply path of small layers: element bound (env AVID_BN_FUSED_MAX, 0 = off) and grid
+static bool bn_fused_ok(int64_t M, int C) {
+  static long long cap = -1;
+  if (cap < 0) {
+    const char* e = getenv("AVID_BN_FUSED_MAX");
+    cap = e ? atoll(e) : (1ll << 23);   // conv3x-sized layers (6.4 M elements) still gain a launch; conv2x-sized ones lose
+  }
+  return C % FA_CH == 0 && (long long)M * C <= cap;
+}
+static unsigned bn_fused_grid(int64_t M, int C) {
+  const int ncg = C / FA_CH;
+  static int cap = 0;
+  if (!cap) {
+    const char* e = getenv("AVID_BN_FUSED_BLOCKS");
+    cap = e ? atoi(e) : 256;      // more blocks repeat the fold more often: 512 / 1024 / 2048 measured slower
+  }
+  // each block folds its 16 channels' partial rows itself (a fixed ~3 us): at least 4 x 64 rows of apply work per
+  // block, at most `cap` blocks
+  const long long chunks = (M + 63) / 64;
+  long long nsl = (chunks + 3) / 4;
+  if (nsl > cap / ncg) nsl = cap / ncg;
+  if (nsl < 1) nsl = 1;
+  return (unsigned)(ncg * nsl);
+}
+
 static unsigned ew_grid(long long n) {
   static int cap = 0;
   if (!cap) {
@@ -782,6 +973,13 @@ extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* 
     ScopedTimer t(s, "bn_stats_partial_kernel", 0.0, 4.0 * M * C);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
                        p.rows_per_pass, p.rows_per_block);
+  }
+  if (bn_fused_ok(M, C)) {
+    ScopedTimer t(s, "bn_fin_apply_kernel", 0.0, 8.0 * M * C);
+    hipLaunchKernelGGL(bn_fin_apply_kernel, dim3(bn_fused_grid(M, C)), dim3(256), 0, s, part, nblk, (long long)M, C, gamma,
+                       beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift,
+                       reinterpret_cast<long long*>(num_batches_tracked), x, y, relu);
+    return check_launch("bn_fwd_train");
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, nblk, (long long)M,
                      C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift,
@@ -840,6 +1038,12 @@ extern "C" int avid_bn_bwd(int64_t M, int C, const float* x, const float* dy, co
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, save_scale, save_shift, dy, save_mean,
                        save_invstd, wsf,
                        (long long)M, C, p.G, p.rows_per_pass, p.rows_per_block, relu);
+  }
+  if (bn_fused_ok(M, C)) {
+    ScopedTimer t(s, "bn_bwd_fin_apply_kernel", 0.0, 4.0 * M * C * 3);
+    hipLaunchKernelGGL(bn_bwd_fin_apply_kernel, dim3(bn_fused_grid(M, C)), dim3(256), 0, s, part, nblk, (long long)M, C, x,
+                       save_scale, save_shift, dy, gamma, save_mean, save_invstd, dgamma, dbeta, dx, relu, frozen);
+    return check_launch("bn_bwd");
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)ceil_div(C, FIN_CH)), dim3(1024), 0, s, part, nblk,
                      (long long)M, C, dgamma, dbeta, k1, k2, frozen);

@@ -319,7 +319,7 @@ def test_maxpool_hw3s2(gpu_device):
 
 @pytest.mark.parametrize("shape", [(2, 3, 10, 12, 64), (1, 2, 7, 9, 64), (3, 2, 56, 56, 64)])
 def test_bn_relu_maxpool_fused(shape, gpu_device):
-    """The fused stem tail against the three separate ops (already checked against torch): identical pooled
+    """The fused stem tail against the three separate ops (already checked against torch): the same pooled
     output, argmax behaviour and running statistics; gradients within 1e-5 (different partial-sum order)."""
     from avid_hip import ops
     B, T_, H, W, C = shape
@@ -339,7 +339,10 @@ def test_bn_relu_maxpool_fused(shape, gpu_device):
         (y * gy).sum().backward()
         outs.append((y.detach(), rm, rv, int(cnt), xx.grad, gg.grad, bb.grad))
     (y0, rm0, rv0, c0, dx0, dg0, db0), (y1, rm1, rv1, c1, dx1, dg1, db1) = outs
-    assert torch.equal(y0, y1) and torch.equal(rm0, rm1) and torch.equal(rv0, rv1) and c0 == c1 == 1
+    # (small layers fold their partial sums inside the apply launch, in another order than bn_finalize_kernel: the
+    # statistics agree to the last bit or two, the pooled output — a max over 9 activations — is compared exactly
+    # only where the two normalisations round alike)
+    assert relerr(y1, y0) < 1e-6 and relerr(rm1, rm0) < 1e-6 and relerr(rv1, rv0) < 1e-6 and c0 == c1 == 1
     assert relerr(dx1, dx0) < 1e-5 and relerr(dg1, dg0) < 1e-5 and relerr(db1, db0) < 1e-5
 
 
