@@ -256,7 +256,7 @@ class TrainStep:
             self.sync_buffers()
         from . import ops
         helper = None
-        if self.twt is not None and self.flat.grad.is_cuda and ops.DEFER_WGRAD and not self.buckets.comm and not lib_timing():
+        if self.twt is not None and self.flat.grad.is_cuda and ops.DEFER_WGRAD and self._defer_ok() and not lib_timing():
             # what the backward needs but the forward does not — zeroed gradients, the transposed weight copies —
             # runs on a helper stream next to the forward instead of in front of / behind it (the weights cannot
             # change in between: this method owns the step)
@@ -276,12 +276,17 @@ class TrainStep:
                 torch.cuda.current_stream().wait_stream(helper)
             else:
                 self.twt.refresh()                   # after the forward: whatever the weights are now
-            with self.twt.armed(), self.slots.armed(), ops.deferred_wgrads(enabled=not self.buckets.comm):
+            with self.twt.armed(), self.slots.armed(), ops.deferred_wgrads(enabled=self._defer_ok()):
                 loss.backward()
         else:
             loss.backward()
         self.buckets.finish()
         return loss
+
+    def _defer_ok(self):
+        """Trailing weight-gradient streams: single-process steps only; AVID_DEFER_DIST=1 forces
+        them on with a process group for experiments."""
+        return (not self.buckets.comm) or os.environ.get("AVID_DEFER_DIST", "0") == "1"
 
     def optimizer_step(self):
         from . import ops
