@@ -253,7 +253,10 @@ def test_linear_bias_relu(gpu_device):
         assert relerr(bd.grad, br.grad) < 2e-5
 
 
-@pytest.mark.parametrize("M,C", [(1, 64), (2 * 8 * 28 * 28, 64), (777, 128), (3 * 49 * 2, 256), (40, 512), (100003, 64)])
+# (up to 8 M elements the finalize runs inside the apply launch, bn_fin_apply / bn_bwd_fin_apply; 140000 x 64 takes the
+# separate finalize + apply kernels of the large layers)
+@pytest.mark.parametrize("M,C", [(1, 64), (2 * 8 * 28 * 28, 64), (777, 128), (3 * 49 * 2, 256), (40, 512), (100003, 64),
+                                 (140000, 64)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_batchnorm_train(M, C, relu, gpu_device):
     """Train-mode BN(+ReLU) fwd/bwd + running-stat update vs float64 F.batch_norm.  Tol 1e-5 rel."""
