@@ -68,9 +68,18 @@ class R2Plus1D(nn.Module):
                                        bn.momentum, bn.eps, bn.num_batches_tracked, partials=part)
         else:
             x_c1 = self.conv1[3](bn(conv(x.contiguous()), relu=True))
+        hook = getattr(self, "_stage_hook", None)     # (stage index, issued so far) -> AV_Wrapper starts the audio tower
+        if hook is not None:
+            hook(1)
         x_b1 = self.conv2x(x_c1)
+        if hook is not None:
+            hook(2)
         x_b2 = self.conv3x(x_b1)
+        if hook is not None:
+            hook(3)
         x_b3 = self.conv4x(x_b2)
+        if hook is not None:
+            hook(4)
         x_b4 = self.conv5x(x_b3)
         pooled = ops.global_maxpool(x_b4)
         x_pool = pooled.view(pooled.shape[0], pooled.shape[1], 1, 1, 1)
