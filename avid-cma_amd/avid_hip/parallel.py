@@ -95,6 +95,10 @@ class FlatBuffers:
         return dist.broadcast(self.flat, src, async_op=async_op)
 
 
+def _late_buckets():
+    return os.environ.get("AVID_DEFER_DIST", "0") == "1"
+
+
 def lib_timing():
     from . import lib
     return lib.TIMING
@@ -139,7 +143,12 @@ class GradBuckets:
         if self.flat.grad.is_cuda:
             self.producers[b].add(torch.cuda.current_stream(self.flat.grad.device))
         self.pending[b] -= 1
-        if self.pending[b] == 0:
+        # (with the weight gradients on trailing streams — AVID_DEFER_DIST=1 — a bucket's collective would make RCCL's
+        # stream wait for a trailing stream in the middle of the backward; whatever shares its hardware queue then
+        # stalls behind that wait: 4320 / 2840 clips/s with 4 / 8 queues on the one-rank group.  Those runs launch
+        # every bucket from finish(): 4470 / 4860, at the price of an all-reduce that no longer hides under the
+        # backward)
+        if self.pending[b] == 0 and not _late_buckets():
             self._launch(b)
 
     def _make_hook(self, i):
