@@ -948,8 +948,56 @@ class _NCELoss(Function):
         return dpos, dneg, None
 
 
+class _NCELossJoint(Function):
+    """NCE over one score tensor ``s [bs, P + K]`` whose first P columns are the positives (bank_scores' layout).
+    Same kernels as _NCELoss; the gradient goes back as ONE tensor — through ``s[:, :P]`` / ``s[:, P:]`` autograd
+    builds it from two zero-filled tensors, two slice copies and an add (5 small kernels per NCE term on the
+    chain between forward and backward)."""
+
+    @staticmethod
+    def forward(ctx, s, P, Z):
+        _need_cuda(s, Z)
+        if s.stride(1) != 1:
+            s = s.contiguous()
+        bs, K = s.shape[0], s.shape[1] - P
+        spos, sneg = s[:, :P], s[:, P:]
+        loss = torch.empty((), dtype=torch.float32, device=s.device)
+        ws = _nce_ws(s.device)
+        lib.call("avid_nce_fwd", bs, P, K, _p(spos), spos.stride(0), _p(sneg), sneg.stride(0), _p(Z), 1.0, 0,
+                 _p(loss), _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(s, Z)
+        ctx.P = P
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        s, Z = ctx.saved_tensors
+        P = ctx.P
+        bs, K = s.shape[0], s.shape[1] - P
+        spos, sneg = s[:, :P], s[:, P:]
+        dpos = torch.empty((bs, P), dtype=torch.float32, device=s.device)
+        dneg = torch.empty((bs, K), dtype=torch.float32, device=s.device)
+        lib.call("avid_nce_bwd", bs, P, K, _p(spos), spos.stride(0), _p(sneg), sneg.stride(0), _p(Z),
+                 _p(dloss.contiguous()), 1.0, _p(dpos), _p(dneg), _stream())
+        return torch.cat([dpos, dneg], 1), None, None
+
+
 def nce_loss(spos, sneg, Z):
+    # the two views of one bank_scores result (criterions/avid.py tags them): differentiate the joint tensor
+    joint = getattr(spos, "_avid_joint", None)
+    if (joint is not None and getattr(sneg, "_avid_joint", None) is joint and joint.is_cuda
+            and spos.shape[1] + sneg.shape[1] == joint.shape[1] and spos.data_ptr() == joint.data_ptr()):
+        return _NCELossJoint.apply(joint, spos.shape[1], Z)
     return _NCELoss.apply(spos, sneg, Z)
+
+
+def split_scores(s, P):
+    """``[s[:, :P], s[:, P:]]`` (the reference's [positives, negatives] pair, criterions/avid.py:70-75) tagged with
+    the tensor they are views of, so that ``nce_loss`` can take the joint path."""
+    pos, neg = s[:, :P], s[:, P:]
+    pos._avid_joint = s
+    neg._avid_joint = s
+    return [pos, neg]
 
 
 def alias_draw(n, K, prob, alias, uniform, seed, offset, y=None, per_row=1, device=None, offset_dev=None):

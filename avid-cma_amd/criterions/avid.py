@@ -70,14 +70,14 @@ class AVIDSimilarityMemoryBank(nn.Module):
         scores = {}
         if self.xModal:
             s = ops.bank_scores(video_emb, self.view2_mem, rows, inv_T)
-            scores['v2a'] = [s[:, :1], s[:, 1:]]
+            scores['v2a'] = ops.split_scores(s, 1)
             s = ops.bank_scores(audio_emb, self.view1_mem, rows, inv_T)
-            scores['a2v'] = [s[:, :1], s[:, 1:]]
+            scores['a2v'] = ops.split_scores(s, 1)
         if self.wModal:
             s = ops.bank_scores(video_emb, self.view1_mem, rows, inv_T)
-            scores['v2v'] = [s[:, :1], s[:, 1:]]
+            scores['v2v'] = ops.split_scores(s, 1)
             s = ops.bank_scores(audio_emb, self.view2_mem, rows, inv_T)
-            scores['a2a'] = [s[:, :1], s[:, 1:]]
+            scores['a2a'] = ops.split_scores(s, 1)
 
         # Update memory bank (scores above used the pre-update rows; their snapshot is kept for backward)
         self.update_memory(video_emb.detach(), audio_emb.detach(), y)

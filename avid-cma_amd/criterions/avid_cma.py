@@ -104,8 +104,8 @@ class AVIDSimilarityPositiveExpansion(AVIDSimilarityMemoryBank):
             wrows = rows[:, 1:1 + P + Kw].contiguous()                  # [P positives | first Kw negatives]
             s_v2v = ops.bank_scores(video_emb, self.view1_mem, wrows, inv_T)
             s_a2a = ops.bank_scores(audio_emb, self.view2_mem, wrows, inv_T)
-            scores['pos-v2v'] = [s_v2v[:, :P], s_v2v[:, P:]]
-            scores['pos-a2a'] = [s_a2a[:, :P], s_a2a[:, P:]]
+            scores['pos-v2v'] = ops.split_scores(s_v2v, P)
+            scores['pos-a2a'] = ops.split_scores(s_a2a, P)
 
         self.update_memory(video_emb.detach(), audio_emb.detach(), y)
         ops.poll_device_errors(y.device)
