@@ -473,6 +473,28 @@ def test_nce_multi_block_path(gpu_device):
         np.testing.assert_allclose(snd.grad.cpu().numpy(), snr.grad.float().numpy(), rtol=2e-5, atol=1e-9)
 
 
+def test_nce_joint_score_tensor_path(gpu_device):
+    """ops.split_scores tags the [positives | negatives] views of one bank_scores result; nce_loss then differentiates
+    the joint tensor (one gradient tensor, no zero-fill / slice-copy / add kernels from autograd).  Loss and the
+    gradient of the joint tensor are bit-identical to the path through two plain views."""
+    from avid_hip import ops
+    for bs, Pn, K in ((64, 1, 1024), (16, 32, 64)):
+        gen = torch.Generator().manual_seed(7 * bs + Pn)
+        base = (torch.rand(bs, Pn + K, generator=gen) * 12 - 6).to(gpu_device)
+        Z = torch.tensor(0.41, device=gpu_device)
+        s1 = base.clone().requires_grad_(True)
+        l1 = ops.nce_loss(s1[:, :Pn], s1[:, Pn:], Z)                 # plain views: the separate-tensor path
+        (l1 * 0.5).backward()
+        s2 = base.clone().requires_grad_(True)
+        t = s2 * 1.0                                                # a non-leaf, like a bank_scores result
+        pos, neg = ops.split_scores(t, Pn)
+        assert pos._avid_joint is t and neg._avid_joint is t
+        l2 = ops.nce_loss(pos, neg, Z)
+        assert type(l2.grad_fn).__name__.startswith("_NCELossJoint")
+        (l2 * 0.5).backward()
+        assert torch.equal(l1, l2) and torch.equal(s1.grad, s2.grad)
+
+
 def test_bank_update(gpu_device):
     from avid_hip import ops
     N, B = 3000, 40
