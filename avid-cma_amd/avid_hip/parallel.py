@@ -96,7 +96,7 @@ class FlatBuffers:
 
 
 def _late_buckets():
-    return os.environ.get("AVID_DEFER_DIST", "0") == "1"
+    return os.environ.get("AVID_DEFER_DIST", "0") == "1" and os.environ.get("AVID_EARLY_BUCKETS", "0") != "1"
 
 
 def lib_timing():
