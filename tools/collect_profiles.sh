@@ -3,7 +3,7 @@
 # and the per-kernel HBM traffic table.  Only the summaries are kept (the traces are hundreds of MB):
 #   gpurun_out/prof/{bench.json, breakdown.txt, kernel_stats.csv, pmc_summary.csv, pmc_traffic.json}
 # Copy them to profiles/<round>_* and pmc_traffic.json to profiles/pmc_traffic.json (bench.py reads that one and
-# refuses to run if its dominant kernel is missing from it).
+# reports roofline.traffic = null, with a note on stderr, if its dominant kernel is missing from it).
 set -u
 cd /root/repo
 rm -rf gpurun_out/prof
