@@ -32,6 +32,9 @@ OVERLAP_WGRAD = bool(int(__import__('os').environ.get('AVID_OVERLAP_WGRAD', '0')
 # next to the collectives' own made the step slower (4320 -> 4220 clips/s; 2570 with GPU_MAX_HW_QUEUES=8), so
 # TrainStep keeps the weight gradients on the compute streams whenever gradients are all-reduced.
 DEFER_WGRAD = int(__import__('os').environ.get('AVID_DEFER_WGRAD', '1'))
+# (inside a hipGraph capture the trailing streams become graph branches; the replay schedules them worse than the
+# eager streams: 4518 -> 4309 clips/s with --graph 1, so a capture keeps the weight gradients on the compute streams)
+DEFER_IN_CAPTURE = bool(int(__import__('os').environ.get('AVID_DEFER_IN_CAPTURE', '0')))
 _DEFER_ON = False          # set by parallel.TrainStep around loss.backward()
 _DEFERRED = {}             # compute stream handle -> its trailing wgrad stream
 _DEFER_USED = set()
@@ -485,14 +488,16 @@ class _ConvCL(Function):
 
         side = None
         deferred = False
-        if (need_dw and _DEFER_ON and _SLOTS is not None and not torch.cuda.is_current_stream_capturing()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if (need_dw and _DEFER_ON and _SLOTS is not None and (DEFER_IN_CAPTURE or not capturing)
                 and _SLOTS.has_slot(w.data_ptr())):
             main, trail = wgrad_stream(x.device)
             trail.wait_stream(main)            # dy (after the ReLU mask) is complete
             with torch.cuda.stream(trail):
                 dw = run_wgrad()
-            x.record_stream(trail)
-            dy.record_stream(trail)
+            if not capturing:                  # (a capture's private pool frees nothing before the graph is done)
+                x.record_stream(trail)
+                dy.record_stream(trail)
             _DEFER_USED.add(trail)
             deferred = True
         elif need_dw and need_dx and OVERLAP_WGRAD and (OVERLAP_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()):
@@ -530,7 +535,8 @@ class _ConvCL(Function):
                     trail.wait_stream(main)
                     with torch.cuda.stream(trail):
                         dw_res = run_wgrad_res()
-                    d_res.record_stream(trail)
+                    if not capturing:
+                        d_res.record_stream(trail)
                 else:
                     dw_res = run_wgrad_res()
         if need_dx:
