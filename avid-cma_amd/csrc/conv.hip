@@ -1921,7 +1921,17 @@ static int pk_alt() {
   }
   return alt;
 }
-static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_out) {
+static double pk_red_scale(int mode) {   // tuning knob: weight of the slab pass in the planner's cost, per direction
+  static double sc[2] = {-1.0, -1.0};
+  if (sc[0] < 0) {
+    const char* e0 = getenv("AVID_PK_RED_FWD");
+    const char* e1 = getenv("AVID_PK_RED_DGRAD");
+    sc[0] = e0 ? atof(e0) : 1.0;
+    sc[1] = e1 ? atof(e1) : 1.0;
+  }
+  return sc[mode ? 1 : 0];
+}
+static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_out, int mode) {
   PkPlan k{};
   const int cus = device_cus();
   int per_cu = 2;
@@ -1941,7 +1951,7 @@ static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_o
   // every CU gets the same number; the remaining tail tiles are cut into f K-ranges ("units", at most one
   // per workgroup, handed out starting with the workgroups that got one full tile less).  Cost model in
   // k-tiles per CU: a started tile or unit pays ~2 k-tiles of prologue/epilogue, a split adds the slab pass.
-  const double ovh = 2.0, red = 4.0 * 128 / k.BN;
+  const double ovh = 2.0, red = 4.0 * 128 / k.BN * pk_red_scale(mode);
   double best = 1e300;
   const int fmax = nk / 3 < 64 ? (nk / 3 < 1 ? 1 : nk / 3) : 64;
   for (long long m = T / C; m >= 0 && m >= T / C - 1; --m) {
@@ -1976,15 +1986,15 @@ static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_o
 // Tile shape: 128x64 when Cd is not a multiple of 128; otherwise whichever of 128x128 / 128x64 the cost model
 // rates cheaper — the narrow tile quantises M x Cd better (twice the tiles to deal) but reads the activation
 // rows twice and runs a few % below the square tile per flop, so it only wins where whole rounds are lost.
-static PkPlan plan_pk(long long M, int Cd, int nk) {
+static PkPlan plan_pk(long long M, int Cd, int nk, int mode) {
   double c0, c1;
   const int alt = pk_alt();
-  if (Cd % 128 != 0) return plan_pk_tile(M, Cd, nk, alt == 1 ? 3 : 1, &c0);
-  if (alt == 1) return plan_pk_tile(M, Cd, nk, 2, &c0);
-  if (alt == 2) return plan_pk_tile(M, Cd, nk, 1, &c0);
-  const PkPlan wide = plan_pk_tile(M, Cd, nk, 0, &c0);
+  if (Cd % 128 != 0) return plan_pk_tile(M, Cd, nk, alt == 1 ? 3 : 1, &c0, mode);
+  if (alt == 1) return plan_pk_tile(M, Cd, nk, 2, &c0, mode);
+  if (alt == 2) return plan_pk_tile(M, Cd, nk, 1, &c0, mode);
+  const PkPlan wide = plan_pk_tile(M, Cd, nk, 0, &c0, mode);
   if (alt == 3) return wide;
-  const PkPlan narrow = plan_pk_tile(M, Cd, nk, 1, &c1);
+  const PkPlan narrow = plan_pk_tile(M, Cd, nk, 1, &c1, mode);
   return c1 * 1.04 < c0 ? narrow : wide;
 }
 
@@ -2298,7 +2308,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
   const int nk_total = a.kt * a.kh * a.kw * (a.Cs / BK);
   // Everything dense goes to the persistent kernel (whole rounds + K-split tail in one launch).
   if (pk_enabled()) {
-    PkPlan pk = plan_pk(a.M, a.Cd, nk_total);
+    PkPlan pk = plan_pk(a.M, a.Cd, nk_total, MODE);
     if (pk.f > 1 && (ws == nullptr || ws_bytes < sizeof(float) * pk.ws_floats)) {   // no scratch: unsplit
       AVID_REQUIRE(!a.stats, AVID_E_BADARG, "conv: BatchNorm partials need the planned workspace");
       pk.tail_units /= pk.f;
@@ -2411,8 +2421,8 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
 }
 
 // scratch floats the non-strided igemm dispatch wants for an M x Cd problem (mirrors dispatch_igemm)
-static size_t igemm_ws_floats(long long M, int Cd, int nk) {
-  if (pk_enabled()) return plan_pk(M, Cd, nk).ws_floats;
+static size_t igemm_ws_floats(long long M, int Cd, int nk, int mode) {
+  if (pk_enabled()) return plan_pk(M, Cd, nk, mode).ws_floats;
   const long long Mr = M;
   const IgemmPlan pl = plan_igemm(Mr, Cd, nk, true);
   if (pl.nsplit > 1) return (size_t)pl.nsplit * Mr * Cd;
@@ -2535,7 +2545,7 @@ extern "C" size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d) {
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
   const Trim tr = trim_taps(d);
   const int nk = tr.d.kt * d->kh * d->kw * (d->Cin / BK);
-  return sizeof(float) * igemm_ws_floats(M, d->Cout, nk);
+  return sizeof(float) * igemm_ws_floats(M, d->Cout, nk, 0);
 }
 
 extern "C" int avid_conv_fwd_stats_rows(const avid_conv_desc* d) {
@@ -2544,7 +2554,7 @@ extern "C" int avid_conv_fwd_stats_rows(const avid_conv_desc* d) {
   if (!vec) return stem_fwd_supported(d) ? stem_fwd_grid(d) : 0;     // LDS-patch stems: one row per workgroup
   if (!pk_enabled() || d->Cout > 1024 || (256 % (d->Cout / 4)) != 0) return 0;
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
-  const PkPlan pk = plan_pk(M, d->Cout, trim_taps(d).d.kt * d->kh * d->kw * (d->Cin / BK));
+  const PkPlan pk = plan_pk(M, d->Cout, trim_taps(d).d.kt * d->kh * d->kw * (d->Cin / BK), 0);
   return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cout)) : 0);
 }
 
@@ -2590,7 +2600,7 @@ extern "C" size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
   const int nk = trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK);
-  size_t fl = igemm_ws_floats(M, d->Cin, nk);
+  size_t fl = igemm_ws_floats(M, d->Cin, nk, 1);
   if (d->st > 1 || d->sh > 1 || d->sw > 1) {   // strided: destination-shaped slabs of the K-split classes (<= 8 pieces)
     const size_t want = (size_t)8 * (size_t)M * d->Cin;
     if (want > fl) fl = want;
@@ -2628,7 +2638,7 @@ extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
     const StridedPlan pl = plan_strided(a, 128, BN, (size_t)8 * (size_t)M * d->Cin);
     return pl.grid + (pl.any_split ? (int)ceil_div(M, stats_rpb(M, d->Cin)) : 0);
   }
-  const PkPlan pk = plan_pk(M, d->Cin, trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK));
+  const PkPlan pk = plan_pk(M, d->Cin, trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK), 1);
   return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cin)) : 0);
 }
 
@@ -2843,7 +2853,7 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
   const Trim tr = trim_taps(d);
   const int ktl = tr.d.kt;           // live temporal taps
   auto pk_name = [&](long long M, int Cd, int nk, int mode) {
-    const PkPlan pk = plan_pk(M, Cd, nk);
+    const PkPlan pk = plan_pk(M, Cd, nk, mode);
     static const char* kPk[] = {"2,2,2,2", "4,1,1,2", "4,2,2,2", "4,2,2,1"};
     snprintf(buf, len, "igemm_pk_kernel<%s,%d> full=%d tail_units=%d f=%d", kPk[pk.tile], mode, pk.full, pk.tail_units, pk.f);
   };
