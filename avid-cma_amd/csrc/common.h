@@ -55,6 +55,13 @@ int stem_fwd(const avid_conv_desc* d, const float* x, const float* w, float* y, 
 int stem_fwd_grid(const avid_conv_desc* d);
 int stem_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, hipStream_t s);
 
+// wino.hip: Winograd F(2x2, 3x3) forward / input gradient of the (1,3,3) stride-1 layers (mode 0 / 1)
+bool wino_supported(const avid_conv_desc* d, int mode);
+size_t wino_ws_bytes(const avid_conv_desc* d, int mode);
+int wino_grid(const avid_conv_desc* d, int mode);
+int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* w, float* dst, const float* addend,
+              float* stats, const avid_bn_bwd_fuse* bn, void* ws, hipStream_t s);
+
 // 64-lane wave reductions (DPP/ds_swizzle chosen by the compiler from __shfl_xor).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

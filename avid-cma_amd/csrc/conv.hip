@@ -2545,13 +2545,16 @@ extern "C" size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d) {
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
   const Trim tr = trim_taps(d);
   const int nk = tr.d.kt * d->kh * d->kw * (d->Cin / BK);
-  return sizeof(float) * igemm_ws_floats(M, d->Cout, nk, 0);
+  size_t need = sizeof(float) * igemm_ws_floats(M, d->Cout, nk, 0);
+  if (wino_supported(d, 0) && wino_ws_bytes(d, 0) > need) need = wino_ws_bytes(d, 0);
+  return need;
 }
 
 extern "C" int avid_conv_fwd_stats_rows(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
   if (!vec) return stem_fwd_supported(d) ? stem_fwd_grid(d) : 0;     // LDS-patch stems: one row per workgroup
+  if (wino_supported(d, 0)) return wino_grid(d, 0);
   if (!pk_enabled() || d->Cout > 1024 || (256 % (d->Cout / 4)) != 0) return 0;
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
   const PkPlan pk = plan_pk(M, d->Cout, trim_taps(d).d.kt * d->kh * d->kw * (d->Cin / BK), 0);
@@ -2566,6 +2569,8 @@ extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const floa
   AVID_REQUIRE(x && w && y, AVID_E_BADARG, "conv_fwd: null pointer");
   if (stem_fwd_supported(d) && !addend && !bias && !relu && ws && ws_bytes >= stem_fwd_ws_bytes(d))
     return stem_fwd(d, x, w, y, bn_partials, ws, (hipStream_t)stream);
+  if (wino_supported(d, 0) && !bias && !relu && ws && ws_bytes >= wino_ws_bytes(d, 0))
+    return wino_conv(d, 0, x, w, y, addend, bn_partials, nullptr, ws, (hipStream_t)stream);
   const Trim tr = trim_taps(d);
   ConvArgs a;
   fill_common(a, &tr.d);
@@ -2605,7 +2610,9 @@ extern "C" size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d) {
     const size_t want = (size_t)8 * (size_t)M * d->Cin;
     if (want > fl) fl = want;
   }
-  return dgrad_wt_bytes(d) + sizeof(float) * fl;
+  size_t need = dgrad_wt_bytes(d) + sizeof(float) * fl;
+  if (wino_supported(d, 1) && wino_ws_bytes(d, 1) > need) need = wino_ws_bytes(d, 1);
+  return need;
 }
 
 extern "C" int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_dev, int64_t max_elems,
@@ -2624,6 +2631,7 @@ extern "C" int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_de
 extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   if (d->x_channel_first || d->Cin % 64 || d->Cout % 32 || d->st > 2 || d->sh > 2 || d->sw > 2) return 0;
+  if (wino_supported(d, 1)) return wino_grid(d, 1);
   if (!pk_enabled() || d->Cin > 1024 || (256 % (d->Cin / 4)) != 0) return 0;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
   if (d->st > 1 || d->sh > 1 || d->sw > 1) {   // strided: the plan of dispatch_igemm<1>'s parity-class branch
@@ -2672,6 +2680,8 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
   AVID_REQUIRE(d->st <= 2 && d->sh <= 2 && d->sw <= 2, AVID_E_UNSUPPORTED, "conv_dgrad: stride > 2");
   AVID_REQUIRE(ws_bytes >= dgrad_wt_bytes(d), AVID_E_BADARG, "conv_dgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
+  if (wino_supported(d, 1) && !sparse_add && ws_bytes >= wino_ws_bytes(d, 1))
+    return wino_conv(d, 1, dy, w, dx, addend, nullptr, bn, ws, s);
   const int ntaps = d->kt * d->kh * d->kw;
   const float* wt = wt_in;
   if (!wt) {
@@ -2864,6 +2874,8 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
         snprintf(buf, len, "stem_fwd_kernel<%d,%d>", d->Cin, d->kt);
       else
         snprintf(buf, len, "igemm_gather_kernel<%s>", ((M + 127) / 128) * (d->Cout / 64) >= 256 ? "4,1,1,2" : "2,2,1,1");
+    } else if (wino_supported(d, 0)) {
+      snprintf(buf, len, "wino_kernel<0> grid=%d", wino_grid(d, 0));
     } else if (pk_enabled()) {
       pk_name(M, d->Cout, ktl * d->kh * d->kw * (d->Cin / BK), 0);
     } else {
@@ -2873,7 +2885,9 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
   } else if (which == 1) {
     const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
     const bool strided = d->st > 1 || d->sh > 1 || d->sw > 1;
-    if (pk_enabled() && strided) {
+    if (wino_supported(d, 1)) {
+      snprintf(buf, len, "wino_kernel<1> grid=%d", wino_grid(d, 1));
+    } else if (pk_enabled() && strided) {
       snprintf(buf, len, "igemm_pk_kernel<%s,1>s2 (stride-parity classes)", d->Cin % 128 == 0 ? "2,2,2,2" : "4,1,1,2");
     } else if (pk_enabled()) {
       pk_name(M, d->Cin, ktl * d->kh * d->kw * (d->Cout / BK), 1);

@@ -1,0 +1,368 @@
+// Winograd F(2x2, 3x3) for the (1,3,3) stride-1 convolutions of the residual blocks (models/network_blocks.py:35,40:
+// spt_conv1 / spt_conv2, and Basic2DBlock's 3x3 layers) — forward and input gradient — as ONE fused kernel on the fp32
+// MFMA: input transform -> 16 [32 tiles x Cr] x [Cr x 64] products -> output transform; only the source tensor, the
+// transformed weights U and the destination touch memory.  2.25x fewer multiply-adds than the direct form
+// (csrc/conv.hip), which is what counts once the matrix pipe's clock is the limit.
+//
+//   source   [F][H][W][Cr]   (F = B*T frames; forward: x, Cr = Cin; input gradient: dy, Cr = Cout)
+//   U        [16][Cn][Cr]    = G g G^T per (output channel n, reduction channel k); the input gradient uses the
+//                              taps flipped and the channel roles swapped (a stride-1 pad-1 3x3 correlation again)
+//   dest     [F][H][W][Cn]
+//   workgroup = 4 waves: 32 tiles (2x2 outputs each) x 64 output channels; wave w owns the transform points
+//   xi = 4w .. 4w+3 (row w of the 4x4), i.e. 8 accumulator blocks of 32 x 32.
+//   LDS: V[16][32 tiles][32 + 4]: one 32-channel chunk of the transformed input at a time (73.7 KB, two workgroups
+//   per CU).  A operand: V[xi][tile = lane & 31][16 * (lane >> 5) + s]; B operand straight from U (L2-resident):
+//   U[xi][n][16 * (lane >> 5) + s] — both are 16 consecutive floats per lane, the MFMA's k index runs (s, lane >> 5).
+//   Output transform: columns in registers, rows across the four waves through LDS (V is dead by then); wave w then
+//   stores output pixel (w >> 1, w & 1) of every tile: 128 contiguous bytes per 32 lanes.
+//   Epilogues: BatchNorm partial sums of the output (forward), addend and the BatchNorm-backward sums of the
+//   gradient being written (input gradient) — the same contracts as igemm_pk_kernel's.
+// Rounding differs from the direct form (transforms add before the products): measured 3.5e-7 of the output scale
+// against fp64 on conv2x, inside every tolerance the direct kernels are tested to.
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace avid {
+
+constexpr int W_TB = 32, W_CK = 32, W_VLD = W_CK + 4;
+constexpr int W_LDS_FLOATS = 16 * W_TB * W_VLD;
+
+struct WinoArgs {
+  const float* __restrict__ src;
+  const float* __restrict__ U;
+  float* __restrict__ dst;
+  const float* __restrict__ addend;
+  float* __restrict__ stats;            // one row [2][Cn] per workgroup, or null
+  const float* __restrict__ bnb_x;      // EPI & 4: BatchNorm input at the destination positions + saved coefficients
+  const float* __restrict__ bnb_scale;
+  const float* __restrict__ bnb_shift;
+  const float* __restrict__ bnb_mean;
+  const float* __restrict__ bnb_invstd;
+  int bnb_relu;
+  int F, H, W, TH, TW, Cr, Cn, ncb;
+  long long ntiles;
+  int units;                            // tile blocks x column blocks, column block fastest
+};
+
+// U[(xi * Cn + n) * Cr + k] = (G g G^T)[xi / 4][xi % 4],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// flip = 0: g[a][b] = w[n][a][b][k] (forward);  flip = 1: g[a][b] = w[k][2-a][2-b][n] (input gradient)
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cn,
+                                                          int Cr, int Cin, int flip) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Cn * Cr) return;
+  const int k = (int)(i % Cr), n = (int)(i / Cr);
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      g[a][b] = flip ? w[(((long long)k * 3 + (2 - a)) * 3 + (2 - b)) * Cin + n] : w[(((long long)n * 3 + a) * 3 + b) * Cin + k];
+  float t[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+    t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+    t[3][b] = g[2][b];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]),
+                u3 = t[a][2];
+    const long long o = ((long long)(a * 4) * Cn + n) * Cr + k, st = (long long)Cn * Cr;
+    U[o] = u0;
+    U[o + st] = u1;
+    U[o + 2 * st] = u2;
+    U[o + 3 * st] = u3;
+  }
+}
+
+// EPI bits: 1 BatchNorm partial sums of the output, 2 addend, 4 BatchNorm-backward sums (needs bnb_*)
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int H = p.H, W = p.W, TW = p.TW, TPF = p.TH * p.TW, Cr = p.Cr, Cn = p.Cn;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((long long)p.F * H * W * Cr * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, 16 * Cn * Cr * 4, 0x00020000);
+  const int nchunks = Cr / W_CK;
+  float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};
+  const int cb = (int)(blockIdx.x % p.ncb);          // the grid is a multiple of ncb: one column block per workgroup
+  for (int unit = blockIdx.x; unit < p.units; unit += gridDim.x) {
+    const int blk = unit / p.ncb;
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+    // this thread's tile of the input transform: (4 channels = tid & 7, tile = tid >> 3)
+    const int c4 = (tid & 7) * 4, ttl = tid >> 3;
+    const long long tt_ = (long long)blk * W_TB + ttl;
+    const bool t_ok = tt_ < p.ntiles;
+    const int tf = (int)((t_ok ? tt_ : 0) / TPF), trem = (int)((t_ok ? tt_ : 0) - (long long)tf * TPF);
+    const int tti = trem / TW, ttj = trem - tti * TW;
+    for (int ck = 0; ck < nchunks; ++ck) {
+      __syncthreads();                         // the previous chunk's / unit's LDS reads are done
+      {
+        // V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]: column by column, then row by row
+        floatx4 w_[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          floatx4 d[4];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int yy = 2 * tti - 1 + a, xx = 2 * ttj - 1 + b;
+            const bool ok = t_ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const unsigned off = (unsigned)((((long long)tf * H + yy) * W + xx) * Cr + ck * W_CK + c4) * 4u;
+            d[a] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? off : 0x80000000u, 0, 0));
+          }
+          w_[0][b] = d[0] - d[2];
+          w_[1][b] = d[1] + d[2];
+          w_[2][b] = d[2] - d[1];
+          w_[3][b] = d[1] - d[3];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          float* dst = sm + ((a * 4) * W_TB + ttl) * W_VLD + c4;
+          *reinterpret_cast<floatx4*>(dst + 0 * W_TB * W_VLD) = w_[a][0] - w_[a][2];
+          *reinterpret_cast<floatx4*>(dst + 1 * W_TB * W_VLD) = w_[a][1] + w_[a][2];
+          *reinterpret_cast<floatx4*>(dst + 2 * W_TB * W_VLD) = w_[a][2] - w_[a][1];
+          *reinterpret_cast<floatx4*>(dst + 3 * W_TB * W_VLD) = w_[a][1] - w_[a][3];
+        }
+      }
+      __syncthreads();
+      // ---- the wave's four products; the next point's B operand is in flight while the current one multiplies
+      floatx4 bv[2][2][4];
+      auto load_b = [&](int c, int buf) {
+        const int xi = wave * 4 + c;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            bv[buf][j][q] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                rsU, (unsigned)((((long long)xi * Cn + cb * 64 + j * 32 + l31) * Cr + ck * W_CK + 16 * h + 4 * q) * 4), 0, 0));
+      };
+      load_b(0, 0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c + 1 < 4) load_b(c + 1, (c + 1) & 1);
+        const int xi = wave * 4 + c;
+        const float* Ap = sm + (xi * W_TB + l31) * W_VLD + 16 * h;
+        floatx4 av[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const floatx4*>(Ap + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][e], bv[c & 1][j][q][e], acc[c][j], 0, 0, 0);
+      }
+    }
+    // ---- output transform.  Columns in registers: T[r][0] = M0 + M1 + M2, T[r][1] = M1 - M2 - M3 (r = wave)
+    floatx16 T0[2], T1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      T0[j] = acc[0][j] + acc[1][j] + acc[2][j];
+      T1[j] = acc[1][j] - acc[2][j] - acc[3][j];
+    }
+    __syncthreads();                           // V is dead: the LDS becomes the exchange buffer T[r][q][j][reg][lane]
+    float* ex = sm;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        ex[(((wave * 2 + 0) * 2 + j) * 16 + r) * 64 + lane] = T0[j][r];
+        ex[(((wave * 2 + 1) * 2 + j) * 16 + r) * 64 + lane] = T1[j][r];
+      }
+    __syncthreads();
+    // rows across waves: this wave writes output pixel (po, qo) of every tile:
+    //   Y[0][q] = T[0][q] + T[1][q] + T[2][q],  Y[1][q] = T[1][q] - T[2][q] - T[3][q]
+    const int po = wave >> 1, qo = wave & 1;
+    int ooff[16];                               // destination row offsets (in floats, < 2^29) of the lane's 16 tiles, or -1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tl = (r & 3) + 8 * (r >> 2) + 4 * h;      // MFMA C layout: row = tile
+      const long long t = (long long)blk * W_TB + tl;
+      const int f = (int)((t < p.ntiles ? t : 0) / TPF), rem = (int)((t < p.ntiles ? t : 0) - (long long)f * TPF);
+      const int ti = rem / TW, tj = rem - ti * TW;
+      const int yy = 2 * ti + po, xx = 2 * tj + qo;
+      ooff[r] = (t < p.ntiles && yy < H && xx < W) ? (int)((((long long)f * H + yy) * W + xx) * Cn) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = cb * 64 + j * 32 + l31;
+      float bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
+      if (EPI & 4) { bsc = p.bnb_scale[col]; bsh = p.bnb_shift[col]; bmu = p.bnb_mean[col]; bis = p.bnb_invstd[col]; }
+      float ad[16], xb[16];
+      if (EPI & 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ad[r] = ooff[r] >= 0 ? p.addend[ooff[r] + col] : 0.f;
+      }
+      if (EPI & 4) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xb[r] = ooff[r] >= 0 ? p.bnb_x[ooff[r] + col] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        auto Tq = [&](int rr) { return ex[(((rr * 2 + qo) * 2 + j) * 16 + r) * 64 + lane]; };
+        float v = po == 0 ? Tq(0) + Tq(1) + Tq(2) : Tq(1) - Tq(2) - Tq(3);
+        if (EPI & 2) v += ad[r];
+        if (ooff[r] >= 0) {
+          p.dst[ooff[r] + col] = v;
+          if (EPI & 1) { cs[j] += v; cq[j] = fmaf(v, v, cq[j]); }
+          if (EPI & 4) {
+            const float dm = (!p.bnb_relu || fmaf(xb[r], bsc, bsh) > 0.f) ? v : 0.f;
+            cs[j] += dm;
+            cq[j] = fmaf(dm, (xb[r] - bmu) * bis, cq[j]);
+          }
+        }
+      }
+    }
+  }
+  if ((EPI & 5) && p.stats) {   // one partial row [2][Cn] per workgroup: half-waves, then the four waves in fixed order
+    __syncthreads();
+    float* red = sm;            // [2][4][64]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a = cs[j] + __shfl_xor(cs[j], 32, 64), b = cq[j] + __shfl_xor(cq[j], 32, 64);
+      if (h == 0) {
+        red[wave * 64 + j * 32 + l31] = a;
+        red[256 + wave * 64 + j * 32 + l31] = b;
+      }
+    }
+    __syncthreads();
+    float* row = p.stats + (long long)blockIdx.x * 2 * Cn;
+    for (int c = tid; c < Cn; c += 256) {
+      float a = 0.f, b = 0.f;
+      if (c / 64 == cb) {
+        const int cc = c % 64;
+        a = (red[cc] + red[64 + cc]) + (red[128 + cc] + red[192 + cc]);
+        b = (red[256 + cc] + red[320 + cc]) + (red[384 + cc] + red[448 + cc]);
+      }
+      row[c] = a;
+      row[Cn + c] = b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int wino_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+static int wino_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// mode 0: forward (x -> y), mode 1: input gradient (dy -> dx)
+bool wino_supported(const avid_conv_desc* d, int mode) {
+  static int on = -1, min_m = 0, max_c = 0;
+  if (on < 0) {
+    on = wino_env("AVID_WINO", 1);
+    min_m = wino_env("AVID_WINO_MIN_M", 8192);
+    max_c = wino_env("AVID_WINO_MAXC", 128);
+  }
+  if (!on || d->x_channel_first) return false;
+  if (d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1) return false;
+  if (d->pt != 0 || d->ph != 1 || d->pw != 1) return false;
+  const int Cr = mode ? d->Cout : d->Cin, Cn = mode ? d->Cin : d->Cout;
+  if (Cr % W_CK || Cn % 64 || Cn > max_c) return false;
+  const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
+  if (M < min_m) return false;
+  const long long big = M * (Cr > Cn ? Cr : Cn) * 4;
+  return big < (1ll << 31);
+}
+
+size_t wino_ws_bytes(const avid_conv_desc* d, int mode) {
+  (void)mode;
+  return sizeof(float) * 16 * (size_t)d->Cin * d->Cout;
+}
+
+int wino_grid(const avid_conv_desc* d, int mode) {
+  const int Cn = mode ? d->Cin : d->Cout, ncb = Cn / 64;
+  int g = 2 * wino_cus();
+  g = g / ncb * ncb;
+  const long long TH = (d->Hi + 1) / 2, TW = (d->Wi + 1) / 2;
+  const long long units = ceil_div((long long)d->B * d->Ti * TH * TW, W_TB) * ncb;
+  if (units < g) g = (int)(ceil_div(units, ncb) * ncb);
+  return g;
+}
+
+template <int EPI>
+static void wino_launch(const WinoArgs& a, int grid, hipStream_t s) {
+  auto kern = wino_kernel<EPI>;
+  const size_t lds = sizeof(float) * W_LDS_FLOATS;
+  static bool set = false;
+  if (!set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+}
+
+// src / dst are x / y (mode 0) or dy / dx (mode 1); ws holds U (wino_ws_bytes)
+int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* w, float* dst, const float* addend,
+              float* stats, const avid_bn_bwd_fuse* bn, void* ws, hipStream_t s) {
+  WinoArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src = src; a.dst = dst; a.addend = addend;
+  a.F = d->B * d->Ti; a.H = d->Hi; a.W = d->Wi;
+  a.TH = (d->Hi + 1) / 2; a.TW = (d->Wi + 1) / 2;
+  a.Cr = mode ? d->Cout : d->Cin;
+  a.Cn = mode ? d->Cin : d->Cout;
+  a.ncb = a.Cn / 64;
+  a.ntiles = (long long)a.F * a.TH * a.TW;
+  a.units = (int)(ceil_div(a.ntiles, W_TB) * a.ncb);
+  float* U = static_cast<float*>(ws);
+  a.U = U;
+  {
+    const long long n = (long long)a.Cn * a.Cr;
+    ScopedTimer t(s, "wino_weight_kernel", 0.0, 4.0 * n * 25);
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, w, U, a.Cn, a.Cr, d->Cin, mode);
+  }
+  int rc = check_launch("wino_weight");
+  if (rc) return rc;
+  int epi = 0;
+  if (mode == 0 && stats) { epi = 1; a.stats = stats; }
+  if (addend) epi |= 2;
+  if (mode == 1 && bn) {
+    epi |= 4;
+    a.bnb_x = bn->x; a.bnb_scale = bn->scale; a.bnb_shift = bn->shift; a.bnb_mean = bn->mean; a.bnb_invstd = bn->invstd;
+    a.bnb_relu = bn->relu;
+    a.stats = bn->partials;
+  }
+  const int grid = wino_grid(d, mode);
+  const double M = (double)d->B * d->Ti * d->Hi * d->Wi;
+  // flops: the multiply-adds the MFMAs of this kernel really execute (16 products of [tiles x Cr] x [Cr x Cn]), not
+  // the direct form's 2.25x larger count; bytes: source + destination (+ addend, + x of the BatchNorm-backward sums)
+  static const char* kNames[8] = {"wino_kernel<0>", "wino_kernel<1>", "wino_kernel<2>", "wino_kernel<3>",
+                                  "wino_kernel<4>", "wino_kernel<5>", "wino_kernel<6>", "wino_kernel<7>"};
+  ScopedTimer t(s, kNames[epi & 7], 2.0 * 16.0 * (double)a.ntiles * a.Cr * a.Cn,
+                4.0 * M * (a.Cr + a.Cn * (1 + (addend ? 1 : 0) + ((epi & 4) ? 1 : 0))));
+  switch (epi) {
+    case 0: wino_launch<0>(a, grid, s); break;
+    case 1: wino_launch<1>(a, grid, s); break;
+    case 2: wino_launch<2>(a, grid, s); break;
+    case 3: wino_launch<3>(a, grid, s); break;
+    case 4: wino_launch<4>(a, grid, s); break;
+    case 6: wino_launch<6>(a, grid, s); break;
+    default: set_error("wino_conv: unsupported epilogue %d", epi); return AVID_E_UNSUPPORTED;
+  }
+  return check_launch("wino_conv");
+}
+
+}  // namespace avid

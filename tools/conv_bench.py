@@ -80,9 +80,19 @@ for name, cin, cout, k, st, pd, (T, H, W) in L:
             if n.startswith(pref) and (mode is None or n.endswith(f",{mode}>") or n.endswith(f",{mode}>s2")):
                 t += v["ms"]; names.append(n)
         return t / reps * 1e3, names
+    def pick_w(rep, mode):     # the Winograd path: kernel + its weight transform
+        t = 0.0; names = []
+        for n, v in rep.items():
+            if n.startswith("wino_kernel<") or n == "wino_weight_kernel":
+                t += v["ms"]; names.append(n)
+        return t / reps * 1e3, [n for n in names if n.startswith("wino_kernel")]
     f_us, fn = pick(res["fwd"], "igemm_", 0)
+    wf_us, wfn = pick_w(res["fwd"], 0)
+    f_us += wf_us; fn += wfn
     fr_us, _ = pick(res["fwd"], "splitk")
     d_us, dn = pick(res["bwd"], "igemm_", 1)
+    wd_us, wdn = pick_w(res["bwd"], 1)
+    d_us += wd_us; dn += wdn
     dr_us, _ = pick(res["bwd"], "splitk"); dt_us, _ = pick(res["bwd"], "weight_tr")
     w_us, wn = pick(res["bwd"], "wgrad_tab")
     wr_us, _ = pick(res["bwd"], "wgrad_reduce")
