@@ -27,6 +27,7 @@ namespace avid {
 
 constexpr int W_TB = 32, W_CK = 32, W_VLD = W_CK + 4;
 constexpr int W_LDS_FLOATS = 16 * W_TB * W_VLD;
+constexpr int W_TAB_INTS = 2 * W_TB * 4;          // double-buffered tile table: (frame or -1, ti, tj, -) per tile of a unit
 
 struct WinoArgs {
   const float* __restrict__ src;
@@ -78,6 +79,15 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   }
 }
 
+#ifdef AVID_WINO_TRACE
+__device__ long long g_wino_trace[1024 * 8];
+extern "C" int avid_debug_wino_trace(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_trace), sizeof(long long) * 1024 * 8);
+}
+#define W_STAMP(i) do { if (threadIdx.x == 0) { const long long now_ = wall_clock64(); g_wino_trace[blockIdx.x * 8 + (i)] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
+#define W_STAMP(i) do {} while (0)
+#endif
 // EPI bits: 1 BatchNorm partial sums of the output, 2 addend, 4 BatchNorm-backward sums (needs bnb_*)
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
@@ -90,8 +100,14 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
   const int nchunks = Cr / W_CK;
   float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};
   const int cb = (int)(blockIdx.x % p.ncb);          // the grid is a multiple of ncb: one column block per workgroup
+#ifdef AVID_WINO_TRACE
+  long long tprev_ = wall_clock64();
+  if (threadIdx.x == 0) for (int i = 0; i < 8; ++i) g_wino_trace[blockIdx.x * 8 + i] = 0;
+#endif
+  int uidx = 0;
   for (int unit = blockIdx.x; unit < p.units; unit += gridDim.x) {
     const int blk = unit / p.ncb;
+    W_STAMP(0);
     floatx16 acc[4][2];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -99,14 +115,30 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+    // tile table of this unit (tile index -> frame, ti, tj; frame = -1 past the end): the two integer divisions per
+    // tile are done once, by 32 lanes, instead of by every thread of the transform and 16 times per lane of the
+    // epilogue (~1000 VALU instructions per wave and unit, on the matrix pipe's time)
+    int4* tab = reinterpret_cast<int4*>(sm + W_LDS_FLOATS) + (uidx & 1) * W_TB;
+    if (tid < W_TB) {
+      const long long t = (long long)blk * W_TB + tid;
+      int4 e = {-1, 0, 0, 0};
+      if (t < p.ntiles) {
+        const int f = (int)(t / TPF), rem = (int)(t - (long long)f * TPF);
+        e.x = f; e.y = rem / TW; e.z = rem - e.y * TW;
+      }
+      tab[tid] = e;
+    }
+    ++uidx;
     // this thread's tile of the input transform: (4 channels = tid & 7, tile = tid >> 3)
     const int c4 = (tid & 7) * 4, ttl = tid >> 3;
-    const long long tt_ = (long long)blk * W_TB + ttl;
-    const bool t_ok = tt_ < p.ntiles;
-    const int tf = (int)((t_ok ? tt_ : 0) / TPF), trem = (int)((t_ok ? tt_ : 0) - (long long)tf * TPF);
-    const int tti = trem / TW, ttj = trem - tti * TW;
+    int tf = 0, tti = 0, ttj = 0;
+    bool t_ok = false;
     for (int ck = 0; ck < nchunks; ++ck) {
-      __syncthreads();                         // the previous chunk's / unit's LDS reads are done
+      __syncthreads();                         // the previous chunk's / unit's LDS reads are done; the tile table is there
+      if (ck == 0) {
+        const int4 e = tab[ttl];
+        t_ok = e.x >= 0; tf = e.x; tti = e.y; ttj = e.z;
+      }
       {
         // V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]: column by column, then row by row
         floatx4 w_[4][4];
@@ -135,21 +167,25 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
         }
       }
       __syncthreads();
+      W_STAMP(1);
       // ---- the wave's four products; the next point's B operand is in flight while the current one multiplies
+      // B operand (U, from L2): double-buffered per transform point, the next point in flight while one multiplies
+      // (keeping the first point of the NEXT chunk in flight across the input transform cost more in spills than
+      // the hidden latency was worth: 218 -> 225 us)
       floatx4 bv[2][2][4];
-      auto load_b = [&](int c, int buf) {
+      auto load_b = [&](int c, int buf, int ck_) {
         const int xi = wave * 4 + c;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             bv[buf][j][q] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
-                rsU, (unsigned)((((long long)xi * Cn + cb * 64 + j * 32 + l31) * Cr + ck * W_CK + 16 * h + 4 * q) * 4), 0, 0));
+                rsU, (unsigned)((((long long)xi * Cn + cb * 64 + j * 32 + l31) * Cr + ck_ * W_CK + 16 * h + 4 * q) * 4), 0, 0));
       };
-      load_b(0, 0);
+      load_b(0, 0, ck);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        if (c + 1 < 4) load_b(c + 1, (c + 1) & 1);
+        if (c + 1 < 4) load_b(c + 1, (c + 1) & 1, ck);
         const int xi = wave * 4 + c;
         const float* Ap = sm + (xi * W_TB + l31) * W_VLD + 16 * h;
         floatx4 av[4];
@@ -163,8 +199,10 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
             for (int j = 0; j < 2; ++j)
               acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][e], bv[c & 1][j][q][e], acc[c][j], 0, 0, 0);
       }
+      W_STAMP(2);
     }
     // ---- output transform.  Columns in registers: T[r][0] = M0 + M1 + M2, T[r][1] = M1 - M2 - M3 (r = wave)
+    W_STAMP(3);
     floatx16 T0[2], T1[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -172,13 +210,14 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
       T1[j] = acc[1][j] - acc[2][j] - acc[3][j];
     }
     __syncthreads();                           // V is dead: the LDS becomes the exchange buffer T[r][q][j][reg][lane]
-    float* ex = sm;
+    float* ex = sm;                             // ex[row][q][j][r / 4][lane][r % 4]: 16-byte accesses, conflict-free
+    auto ex_at = [&](int row, int q_, int j, int r4) { return ex + (((((row * 2 + q_) * 2 + j) * 4 + r4) * 64 + lane) << 2); };
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        ex[(((wave * 2 + 0) * 2 + j) * 16 + r) * 64 + lane] = T0[j][r];
-        ex[(((wave * 2 + 1) * 2 + j) * 16 + r) * 64 + lane] = T1[j][r];
+      for (int r4 = 0; r4 < 4; ++r4) {
+        *reinterpret_cast<floatx4*>(ex_at(wave, 0, j, r4)) = floatx4{T0[j][4 * r4], T0[j][4 * r4 + 1], T0[j][4 * r4 + 2], T0[j][4 * r4 + 3]};
+        *reinterpret_cast<floatx4*>(ex_at(wave, 1, j, r4)) = floatx4{T1[j][4 * r4], T1[j][4 * r4 + 1], T1[j][4 * r4 + 2], T1[j][4 * r4 + 3]};
       }
     __syncthreads();
     // rows across waves: this wave writes output pixel (po, qo) of every tile:
@@ -187,12 +226,9 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
     int ooff[16];                               // destination row offsets (in floats, < 2^29) of the lane's 16 tiles, or -1
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int tl = (r & 3) + 8 * (r >> 2) + 4 * h;      // MFMA C layout: row = tile
-      const long long t = (long long)blk * W_TB + tl;
-      const int f = (int)((t < p.ntiles ? t : 0) / TPF), rem = (int)((t < p.ntiles ? t : 0) - (long long)f * TPF);
-      const int ti = rem / TW, tj = rem - ti * TW;
-      const int yy = 2 * ti + po, xx = 2 * tj + qo;
-      ooff[r] = (t < p.ntiles && yy < H && xx < W) ? (int)((((long long)f * H + yy) * W + xx) * Cn) : -1;
+      const int4 e = tab[(r & 3) + 8 * (r >> 2) + 4 * h];      // MFMA C layout: row = tile
+      const int yy = 2 * e.y + po, xx = 2 * e.z + qo;
+      ooff[r] = (e.x >= 0 && yy < H && xx < W) ? ((e.x * H + yy) * W + xx) * Cn : -1;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -208,10 +244,19 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) xb[r] = ooff[r] >= 0 ? p.bnb_x[ooff[r] + col] : 0.f;
       }
+      float yv[16];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const floatx4 a = *reinterpret_cast<const floatx4*>(ex_at(po, qo, j, r4));        // rows po, po + 1, po + 2
+        const floatx4 b = *reinterpret_cast<const floatx4*>(ex_at(po + 1, qo, j, r4));
+        const floatx4 c = *reinterpret_cast<const floatx4*>(ex_at(po + 2, qo, j, r4));
+        const floatx4 y4 = po == 0 ? a + b + c : a - b - c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yv[4 * r4 + e] = y4[e];
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        auto Tq = [&](int rr) { return ex[(((rr * 2 + qo) * 2 + j) * 16 + r) * 64 + lane]; };
-        float v = po == 0 ? Tq(0) + Tq(1) + Tq(2) : Tq(1) - Tq(2) - Tq(3);
+        float v = yv[r];
         if (EPI & 2) v += ad[r];
         if (ooff[r] >= 0) {
           p.dst[ooff[r] + col] = v;
@@ -225,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
       }
     }
   }
+  W_STAMP(4);
   if ((EPI & 5) && p.stats) {   // one partial row [2][Cn] per workgroup: half-waves, then the four waves in fixed order
     __syncthreads();
     float* red = sm;            // [2][4][64]
@@ -305,7 +351,7 @@ int wino_grid(const avid_conv_desc* d, int mode) {
 template <int EPI>
 static void wino_launch(const WinoArgs& a, int grid, hipStream_t s) {
   auto kern = wino_kernel<EPI>;
-  const size_t lds = sizeof(float) * W_LDS_FLOATS;
+  const size_t lds = sizeof(float) * W_LDS_FLOATS + sizeof(int) * W_TAB_INTS;
   static bool set = false;
   if (!set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
