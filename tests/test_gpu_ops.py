@@ -113,6 +113,8 @@ def test_conv_bn_partials(shape, cout, gpu_device):
     ((8, 8, 28, 28), 64, 128, (1, 3, 3), (0, 1, 1), (1, 2, 2)),       # strided consumer, tiles written directly
     ((3, 4, 13, 15), 128, 256, (1, 3, 3), (0, 1, 1), (1, 2, 2)),      # strided, every tile K-split (reduce kernel)
     ((3, 5, 9, 9), 64, 64, (3, 1, 1), (1, 0, 0), (2, 1, 1)),          # temporal stride, odd extent
+    ((6, 8, 27, 29), 64, 64, (1, 3, 3), (0, 1, 1), (1, 1, 1)),        # Winograd input gradient (>= 32768 pixels), odd extents
+    ((5, 4, 45, 47), 128, 128, (1, 3, 3), (0, 1, 1), (1, 1, 1)),      # Winograd, two 64-column blocks, 4 reduction chunks
 ])
 def test_bn_backward_partials_from_dgrad(shape, cmid, cout, k, pad, stride, gpu_device):
     """conv1 -> BN+ReLU -> conv2 [+ tap]: with ops.BnSource the BatchNorm's backward partial sums come out of
