@@ -248,7 +248,7 @@ def main():
         clips = bs * world * args.steps / dt
         # every MFMA kernel of the step: implicit-GEMM forward / dgrad, weight gradients, the two LDS-patch stems
         mfma = {k: v for k, v in kern.items()
-                if v["flops"] > 0 and ("igemm" in k or "wgrad" in k or k.startswith("stem_") or k.startswith("wino_kernel"))}
+                if v["flops"] > 0 and ("igemm" in k or "wgrad" in k or k.startswith("stem_") or k.startswith(("wino_kernel", "winot_kernel")))}
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         d = mfma[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12

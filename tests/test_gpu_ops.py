@@ -42,6 +42,9 @@ CONV_CASES = [
     ("late_64x64", 256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (3, 2, 14, 14)),
     ("big_128x64", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 8, 48, 48)),
     ("big_128x128", 64, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 8, 48, 48)),
+    # large temporal layers: an odd number of frames, T = 2
+    ("tmp_odd_T", 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (3, 7, 40, 41)),
+    ("tmp_T2_128", 128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (9, 2, 45, 47)),
     # persistent kernel: whole rounds + split-K remainder with a ragged last tile; 27 taps crossing batch items
     ("big_ragged_333", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (5, 7, 45, 47)),
     # persistent kernel alone, last round 80 % full and ragged (run unbalanced)
@@ -115,6 +118,7 @@ def test_conv_bn_partials(shape, cout, gpu_device):
     ((3, 5, 9, 9), 64, 64, (3, 1, 1), (1, 0, 0), (2, 1, 1)),          # temporal stride, odd extent
     ((6, 8, 27, 29), 64, 64, (1, 3, 3), (0, 1, 1), (1, 1, 1)),        # Winograd input gradient (>= 32768 pixels), odd extents
     ((5, 4, 45, 47), 128, 128, (1, 3, 3), (0, 1, 1), (1, 1, 1)),      # Winograd, two 64-column blocks, 4 reduction chunks
+    ((3, 7, 40, 41), 64, 64, (3, 1, 1), (1, 0, 0), (1, 1, 1)),        # large temporal layer, odd frame count
 ])
 def test_bn_backward_partials_from_dgrad(shape, cmid, cout, k, pad, stride, gpu_device):
     """conv1 -> BN+ReLU -> conv2 [+ tap]: with ops.BnSource the BatchNorm's backward partial sums come out of
