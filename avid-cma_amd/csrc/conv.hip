@@ -2569,8 +2569,13 @@ extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const floa
   AVID_REQUIRE(x && w && y, AVID_E_BADARG, "conv_fwd: null pointer");
   if (stem_fwd_supported(d) && !addend && !bias && !relu && ws && ws_bytes >= stem_fwd_ws_bytes(d))
     return stem_fwd(d, x, w, y, bn_partials, ws, (hipStream_t)stream);
-  if (wino_supported(d, 0) && !bias && !relu && ws && ws_bytes >= wino_ws_bytes(d, 0))
-    return wino_conv(d, 0, x, w, y, addend, bn_partials, nullptr, ws, (hipStream_t)stream);
+  if (wino_supported(d, 0) && !bias && !relu) {
+    // (avid_conv_fwd_stats_rows promised this kernel's rows: without its workspace the partials would not match)
+    AVID_REQUIRE(!bn_partials || (ws && ws_bytes >= wino_ws_bytes(d, 0)), AVID_E_BADARG,
+                 "conv_fwd: BatchNorm partials of this layer need the planned workspace (avid_conv_fwd_workspace_bytes)");
+    if (ws && ws_bytes >= wino_ws_bytes(d, 0))
+      return wino_conv(d, 0, x, w, y, addend, bn_partials, nullptr, ws, (hipStream_t)stream);
+  }
   const Trim tr = trim_taps(d);
   ConvArgs a;
   fill_common(a, &tr.d);
