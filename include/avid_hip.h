@@ -66,7 +66,11 @@ typedef struct avid_conv_desc {
 
 /* y = conv(x, w) [+ addend] [+ bias] [relu].  addend: [B,To,Ho,Wo,Cout] or NULL (residual add of
  * models/network_blocks.py:59 fused into tmp_conv2/res_conv); bias: [Cout] or NULL.
- * ws: scratch for the split-K partial slabs of small-M layers (may be NULL: single pass, slower). */
+ * ws: scratch for the split-K partial slabs of small-M layers (may be NULL: single pass, slower).
+ * Large (1,3,3) stride-1 layers with <= 128 output channels run as a fused Winograd F(2x2,3x3) kernel (forward and
+ * input gradient; csrc/wino.hip, AVID_WINO=0 to switch it off): same contract, results within 1e-6 of the direct
+ * form; its transformed weights live in ws, so BatchNorm partials / the fused BatchNorm-backward sums of such a
+ * layer need the planned workspace. */
 size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d);
 /* bn_partials (or NULL): BatchNorm partial sums of the output y, [rows][2][Cout] with rows =
  * avid_conv_fwd_stats_rows(d) (0 = this layer cannot produce them), written by the conv epilogue so that
