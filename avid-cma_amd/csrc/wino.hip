@@ -319,7 +319,7 @@ bool wino_supported(const avid_conv_desc* d, int mode) {
   static int on = -1, min_m = 0, max_c = 0;
   if (on < 0) {
     on = wino_env("AVID_WINO", 1);
-    min_m = wino_env("AVID_WINO_MIN_M", 32768);   // (16000 pixels, audio block 1: 33.5 us against the direct kernel's 28.6)
+    min_m = wino_env("AVID_WINO_MIN_M", 24576);   // (25088 pixels: 32 vs 33 us forward, 31 vs 39 us input gradient; 16000: 33.5 vs 28.6)
     max_c = wino_env("AVID_WINO_MAXC", 128);
   }
   if (!on || d->x_channel_first) return false;
