@@ -86,6 +86,7 @@ SIGNATURES = {
     "avid_conv_wgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_wgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_conv_kernel_name": (_i, [_dp, _i, C.c_char_p, _i]),
+    "avid_wino_configure": (_i, [_i, _i64, _i]),
     "avid_bn_workspace_bytes": (_sz, [_i64, _i]),
     "avid_bn_fwd_train": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "avid_bn_fwd_eval": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),

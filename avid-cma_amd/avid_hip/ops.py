@@ -223,6 +223,13 @@ def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
     return hit
 
 
+def wino_configure(enabled=-1, min_pixels=-1, max_channels=-1):
+    """Dispatch switches of the Winograd kernels (``avid_wino_configure``; negative = environment / default) — and
+    drop the per-layer plans cached here, which depend on them."""
+    lib.call("avid_wino_configure", int(enabled), int(min_pixels), int(max_channels))
+    _DESC_CACHE.clear()
+
+
 def _bn_ws_bytes(M, Cc):
     key = (M, Cc)
     nb = _BN_WS_CACHE.get(key)

@@ -123,6 +123,7 @@ class GradBuckets:
         for b in self.bucket_of:
             self.counts[b] += 1
         self.pending = list(self.counts)
+        self.launched = [False] * len(self.bounds)        # bucket b's collective has been issued this step
         self.works = []
         self.hooks = []
         self.comm_stream = None
@@ -157,6 +158,10 @@ class GradBuckets:
         return hook
 
     def _launch(self, b):
+        self.launched[b] = True
+        self._issue(b)
+
+    def _issue(self, b):
         """Issue bucket b's all-reduce.  The two towers' backward passes run on two streams (models/av_wrapper.py)
         and a bucket may hold gradients from both, so the collective must wait for every stream that produced
         them — but the compute streams themselves never wait for each other here (that serialised the audio
@@ -187,13 +192,16 @@ class GradBuckets:
         current stream wait for all buckets."""
         if self.comm:
             for b, left in enumerate(self.pending):
+                if self.launched[b]:
+                    continue
                 if left > 0:
                     self.producers[b].clear()        # not all producers are known: wait for both towers
-                    self._launch(b)
+                self._launch(b)                      # (a COMPLETE bucket is still unlaunched in late-bucket mode)
             for w in self.works:
                 w.wait()                             # the current (compute) stream waits for the collective
         self.works = []
         self.pending = list(self.counts)
+        self.launched = [False] * len(self.bounds)
         for p in self.producers:
             p.clear()
 
@@ -206,13 +214,14 @@ class TrainStep:
     """
 
     def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5,
-                 bucket_bytes=16 << 20, broadcast_buffers="lazy"):
+                 bucket_bytes=16 << 20, broadcast_buffers="step"):
         """``broadcast_buffers``: DistributedDataParallel broadcasts rank 0's BatchNorm buffers before EVERY
         forward (utils/main_utils.py:112, default ``broadcast_buffers=True``).  A training-mode forward never
         reads them (it normalises with the batch statistics), and rank 0's own buffers are never overwritten, so
-        the only observable effect is what a non-zero rank evaluates / saves with.  ``"lazy"`` (default) therefore
-        broadcasts at ``sync_buffers()`` only — call it before evaluation and before saving a checkpoint —
-        ``"step"`` reproduces DDP literally with one flat 78 KB broadcast per step, ``"off"`` never broadcasts."""
+        the only observable effect is what a non-zero rank evaluates / saves with.  ``"step"`` (default) reproduces
+        DDP literally with ONE flat 78 KB broadcast per step (the running statistics are views of one buffer);
+        ``"lazy"`` broadcasts at ``sync_buffers()`` only — the caller must invoke it before evaluating or saving on a
+        rank other than 0 — ``"off"`` never broadcasts."""
         import os
         self.model, self.criterion = model, criterion
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -307,9 +316,11 @@ class TrainStep:
     # ---- optimizer / sampler state in torch.optim.Adam's format (main-avid.py:115,127,138 save and restore
     # ``optimizer.state_dict()``; utils/main_utils.py:250-261 builds Adam over model.parameters())
     def _param_order(self):
-        """index in ``model.parameters()`` order -> (slot in the flat layout, parameter)."""
+        """[(index in ``list(model.parameters())`` — frozen parameters included, as torch.optim.Adam built over
+        ``model.parameters()`` numbers them (utils/main_utils.py:250-261) —, slot in the flat layout, parameter)]
+        for the trainable parameters."""
         slot = {id(p): i for i, p in enumerate(self.flat.params)}
-        return [(slot[id(p)], p) for p in self.model.parameters() if id(p) in slot]
+        return [(k, slot[id(p)], p) for k, p in enumerate(self.model.parameters()) if id(p) in slot]
 
     def _slice(self, flat_tensor, i):
         p, o = self.flat.params[i], self.flat.offsets[i]
@@ -320,12 +331,15 @@ class TrainStep:
         step = float(int(self.t_dev) if self.t_dev is not None else self.t)
         state = {}
         if step > 0:
-            for k, (i, _) in enumerate(order):
+            for k, i, _ in order:                  # (a frozen parameter has an index but no state, as in torch)
                 state[k] = {"step": torch.tensor(step), "exp_avg": self._slice(self.m, i).detach().clone(),
                             "exp_avg_sq": self._slice(self.v, i).detach().clone()}
+        nparams = sum(1 for _ in self.model.parameters())
         sd = {"state": state,
               "param_groups": [{"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
-                                "amsgrad": False, "maximize": False, "params": list(range(len(order)))}]}
+                                "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                                "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                                "params": list(range(nparams))}]}
         mult = getattr(getattr(self.criterion, "nce_average", None), "multinomial", None)
         if mult is not None:       # the negative sampler's stream position (not part of the reference's checkpoint:
             off = int(mult.offset_dev) if getattr(mult, "offset_dev", None) is not None else int(mult.offset)
@@ -340,7 +354,7 @@ class TrainStep:
         self.m.zero_()
         self.v.zero_()
         step = 0
-        for k, (i, _) in enumerate(order):
+        for k, i, _ in order:
             st = sd["state"].get(k, sd["state"].get(str(k)))
             if st is None:
                 continue
@@ -354,9 +368,19 @@ class TrainStep:
         if mult is not None and "avid_sampler" in sd:
             mult.reseed(sd["avid_sampler"]["seed"], sd["avid_sampler"]["offset"])
 
+    def _poll_errors(self):
+        """Out-of-range sample ids raise here (non-blocking look at the device error word, ops.DeviceErrors): the
+        criterion's own polls do not run when a captured graph is replayed.  The error surfaces about one step after
+        the offending kernels, i.e. after Adam has applied that step — ``ops.check_device_errors()`` is the blocking
+        form for checkpoint time."""
+        if self.flat.flat.is_cuda:
+            from . import ops
+            ops.poll_device_errors(self.flat.flat.device)
+
     def step(self, video, audio, index):
         loss = self.forward_backward(video, audio, index)
         self.optimizer_step()
+        self._poll_errors()
         return loss.detach()
 
     # ---- whole-step hipGraph: ~600 launches replayed with one host call (kills the Python launch overhead)
@@ -384,6 +408,7 @@ class TrainStep:
         if index is not None:
             self._si.copy_(index, non_blocking=True)
         self.graph.replay()
+        self._poll_errors()
         self.t += 1
         mult = getattr(getattr(self.criterion, "nce_average", None), "multinomial", None)
         if mult is not None:

@@ -303,32 +303,47 @@ static int wino_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-static int wino_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
+static int wino_cus() {      // per device: a process may touch more than one
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cus[dev]) {
     hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
-    if (cus <= 0) cus = 256;
+    int n = 0;
+    if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    cus[dev] = n > 0 ? n : 256;
   }
-  return cus;
+  return cus[dev];
+}
+
+// The switches of this path: AVID_WINO / AVID_WINO_MIN_M / AVID_WINO_MAXC from the environment, unless
+// avid_wino_configure() (include/avid_hip.h) has overridden them — tests force small fixtures through the kernel.
+struct WinoCfg { int on; long long min_m; int max_c; bool loaded; };
+static WinoCfg g_wino_cfg = {1, 24576, 128, false};
+static int g_wino_override[3] = {-1, -1, -1};
+
+static const WinoCfg& wino_cfg() {
+  WinoCfg& c = g_wino_cfg;
+  if (!c.loaded) {
+    c.on = g_wino_override[0] >= 0 ? g_wino_override[0] : wino_env("AVID_WINO", 1);
+    // (25088 pixels: 32 vs 33 us forward, 31 vs 39 us input gradient; 16000: 33.5 vs 28.6)
+    c.min_m = g_wino_override[1] >= 0 ? g_wino_override[1] : wino_env("AVID_WINO_MIN_M", 24576);
+    c.max_c = g_wino_override[2] >= 0 ? g_wino_override[2] : wino_env("AVID_WINO_MAXC", 128);
+    c.loaded = true;
+  }
+  return c;
 }
 
 // mode 0: forward (x -> y), mode 1: input gradient (dy -> dx)
 bool wino_supported(const avid_conv_desc* d, int mode) {
-  static int on = -1, min_m = 0, max_c = 0;
-  if (on < 0) {
-    on = wino_env("AVID_WINO", 1);
-    min_m = wino_env("AVID_WINO_MIN_M", 24576);   // (25088 pixels: 32 vs 33 us forward, 31 vs 39 us input gradient; 16000: 33.5 vs 28.6)
-    max_c = wino_env("AVID_WINO_MAXC", 128);
-  }
-  if (!on || d->x_channel_first) return false;
+  const WinoCfg& c = wino_cfg();
+  if (!c.on || d->x_channel_first) return false;
   if (d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1) return false;
   if (d->pt != 0 || d->ph != 1 || d->pw != 1) return false;
   const int Cr = mode ? d->Cout : d->Cin, Cn = mode ? d->Cin : d->Cout;
-  if (Cr % W_CK || Cn % 64 || Cn > max_c) return false;
+  if (Cr % W_CK || Cn % 64 || Cn > c.max_c) return false;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
-  if (M < min_m) return false;
+  if (M < c.min_m) return false;
   const long long big = M * (Cr > Cn ? Cr : Cn) * 4;
   return big < (1ll << 31);
 }
@@ -352,10 +367,12 @@ template <int EPI>
 static void wino_launch(const WinoArgs& a, int grid, hipStream_t s) {
   auto kern = wino_kernel<EPI>;
   const size_t lds = sizeof(float) * W_LDS_FLOATS + sizeof(int) * W_TAB_INTS;
-  static bool set = false;
-  if (!set) {
+  static bool set[64] = {false};           // the attribute is per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    set = true;
+    set[dev] = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
 }
@@ -412,3 +429,11 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
 }
 
 }  // namespace avid
+
+extern "C" int avid_wino_configure(int enabled, int64_t min_pixels, int max_channels) {
+  avid::g_wino_override[0] = enabled < 0 ? -1 : (enabled ? 1 : 0);
+  avid::g_wino_override[1] = min_pixels < 0 ? -1 : (int)(min_pixels > 0x7fffffff ? 0x7fffffff : min_pixels);
+  avid::g_wino_override[2] = max_channels < 0 ? -1 : max_channels;
+  avid::g_wino_cfg.loaded = false;
+  return AVID_OK;
+}

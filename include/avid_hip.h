@@ -124,6 +124,14 @@ int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_dev, int64_t 
  * "igemm_kernel<4,1,1,2,1>" — lets bench.py attribute HIP-event timings to rocprofv3 kernel names. */
 int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* buf, int len);
 
+/* Dispatch switches of the Winograd path (defaults: on, layers of >= 24576 output pixels, <= 128 output channels;
+ * environment AVID_WINO / AVID_WINO_MIN_M / AVID_WINO_MAXC).  A negative argument returns that switch to its
+ * environment / default value.  Changes what avid_conv_fwd / avid_conv_dgrad / avid_conv_wgrad dispatch to and what
+ * the *_workspace_bytes / *_rows queries answer from the next call on: callers that cache those answers per layer
+ * must drop them (ops.wino_configure does).  Parity tests use it to send the reference-generated small fixtures
+ * (tests/golden) through the Winograd kernels (models/network_blocks.py:35,40 at 2 clips). */
+int avid_wino_configure(int enabled, int64_t min_pixels, int max_channels);
+
 /* dw[Cout][kt][kh][kw][Cin] = sum_m dy[m][:]^T x_col[m][:]  (deterministic split-M + tree reduce). */
 size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d);
 int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,

@@ -31,3 +31,41 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["default", "wino_forced"])
+def wino_mode(request, gpu_device):
+    """"wino_forced": every (1,3,3) stride-1 layer with Cin % 32 == 0 and 64 | Cout <= 128 goes through the
+    Winograd kernels whatever its size (avid_wino_configure), so that the small reference-generated fixtures
+    traverse them; the test asserts through ``wino_launches`` that they did."""
+    from avid_hip import ops
+    if request.param == "wino_forced":
+        ops.wino_configure(1, 1, 128)
+    yield request.param
+    ops.wino_configure(-1, -1, -1)
+
+
+class _KernelLog:
+    """HIP-event timers of the library used as a launch log: which kernels ran inside the ``with`` block."""
+
+    def __enter__(self):
+        from avid_hip import lib
+        self.lib = lib
+        lib.timing_enable(True)
+        self.report = {}
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        torch.cuda.synchronize()
+        self.report = self.lib.timing_report()
+        self.lib.timing_enable(False)
+        return False
+
+    def launches(self, prefix):
+        return sum(v["launches"] for k, v in self.report.items() if k.startswith(prefix))
+
+
+@pytest.fixture
+def kernel_log():
+    return _KernelLog

@@ -208,3 +208,74 @@ def test_sync_buffers_broadcasts_rank0_running_statistics_in_one_flat_buffer():
     for k in range(2):
         assert (a0[k] == b0[k]).all() and (a1[k] == b0[k]).all()          # rank 0's values everywhere after
     assert int(a0[2]) == int(a1[2]) == 3                                  # the step counter advances identically anyway
+
+
+def _late_bucket_job(rank, world):
+    """AVID_DEFER_DIST=1 (late buckets): every bucket's collective is issued from finish(), complete ones included."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avid-cma_amd"))
+    from avid_hip.parallel import FlatParams, GradBuckets
+    out = {}
+    for mode in ("0", "1"):
+        os.environ["AVID_DEFER_DIST"] = mode
+        m = _tiny_model()
+        flat = FlatParams(m)
+        buckets = GradBuckets(flat, bucket_bytes=256)
+        torch.manual_seed(100 + rank)
+        x = torch.randn(5, 8)
+        grads = []
+        for _ in range(2):
+            flat.zero_grad()
+            m(x).pow(2).sum().backward()
+            launched_in_backward = sum(buckets.launched)
+            buckets.finish()
+            grads.append(flat.grad.clone().numpy())
+        out[mode] = (grads, launched_in_backward, len(buckets.bounds))
+    os.environ.pop("AVID_DEFER_DIST")
+    return out
+
+
+def test_late_bucket_mode_still_allreduces_every_bucket():
+    """with AVID_DEFER_DIST=1 a bucket that completed during backward was never all-reduced
+    (finish() only launched incomplete ones).  Late mode must give exactly the default mode's summed gradients, on
+    both steps, with no collective issued before finish()."""
+    res = run2(_late_bucket_job)
+    for rank in range(2):
+        (g_early, n_early, nb), (g_late, n_late, _) = res[rank]["0"], res[rank]["1"]
+        assert n_early == nb and n_late == 0                     # early: all fired from the hooks; late: none did
+        for a, b in zip(g_early, g_late):
+            assert (a == b).all()
+    assert (res[0]["1"][0][0] == res[1]["1"][0][0]).all()        # and the ranks agree
+    assert not (res[0]["1"][0][0] == 0).all()
+
+
+def test_optimizer_state_dict_indexes_all_parameters_like_torch_adam():
+    """utils/main_utils.py:250-261 builds Adam over model.parameters(): state_dict indices count FROZEN parameters too
+    (they have an index in param_groups but no state).  TrainStep.state_dict must use the same numbering, and a
+    torch.optim.Adam state_dict of the same model must load."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avid-cma_amd"))
+    from avid_hip.parallel import TrainStep
+    m = _tiny_model()
+    m[2].weight.requires_grad_(False)                            # index 2 of 6 is frozen
+    eng = TrainStep(m, criterion=None)
+    eng.t = 3
+    eng.m.copy_(torch.arange(eng.m.numel(), dtype=torch.float32))
+    sd = eng.state_dict()
+    assert sd["param_groups"][0]["params"] == [0, 1, 2, 3, 4, 5]
+    assert sorted(sd["state"]) == [0, 1, 3, 4, 5]
+    params = list(m.parameters())
+    for k in sd["state"]:
+        assert sd["state"][k]["exp_avg"].shape == params[k].shape
+    ref = torch.optim.Adam(m.parameters(), lr=2e-4, weight_decay=1e-5)
+    for p in params:
+        p.grad = torch.ones_like(p) if p.requires_grad else None
+    ref.step()
+    rsd = ref.state_dict()
+    assert sorted(rsd["state"]) == sorted(sd["state"]) and rsd["param_groups"][0]["params"] == sd["param_groups"][0]["params"]
+    eng2 = TrainStep(m, criterion=None)
+    eng2.load_state_dict(rsd)
+    for k, st in rsd["state"].items():
+        i = {id(p): j for j, p in enumerate(eng2.flat.params)}[id(params[k])]
+        assert torch.equal(eng2._slice(eng2.m, i), st["exp_avg"]) and torch.equal(eng2._slice(eng2.v, i), st["exp_avg_sq"])
+    assert eng2.t == 1

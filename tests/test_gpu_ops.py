@@ -54,11 +54,16 @@ CONV_CASES = [
     ("dead_taps_T1", 512, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (16, 1, 4, 4)),
     ("dead_taps_T2_s2", 128, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0), (8, 2, 4, 4)),
     ("dead_taps_333_T1", 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (4, 1, 6, 7)),
+    # Winograd F(2x2,3x3) with Cr = Cn = 128 (two 64-column blocks x four reduction chunks): the benchmark's conv3x
+    # layer (25088 pixels at batch 32; models/network_blocks.py:35,40) and an odd-extent sibling (ragged tiles)
+    ("wino_128x128", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (32, 4, 14, 14)),
+    ("wino_128x128_odd", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (9, 4, 27, 29)),
 ]
+WINO_CASES = {"big_128x64", "big_unbalanced", "wino_128x128", "wino_128x128_odd"}
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_fwd_dgrad_wgrad(case, gpu_device):
+def test_conv_fwd_dgrad_wgrad(case, gpu_device, kernel_log):
     """fp32 MFMA implicit GEMM vs float64 F.conv3d.  Tolerance: 2e-5 of the output scale
     (fp32 products/accumulation over K <= 2304; the reference itself is fp32)."""
     from avid_hip import ops
@@ -75,25 +80,31 @@ def test_conv_fwd_dgrad_wgrad(case, gpu_device):
     wd.copy_(w)
     wd = wd.to(gpu_device).requires_grad_(True)
     assert ops.weight_layout_ok(wd)
-    y = ops.conv_cl(xd, wd, stride, pad)
-    y.backward(cl(gy).to(gpu_device))
+    with kernel_log() as log:
+        y = ops.conv_cl(xd, wd, stride, pad)
+        y.backward(cl(gy).to(gpu_device))
     assert relerr(ncdhw(y.detach()), yr.detach()) < 2e-5
     assert relerr(ncdhw(xd.grad), xr.grad) < 2e-5
     assert relerr(wd.grad, wr.grad) < 5e-5
     assert wd.grad.stride() == wd.stride()
+    if name in WINO_CASES:          # forward and input gradient really took the Winograd kernel
+        assert log.launches("wino_kernel") == 2, log.report.keys()
+    else:
+        assert log.launches("wino_kernel") == 0
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 9, 11), (4, 8, 48, 48), (5, 7, 45, 47), (64, 1, 4, 4)])
 @pytest.mark.parametrize("cout", [64, 128])
-def test_conv_bn_partials(shape, cout, gpu_device):
+@pytest.mark.parametrize("cin", [64, 128])
+def test_conv_bn_partials(shape, cout, cin, gpu_device):
     """BatchNorm partial sums written by the conv epilogue / the split-K reduce: their column totals must be
     the column sums and sums of squares of the conv output (fp32 partials, 1e-5 of the scale), for whole
     tiles, ragged tails and K-split layers alike; with a fused residual add the statistics are of the sum."""
     from avid_hip import ops
     B, Ti, Hi, Wi = shape
-    x = T(detgen.det_normalish(f"cbp:{shape}:x", (B, Ti, Hi, Wi, 64))).to(gpu_device)
-    w = ops.make_weight(cout, 64, 1, 3, 3)
-    w.copy_(T(detgen.det_param(f"cbp:{cout}:w.weight", (cout, 64, 1, 3, 3))))
+    x = T(detgen.det_normalish(f"cbp:{shape}:{cin}:x", (B, Ti, Hi, Wi, cin))).to(gpu_device)
+    w = ops.make_weight(cout, cin, 1, 3, 3)
+    w.copy_(T(detgen.det_param(f"cbp:{cout}:{cin}:w.weight", (cout, cin, 1, 3, 3))))
     w = w.to(gpu_device)
     add = T(detgen.det_uniform(f"cbp:{shape}:{cout}:add", (B, Ti, Hi, Wi, cout))).to(gpu_device)
     for addend in (None, add):

@@ -108,7 +108,7 @@ def _train_job(rank, world, out):
     res = {"bank_after_init": crit.nce_average.view1_mem.clone().cpu(),      # randn on each rank, then rank 0's
            "overlap_default": bool(m.overlap_towers)}
     _set_banks(crit, rank)
-    eng = TrainStep(m, crit, bucket_bytes=4 << 20)
+    eng = TrainStep(m, crit, bucket_bytes=4 << 20, broadcast_buffers="lazy")     # (per-rank statistics stay visible)
     res["overlap_engine"] = bool(m.overlap_towers)
     res["params_after_init"] = eng.flat.flat.clone().cpu()
     res["nbuckets"] = len(eng.buckets.bounds)
