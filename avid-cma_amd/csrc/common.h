@@ -62,6 +62,12 @@ int wino_grid(const avid_conv_desc* d, int mode);
 int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* w, float* dst, const float* addend,
               float* stats, const avid_bn_bwd_fuse* bn, void* ws, hipStream_t s);
 
+// Winograd weight gradient of the same layers: slabs [nsplit][Cout][9][Cin] in ws (nsplit == 1: dw itself)
+bool wino_wgrad_supported(const avid_conv_desc* d);
+size_t wino_wgrad_ws_bytes(const avid_conv_desc* d);
+int wino_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, int* nsplit_out,
+               hipStream_t s);
+
 // 64-lane wave reductions (DPP/ds_swizzle chosen by the compiler from __shfl_xor).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -2777,6 +2777,7 @@ extern "C" size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d) {
   WgradPlan pl = wgrad_plan(&tr.d);
   size_t nb = sizeof(float) * (size_t)pl.nsplit * d->Cout * tr.d.kt * d->kh * d->kw * d->Cin;
   if (stem_wgrad_supported(d) && stem_wgrad_ws_bytes(d) > nb) nb = stem_wgrad_ws_bytes(d);
+  if (wino_wgrad_supported(d) && wino_wgrad_ws_bytes(d) > nb) nb = wino_wgrad_ws_bytes(d);
   return nb;
 }
 
@@ -2787,6 +2788,17 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
   AVID_REQUIRE(x && dy && dw, AVID_E_BADARG, "conv_wgrad: null pointer");
   if (stem_wgrad_supported(d) && ws && ws_bytes >= stem_wgrad_ws_bytes(d))
     return stem_wgrad(d, x, dy, dw, ws, (hipStream_t)stream);
+  if (wino_wgrad_supported(d) && ws && ws_bytes >= wino_wgrad_ws_bytes(d)) {
+    hipStream_t s = (hipStream_t)stream;
+    int nsplit = 1;
+    rc = wino_wgrad(d, x, dy, dw, ws, &nsplit, s);
+    if (rc || nsplit == 1) return rc;
+    const long long n = (long long)d->Cout * 9 * d->Cin;
+    ScopedTimer t(s, "wgrad_reduce_kernel", 0.0, 4.0 * n * (nsplit + 1));
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(n, 128)), dim3(256), 0, s,
+                       static_cast<const float*>(ws), dw, n, nsplit);
+    return check_launch("wgrad_reduce");
+  }
   Trim tr = trim_taps(d);
   if (tr.on && !(ws && ws_bytes >= avid_conv_wgrad_workspace_bytes(d))) tr = Trim{*d, 0, d->kt, false};   // no scratch
   const avid_conv_desc* dfull = d;
@@ -2902,7 +2914,9 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
     }
   } else {
     WgradPlan pl = wgrad_plan(&tr.d);
-    if (!pl.vec)
+    if (wino_wgrad_supported(d))
+      snprintf(buf, len, "wino_wgrad_kernel");
+    else if (!pl.vec)
       snprintf(buf, len, stem_wgrad_supported(d) ? "stem_wgrad_kernel splits=%d" : "wgrad_gather_kernel splits=%d", pl.nsplit);
     else
       snprintf(buf, len, "wgrad_tab_kernel<%d,%d> splits=%d", pl.NB, pl.KC, pl.nsplit);

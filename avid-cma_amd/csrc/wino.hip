@@ -298,6 +298,267 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers through the Winograd identity (backward of models/network_blocks.py:35,40):
+//     dU[xi][n][c] = sum over tiles of (A dY A^T)[xi][tile][n] * (B^T d B)[xi][tile][c],     dw = G^T dU G
+// 16 instead of 36 multiply-adds per (tile, n, c) — the 2.25x of the forward.  One workgroup = 8 waves = one
+// (64 output channels) x (64 input channels) block of dw for a contiguous range of tiles; GEMM-K is the tile index.
+//   per chunk of 8 tiles: the threads of waves 0-3 (tile = tid >> 5, channel pair = tid & 31) load a 4x4 input patch as
+//   8-byte vectors and transform it (V = B^T d B), those of waves 4-7 a 2x2 gradient tile (dM = A dY A^T); out-of-frame
+//   taps / pixels read 0.  LDS holds two stages of V | dM as [tile][xi][64 channels] (131 KB: one workgroup per CU,
+//   two waves per SIMD).  While chunk k is multiplied, the registers holding chunk k + 1 are transformed and written
+//   to the other stage and the loads of chunk k + 2 are issued, all inside the MFMA stream: one barrier per chunk.
+//   products: wave w owns the quadrant (n half, c half) = w & 3 of the block for the transform rows i in {2e, 2e+1},
+//   e = w >> 2, all four columns j: 8 accumulators of 32 x 32; both MFMA operands are ds_read_b32 fragments
+//   (lane = channel, half-wave = tile of the k pair).
+//   epilogue: G^T . G in registers — columns j inside a wave, rows i as two partial sums; the e = 1 waves hand theirs
+//   over through LDS, the e = 0 waves write the block as dw[n][3][3][c] into this split's slab; wgrad_reduce_kernel
+//   (csrc/conv.hip) sums the slabs in fixed order.
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+constexpr int WW_TK = 8;                               // tiles per LDS stage (GEMM-K of a stage)
+constexpr int WW_HALF = WW_TK * 16 * 64;               // floats of V (or dM) in one stage: [tile][xi][64 channels]
+constexpr int WW_STAGE = 2 * WW_HALF;                  // V | dM
+constexpr int WW_LDS_FLOATS = 2 * WW_STAGE;            // two stages: 131072 B
+
+struct WinoWgradArgs {
+  const float* __restrict__ x;
+  const float* __restrict__ dy;
+  float* __restrict__ out;              // [nsplit][Cn][9][Cr]
+  int F, H, W, TH, TW, Cr, Cn, ncb;     // Cr = Cin, Cn = Cout, ncb = Cr / 64
+  int pairs;                            // (Cn / 64) * ncb blocks of dw
+  int nchunks, cps;                     // chunks of WW_TK tiles; chunks per split
+  long long ntiles;
+  unsigned mgTPF, mgTW;                 // multiply-shift division by TH * TW and TW
+  int shTPF, shTW;
+};
+
+// Packed fp32 adds as inline assembly: every VALU instruction of a wave costs ~2.2 ns of its SIMD's MFMA time
+// (tools/mfma_shadow: the fp32 MFMA runs at the vector rate, on the same lanes), a packed add costs the same as a
+// scalar one — and the compiler UNPACKS v_pk_add_f32 wherever it sits behind an MFMA (two instructions for one).
+__device__ __forceinline__ floatx2 pk_add(floatx2 a, floatx2 b) {
+  floatx2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
+  floatx2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// ROLE 0 (waves 0-3): input-transform threads, V = B^T d B of (tile, channel pair); ROLE 1 (waves 4-7): gradient-
+// transform threads, dM' = |A| dY |A|^T of (tile, output-channel pair) — the signs of A's last row (A[3] = [0,-1]) are
+// applied once, in the epilogue (dU[i][j] = s_i s_j dU'[i][j], s = [1,1,1,-1]).  Every wave multiplies.
+// Measured alternatives (conv2x, 401408 pixels; this form: 152 us): 16-tile single stage with the transform between
+// two barriers 173 us; this pipeline with compiler-scheduled (unpacked) adds 158 us; one wave per SIMD holding all 16
+// transform points of a quadrant (no exchange in the epilogue) 168 us; the barrier moved behind k-step 2 with the next
+// chunk's first fragments fetched under k-step 3: 168 us.
+template <int ROLE>
+__device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& p, float* sm, floatx16 (&acc)[8], int cbk, int nbk,
+                                                int ch0, int ch1) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int H = p.H, W = p.W;
+  const int C = ROLE == 0 ? p.Cr : p.Cn;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(ROLE == 0 ? p.x : p.dy), 0, (int)((long long)p.F * H * W * C * 4), 0x00020000);
+  const int tl = (tid >> 5) & 7, c2 = (tid & 31) * 2;           // this thread's tile of a chunk and its channel pair
+  const unsigned chan_b = (unsigned)((ROLE == 0 ? cbk : nbk) * 64 + c2) * 4u;
+  const int px_b = C * 4;
+  const unsigned row_b = (unsigned)W * (unsigned)px_b;
+  constexpr int NP = ROLE == 0 ? 4 : 2;                         // patch extent: 4x4 input patch / 2x2 gradient tile
+  floatx2 raw[NP][NP];                                          // the chunk after the one in LDS
+
+  auto load_chunk = [&](int ch) {
+    const long long t = (long long)ch * WW_TK + tl;
+    const bool t_ok = ch < ch1 && t < p.ntiles;
+    const unsigned tt = t_ok ? (unsigned)t : 0u;
+    const unsigned f = (unsigned)(((unsigned long long)tt * p.mgTPF) >> p.shTPF);
+    const unsigned rem = tt - f * (unsigned)(p.TH * p.TW);
+    const unsigned ti = (unsigned)(((unsigned long long)rem * p.mgTW) >> p.shTW);
+    const unsigned tj = rem - ti * (unsigned)p.TW;
+    // pixel (2 ti, 2 tj) — element (1, 1) of the input patch, (0, 0) of the gradient tile — is always inside the frame.
+    // The range check of a buffer load covers the vector offset only, so every offset is based there: the columns to
+    // its right ride in the scalar offset, column 0 / row 0 of the patch lie one pixel / row below it and are masked
+    // when they leave the frame.
+    const unsigned o11 = (unsigned)(((int)f * H + 2 * (int)ti) * W + 2 * (int)tj) * (unsigned)px_b + chan_b;
+    const int y1 = 2 * (int)ti, x1 = 2 * (int)tj;
+    const bool oky4[4] = {t_ok && ti > 0, t_ok, t_ok && y1 + 1 < H, t_ok && y1 + 2 < H};
+    const bool okx4[4] = {tj > 0, true, x1 + 1 < W, x1 + 2 < W};
+    constexpr int O = ROLE == 0 ? 0 : 1;                        // patch index of local index 0
+#pragma unroll
+    for (int a = 0; a < NP; ++a) {
+      const unsigned rowoff = o11 + (unsigned)(a + O - 1) * row_b;
+#pragma unroll
+      for (int b = 0; b < NP; ++b) {
+        const int pb = b + O;                                    // patch column 0..3
+        const unsigned vo = pb == 0 ? rowoff - (unsigned)px_b : rowoff;
+        raw[a][b] = __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                    rs, (oky4[a + O] && okx4[pb]) ? vo : 0x80000000u, pb == 0 ? 0 : (pb - 1) * px_b, 0));
+      }
+    }
+  };
+  floatx2 w_[4][NP];
+  auto col = [&](int b) {     // one column of the patch through the left factor
+    if (ROLE == 0) {          // B^T d:  rows of B^T = [1,0,-1,0], [0,1,1,0], [0,-1,1,0], [0,1,0,-1]
+      w_[0][b] = pk_sub(raw[0][b], raw[2 % NP][b]);
+      w_[1][b] = pk_add(raw[1][b], raw[2 % NP][b]);
+      w_[2][b] = pk_sub(raw[2 % NP][b], raw[1][b]);
+      w_[3][b] = pk_sub(raw[1][b], raw[3 % NP][b]);
+    } else {                  // |A| dY:  |A| = [[1,0],[1,1],[1,-1],[0,1]]
+      w_[0][b] = raw[0][b];
+      w_[1][b] = pk_add(raw[0][b], raw[1][b]);
+      w_[2][b] = pk_sub(raw[0][b], raw[1][b]);
+      w_[3][b] = raw[1][b];
+    }
+  };
+  auto row_store = [&](float* stage, int a) {     // row a through the right factor -> LDS stage ([tile][xi][64])
+    float* dst = stage + (ROLE == 0 ? 0 : WW_HALF) + (tl * 16 + a * 4) * 64 + c2;
+    floatx2 o0, o1, o2, o3;
+    if (ROLE == 0) {
+      o0 = pk_sub(w_[a][0], w_[a][2 % NP]); o1 = pk_add(w_[a][1], w_[a][2 % NP]);
+      o2 = pk_sub(w_[a][2 % NP], w_[a][1]); o3 = pk_sub(w_[a][1], w_[a][3 % NP]);
+    } else {
+      o0 = w_[a][0]; o1 = pk_add(w_[a][0], w_[a][1]); o2 = pk_sub(w_[a][0], w_[a][1]); o3 = w_[a][1];
+    }
+    *reinterpret_cast<floatx2*>(dst + 0 * 64) = o0;
+    *reinterpret_cast<floatx2*>(dst + 1 * 64) = o1;
+    *reinterpret_cast<floatx2*>(dst + 2 * 64) = o2;
+    *reinterpret_cast<floatx2*>(dst + 3 * 64) = o3;
+  };
+
+  const int quad = wave & 3, e = wave >> 2, nh = quad >> 1, chh = quad & 1;
+  // fragment bases inside a stage: dM (A operand, lane = output channel) and V (B operand, lane = input channel)
+  const int a_frag = WW_HALF + (h * 16 + e * 8) * 64 + nh * 32 + l31;
+  const int b_frag = (h * 16 + e * 8) * 64 + chh * 32 + l31;
+  load_chunk(ch0);
+#pragma unroll
+  for (int b = 0; b < NP; ++b) col(b);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) row_store(sm, a);
+  load_chunk(ch0 + 1);
+  __syncthreads();
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const int u = (ch - ch0) & 1;
+    const float* cur = sm + u * WW_STAGE;
+    float* nxt = sm + (u ^ 1) * WW_STAGE;
+    const float* Ab = cur + a_frag;
+    const float* Bb = cur + b_frag;
+    float af[2][8], bf[2][8];
+    auto frag = [&](int kk, int x8) {
+      af[kk & 1][x8] = Ab[(kk * 2 * 16 + x8) * 64];
+      bf[kk & 1][x8] = Bb[(kk * 2 * 16 + x8) * 64];
+    };
+#pragma unroll
+    for (int x8 = 0; x8 < 8; ++x8) frag(0, x8);
+    // k-step 0: the registers (chunk ch + 1) are transformed and written to the other stage, one slice per MFMA
+#pragma unroll
+    for (int x8 = 0; x8 < 8; ++x8) {
+      frag(1, x8);
+      acc[x8] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][x8], bf[0][x8], acc[x8], 0, 0, 0);
+      if (x8 < 4) {
+        if (x8 < NP) col(x8);
+      } else {
+        row_store(nxt, x8 - 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // k-step 1: the loads of chunk ch + 2 are issued (address arithmetic and VMEM spread over the MFMAs)
+#pragma unroll
+    for (int x8 = 0; x8 < 8; ++x8) frag(2, x8);
+    load_chunk(ch + 2);
+#pragma unroll
+    for (int x8 = 0; x8 < 8; ++x8)
+      acc[x8] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][x8], bf[1][x8], acc[x8], 0, 0, 0);
+#pragma unroll
+    for (int x8 = 0; x8 < 8; ++x8) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                     // DS read
+      __builtin_amdgcn_sched_group_barrier(0x002, ROLE == 0 ? 6 : 4, 0);     // VALU (address arithmetic)
+      __builtin_amdgcn_sched_group_barrier(0x020, ROLE == 0 ? 2 : 1, 0);     // VMEM read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 2; kk < WW_TK / 2; ++kk) {
+#pragma unroll
+      for (int x8 = 0; x8 < 8; ++x8) {
+        if (kk + 1 < WW_TK / 2) frag(kk + 1, x8);
+        acc[x8] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][x8], bf[kk & 1][x8], acc[x8], 0, 0, 0);
+      }
+    }
+    __syncthreads();       // the other stage is written; everyone is done reading this one
+  }
+}
+
+__global__ __launch_bounds__(512) void wino_wgrad_kernel(const WinoWgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int Cr = p.Cr, Cn = p.Cn;
+  const int pair = (int)(blockIdx.x % p.pairs), split = (int)(blockIdx.x / p.pairs);
+  const int cbk = pair % p.ncb, nbk = pair / p.ncb;
+  const int ch0 = split * p.cps, ch1 = min(ch0 + p.cps, p.nchunks);
+  const int quad = wave & 3, e = wave >> 2, nh = quad >> 1, chh = quad & 1;
+  floatx16 acc[8];
+#pragma unroll
+  for (int x8 = 0; x8 < 8; ++x8)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x8][r] = 0.f;
+  if (wave < 4)
+    wino_wgrad_body<0>(p, sm, acc, cbk, nbk, ch0, ch1);
+  else
+    wino_wgrad_body<1>(p, sm, acc, cbk, nbk, ch0, ch1);
+
+  // ---- dw block = G^T dU G.  Columns (j) in registers: T[i][b],  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+  // (the accumulators hold dU' = s_i s_j dU, s = [1,1,1,-1]: column 3 and, for the e = 1 waves, row 3 change sign)
+  floatx16 T[2][3];
+#pragma unroll
+  for (int il = 0; il < 2; ++il) {
+    const float si = (e == 1 && il == 1) ? -1.f : 1.f;
+    const floatx16 d0 = si * acc[il * 4 + 0], d1 = si * acc[il * 4 + 1], d2 = si * acc[il * 4 + 2], d3 = -si * acc[il * 4 + 3];
+    const floatx16 hs = 0.5f * (d1 + d2);
+    T[il][0] = d0 + hs;
+    T[il][1] = 0.5f * (d1 - d2);
+    T[il][2] = hs + d3;
+  }
+  // rows (i): dw[0][b] = T0 + .5 T1 + .5 T2,  dw[1][b] = .5 T1 - .5 T2,  dw[2][b] = .5 T1 + .5 T2 + T3.
+  // The e = 1 waves (rows 2, 3) hand X[b] = .5 T2[b] and Y[b] = .5 T2[b] + T3[b] to their e = 0 partner through LDS.
+  float* ex = sm;                                 // ex[quad][plane 6][r / 4][lane][4]
+  auto ex_at = [&](int plane, int r4) { return ex + ((((quad * 6 + plane) * 4 + r4) * 64 + lane) << 2); };
+  if (e == 1) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const floatx16 X = 0.5f * T[0][b], Y = X + T[1][b];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        *reinterpret_cast<floatx4*>(ex_at(b, r4)) = floatx4{X[4 * r4], X[4 * r4 + 1], X[4 * r4 + 2], X[4 * r4 + 3]};
+        *reinterpret_cast<floatx4*>(ex_at(3 + b, r4)) = floatx4{Y[4 * r4], Y[4 * r4 + 1], Y[4 * r4 + 2], Y[4 * r4 + 3]};
+      }
+    }
+  }
+  __syncthreads();
+  if (e == 0) {
+    float* o = p.out + (long long)split * Cn * 9 * Cr;
+    const int c = cbk * 64 + chh * 32 + l31;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const floatx16 hT1 = 0.5f * T[1][b];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const floatx4 X = *reinterpret_cast<const floatx4*>(ex_at(b, r4));
+        const floatx4 Y = *reinterpret_cast<const floatx4*>(ex_at(3 + b, r4));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * r4 + q;
+          const int n = nbk * 64 + nh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float* row = o + ((long long)n * 9 + b) * Cr + c;
+          row[0] = T[0][b][r] + hT1[r] + X[q];                 // tap (a = 0, b)
+          row[3 * Cr] = hT1[r] - X[q];                         // tap (1, b)
+          row[6 * Cr] = hT1[r] + Y[q];                         // tap (2, b)
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 static int wino_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -318,8 +579,8 @@ static int wino_cus() {      // per device: a process may touch more than one
 
 // The switches of this path: AVID_WINO / AVID_WINO_MIN_M / AVID_WINO_MAXC from the environment, unless
 // avid_wino_configure() (include/avid_hip.h) has overridden them — tests force small fixtures through the kernel.
-struct WinoCfg { int on; long long min_m; int max_c; bool loaded; };
-static WinoCfg g_wino_cfg = {1, 24576, 128, false};
+struct WinoCfg { int on; long long min_m; int max_c; bool loaded; int wg_on; long long wg_min_m; int wg_max_c; };
+static WinoCfg g_wino_cfg = {1, 24576, 128, false, 1, 24576, 128};
 static int g_wino_override[3] = {-1, -1, -1};
 
 static const WinoCfg& wino_cfg() {
@@ -329,6 +590,10 @@ static const WinoCfg& wino_cfg() {
     // (25088 pixels: 32 vs 33 us forward, 31 vs 39 us input gradient; 16000: 33.5 vs 28.6)
     c.min_m = g_wino_override[1] >= 0 ? g_wino_override[1] : wino_env("AVID_WINO_MIN_M", 24576);
     c.max_c = g_wino_override[2] >= 0 ? g_wino_override[2] : wino_env("AVID_WINO_MAXC", 128);
+    // the weight-gradient kernel follows the same switches unless its own are set
+    c.wg_on = c.on && wino_env("AVID_WINO_WGRAD", 1);
+    c.wg_min_m = g_wino_override[1] >= 0 ? g_wino_override[1] : wino_env("AVID_WINO_WGRAD_MIN_M", (int)c.min_m);
+    c.wg_max_c = g_wino_override[2] >= 0 ? g_wino_override[2] : wino_env("AVID_WINO_WGRAD_MAXC", c.max_c);
     c.loaded = true;
   }
   return c;
@@ -426,6 +691,80 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
     default: set_error("wino_conv: unsupported epilogue %d", epi); return AVID_E_UNSUPPORTED;
   }
   return check_launch("wino_conv");
+}
+
+// ---- weight gradient
+bool wino_wgrad_supported(const avid_conv_desc* d) {
+  const WinoCfg& c = wino_cfg();
+  if (!c.wg_on || d->x_channel_first) return false;
+  if (d->kt != 1 || d->kh != 3 || d->kw != 3 || d->st != 1 || d->sh != 1 || d->sw != 1) return false;
+  if (d->pt != 0 || d->ph != 1 || d->pw != 1) return false;
+  if (d->Cin % 64 || d->Cout % 64 || d->Cin > c.wg_max_c || d->Cout > c.wg_max_c) return false;
+  const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
+  if (M < c.wg_min_m) return false;
+  return M * (d->Cin > d->Cout ? d->Cin : d->Cout) * 4 < (1ll << 31);
+}
+
+struct WinoWgradPlan { int pairs, nchunks, cps, nsplit; long long ntiles; };
+
+static WinoWgradPlan wino_wgrad_plan(const avid_conv_desc* d) {
+  WinoWgradPlan pl;
+  const long long TH = (d->Hi + 1) / 2, TW = (d->Wi + 1) / 2;
+  pl.ntiles = (long long)d->B * d->Ti * TH * TW;
+  pl.nchunks = (int)ceil_div(pl.ntiles, WW_TK);
+  pl.pairs = (d->Cin / 64) * (d->Cout / 64);
+  int want = wino_cus() / pl.pairs;            // one workgroup per CU (139 KB of LDS each)
+  if (want < 1) want = 1;
+  if (want > pl.nchunks) want = pl.nchunks;
+  pl.cps = (int)ceil_div(pl.nchunks, want);
+  pl.nsplit = (int)ceil_div(pl.nchunks, pl.cps);
+  return pl;
+}
+
+size_t wino_wgrad_ws_bytes(const avid_conv_desc* d) {
+  const WinoWgradPlan pl = wino_wgrad_plan(d);
+  return sizeof(float) * (size_t)pl.nsplit * d->Cout * 9 * d->Cin;
+}
+
+static void wino_magic(int dv, unsigned& magic, int& shift) {     // n / dv == (n * magic) >> shift for n < 2^31
+  int l = 0;
+  while ((1ll << l) < dv) ++l;
+  shift = 31 + l;
+  magic = (unsigned)(((1ull << shift) + (unsigned)dv - 1) / (unsigned)dv);
+}
+
+// slabs[nsplit][Cout][9][Cin] -> ws; *nsplit_out tells the caller how many to reduce (1: written straight into dw)
+int wino_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, int* nsplit_out,
+               hipStream_t s) {
+  const WinoWgradPlan pl = wino_wgrad_plan(d);
+  WinoWgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.dy = dy;
+  a.out = pl.nsplit == 1 ? dw : static_cast<float*>(ws);
+  a.F = d->B * d->Ti; a.H = d->Hi; a.W = d->Wi;
+  a.TH = (d->Hi + 1) / 2; a.TW = (d->Wi + 1) / 2;
+  a.Cr = d->Cin; a.Cn = d->Cout; a.ncb = d->Cin / 64;
+  a.pairs = pl.pairs; a.nchunks = pl.nchunks; a.cps = pl.cps; a.ntiles = pl.ntiles;
+  wino_magic(a.TH * a.TW, a.mgTPF, a.shTPF);
+  wino_magic(a.TW, a.mgTW, a.shTW);
+  const size_t lds = sizeof(float) * WW_LDS_FLOATS;
+  static bool set[64] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    set[dev] = true;
+  }
+  const double M = (double)d->B * d->Ti * d->Hi * d->Wi;
+  {
+    // flops: the multiply-adds the MFMAs execute (16 per tile, channel pair); bytes: x + dy + dw once
+    ScopedTimer t(s, "wino_wgrad_kernel", 2.0 * 16.0 * (double)pl.ntiles * d->Cin * d->Cout,
+                  4.0 * (M * (d->Cin + d->Cout) + 9.0 * d->Cin * d->Cout));
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3((unsigned)(pl.pairs * pl.nsplit)), dim3(512), lds, s, a);
+  }
+  *nsplit_out = pl.nsplit;
+  return check_launch("wino_wgrad");
 }
 
 }  // namespace avid

@@ -88,9 +88,9 @@ def test_conv_fwd_dgrad_wgrad(case, gpu_device, kernel_log):
     assert relerr(wd.grad, wr.grad) < 5e-5
     assert wd.grad.stride() == wd.stride()
     if name in WINO_CASES:          # forward and input gradient really took the Winograd kernel
-        assert log.launches("wino_kernel") == 2, log.report.keys()
+        assert log.launches("wino_kernel") == 2 and log.launches("wino_wgrad_kernel") == 1, log.report.keys()
     else:
-        assert log.launches("wino_kernel") == 0
+        assert log.launches("wino_kernel") == 0 and log.launches("wino_wgrad_kernel") == 0
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 9, 11), (4, 8, 48, 48), (5, 7, 45, 47), (64, 1, 4, 4)])

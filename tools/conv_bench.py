@@ -97,6 +97,8 @@ for name, cin, cout, k, st, pd, (T, H, W) in L:
     d_us += wd_us; dn += wdn
     dr_us, _ = pick(res["bwd"], "splitk"); dt_us, _ = pick(res["bwd"], "weight_tr")
     w_us, wn = pick(res["bwd"], "wgrad_tab")
+    ww_us, wwn = pick(res["bwd"], "wino_wgrad")
+    w_us += ww_us; wn += wwn
     wr_us, _ = pick(res["bwd"], "wgrad_reduce")
     print(f"{name:10s} {M:8d} {K:5d} {cout:4d} | {f_us+fr_us:8.1f} {fl/(f_us+fr_us)/1e6:6.1f} | {d_us+dr_us+dt_us:8.1f} {fl/(d_us+dr_us+dt_us)/1e6:6.1f} | "
           f"{w_us+wr_us:8.1f} {fl/(w_us+wr_us)/1e6:6.1f}  {fn+dn+wn} (+red {fr_us:.0f}/{dr_us+dt_us:.0f}/{wr_us:.0f})")

@@ -32,6 +32,12 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
           if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(1.0001f));
           if (KIND == 1) asm volatile("s_mul_i32 %0, %0, %1" : "+s"(sa) : "s"(sb));
           if (KIND == 2) asm volatile("ds_read_b32 %0, %1" : "=v"(v[i]) : "v"((lane * 4 + i * 256) & 8191));
+          if (KIND == 4) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[i]) : "v"(3));
+          if (KIND == 5) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(3.f));
+          if (KIND == 6) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*reinterpret_cast<float __attribute__((ext_vector_type(2)))*>(&v[(i & 7) * 2])) : "v"(*reinterpret_cast<float __attribute__((ext_vector_type(2)))*>(&v[((i + 1) & 7) * 2])));
+          if (KIND == 7) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[i]) : "v"(1.5f));
+          if (KIND == 8) asm volatile("ds_write_b64 %0, %1" : : "v"((lane * 8 + i * 512) & 8191), "v"(*reinterpret_cast<float __attribute__((ext_vector_type(2)))*>(&v[(i & 7) * 2])));
+          if (KIND == 9) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "v"(x));
           if (KIND == 3) asm volatile("ds_read_b128 %0, %1" : "=v"(*reinterpret_cast<float __attribute__((ext_vector_type(4)))*>(&v[(i & 3) * 4])) : "v"((lane * 16 + i * 1024) & 8191));
         }
       }
@@ -66,5 +72,11 @@ int main() {
   row<1, false>("s_mul_i32", out);  row<1, true>("s_mul_i32", out);
   row<2, false>("ds_read_b32", out); row<2, true>("ds_read_b32", out);
   row<3, false>("ds_read_b128", out); row<3, true>("ds_read_b128", out);
+  row<4, false>("v_add_u32", out); row<4, true>("v_add_u32", out);
+  row<5, false>("v_cndmask_b32", out); row<5, true>("v_cndmask_b32", out);
+  row<6, false>("v_pk_add_f32", out); row<6, true>("v_pk_add_f32", out);
+  row<7, false>("v_add_f32", out); row<7, true>("v_add_f32", out);
+  row<8, false>("ds_write_b64", out); row<8, true>("ds_write_b64", out);
+  row<9, false>("v_mov_b32", out); row<9, true>("v_mov_b32", out);
   return 0;
 }
