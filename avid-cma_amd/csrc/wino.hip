@@ -88,6 +88,31 @@ extern "C" int avid_debug_wino_trace(long long* host) {
 #else
 #define W_STAMP(i) do {} while (0)
 #endif
+// Packed fp32 adds as inline assembly: every VALU instruction of a wave costs ~2.2 ns of its SIMD's MFMA time
+// (tools/mfma_shadow: the fp32 MFMA runs at the vector rate, on the same lanes), a packed add costs the same as a
+// scalar one — and the compiler UNPACKS v_pk_add_f32 wherever it sits behind an MFMA (two instructions for one).
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ floatx2 pk_add(floatx2 a, floatx2 b) {
+  floatx2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
+  floatx2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ floatx4 pk4_add(floatx4 a, floatx4 b) {
+  const floatx2 lo = pk_add(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+  const floatx2 hi = pk_add(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ floatx4 pk4_sub(floatx4 a, floatx4 b) {
+  const floatx2 lo = pk_sub(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1));
+  const floatx2 hi = pk_sub(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
 // EPI bits: 1 BatchNorm partial sums of the output, 2 addend, 4 BatchNorm-backward sums (needs bnb_*)
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
@@ -98,15 +123,61 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
       __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((long long)p.F * H * W * Cr * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, 16 * Cn * Cr * 4, 0x00020000);
   const int nchunks = Cr / W_CK;
-  float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};
+  // BatchNorm partial sums (EPI & 5): a lane's accumulators hold ONE tile and 32 channels, so the sums over tiles go
+  // through a small LDS staging area per wave (below); this lane then owns channel  16 r + (lane & 15)  of round r =
+  // 2 j + (g >> 1) for the tiles 8 (lane >> 4) .. + 7 of every unit
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
   const int cb = (int)(blockIdx.x % p.ncb);          // the grid is a multiple of ncb: one column block per workgroup
 #ifdef AVID_WINO_TRACE
   long long tprev_ = wall_clock64();
   if (threadIdx.x == 0) for (int i = 0; i < 8; ++i) g_wino_trace[blockIdx.x * 8 + i] = 0;
 #endif
+  // tile table of a unit (tile index -> frame, ti, tj; frame = -1 past the end), double-buffered: the two integer
+  // divisions per tile are done once, by 32 lanes, instead of by every thread of the transform and 16 times per lane
+  // of the epilogue (~1000 VALU instructions per wave and unit, on the matrix pipe's time)
+  int4* tabs = reinterpret_cast<int4*>(sm + W_LDS_FLOATS);
+  auto fill_tab = [&](int unit, int buf) {
+    if (tid < W_TB) {
+      const long long t = (long long)(unit / p.ncb) * W_TB + tid;
+      int4 e = {-1, 0, 0, 0};
+      if (unit < p.units && t < p.ntiles) {
+        const int f = (int)(t / TPF), rem = (int)(t - (long long)f * TPF);
+        e.x = f; e.y = rem / TW; e.z = rem - e.y * TW;
+      }
+      tabs[buf * W_TB + tid] = e;
+    }
+  };
+  // this thread's item of the input transform: (4 channels = tid & 7, tile = tid >> 3).  The 4x4 patch of the NEXT
+  // chunk travels in registers while the current chunk is multiplied: its 16 loads are issued right before the
+  // products and land under them (the first version loaded, transformed and multiplied one chunk after the other:
+  // 47 % products / 27 % input transform / 26 % output transform, nothing overlapping — DESIGN.md 3.1c).
+  const int c4 = (tid & 7) * 4, ttl = tid >> 3;
+  floatx4 raw[4][4];
+  auto issue_loads = [&](const int4 e, int ck) {
+    const bool t_ok = e.x >= 0;
+    const int y1 = 2 * e.y, x1 = 2 * e.z;
+    // pixel (2 ti, 2 tj) = patch element (1, 1) is always inside the frame; the range check of a buffer load covers
+    // the vector offset only, so the columns to its right ride in the scalar offset and column 0 / row 0 are masked
+    const unsigned o11 = (unsigned)(((e.x * H + y1) * W + x1) * Cr + ck * W_CK + c4) * 4u;
+    const unsigned px_b = (unsigned)Cr * 4u, row_b = (unsigned)W * px_b;
+    const bool oky[4] = {t_ok && e.y > 0, t_ok, t_ok && y1 + 1 < H, t_ok && y1 + 2 < H};
+    const bool okx[4] = {e.z > 0, true, x1 + 1 < W, x1 + 2 < W};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const unsigned rowoff = o11 + (unsigned)(a - 1) * row_b;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        raw[a][b] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                    rsX, (oky[a] && okx[b]) ? (b == 0 ? rowoff - px_b : rowoff) : 0x80000000u,
+                                                    b == 0 ? 0 : (b - 1) * (int)px_b, 0));
+    }
+  };
+  fill_tab(blockIdx.x, 0);
+  __syncthreads();
+  int4 e_cur = tabs[ttl];
+  issue_loads(e_cur, 0);
   int uidx = 0;
   for (int unit = blockIdx.x; unit < p.units; unit += gridDim.x) {
-    const int blk = unit / p.ncb;
     W_STAMP(0);
     floatx16 acc[4][2];
 #pragma unroll
@@ -115,93 +186,78 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
-    // tile table of this unit (tile index -> frame, ti, tj; frame = -1 past the end): the two integer divisions per
-    // tile are done once, by 32 lanes, instead of by every thread of the transform and 16 times per lane of the
-    // epilogue (~1000 VALU instructions per wave and unit, on the matrix pipe's time)
-    int4* tab = reinterpret_cast<int4*>(sm + W_LDS_FLOATS) + (uidx & 1) * W_TB;
-    if (tid < W_TB) {
-      const long long t = (long long)blk * W_TB + tid;
-      int4 e = {-1, 0, 0, 0};
-      if (t < p.ntiles) {
-        const int f = (int)(t / TPF), rem = (int)(t - (long long)f * TPF);
-        e.x = f; e.y = rem / TW; e.z = rem - e.y * TW;
-      }
-      tab[tid] = e;
-    }
+    const int tbuf = uidx & 1;
+    const int4* tab = tabs + tbuf * W_TB;
     ++uidx;
-    // this thread's tile of the input transform: (4 channels = tid & 7, tile = tid >> 3)
-    const int c4 = (tid & 7) * 4, ttl = tid >> 3;
-    int tf = 0, tti = 0, ttj = 0;
-    bool t_ok = false;
     for (int ck = 0; ck < nchunks; ++ck) {
-      __syncthreads();                         // the previous chunk's / unit's LDS reads are done; the tile table is there
-      if (ck == 0) {
-        const int4 e = tab[ttl];
-        t_ok = e.x >= 0; tf = e.x; tti = e.y; ttj = e.z;
-      }
+      __syncthreads();                         // the previous chunk's / unit's LDS reads are done
+      if (ck == 0) fill_tab(unit + gridDim.x, tbuf ^ 1);      // (visible behind the next barrier; nobody reads that buffer now)
       {
         // V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]: column by column, then row by row
         floatx4 w_[4][4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          floatx4 d[4];
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const int yy = 2 * tti - 1 + a, xx = 2 * ttj - 1 + b;
-            const bool ok = t_ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            const unsigned off = (unsigned)((((long long)tf * H + yy) * W + xx) * Cr + ck * W_CK + c4) * 4u;
-            d[a] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? off : 0x80000000u, 0, 0));
-          }
-          w_[0][b] = d[0] - d[2];
-          w_[1][b] = d[1] + d[2];
-          w_[2][b] = d[2] - d[1];
-          w_[3][b] = d[1] - d[3];
+          w_[0][b] = pk4_sub(raw[0][b], raw[2][b]);
+          w_[1][b] = pk4_add(raw[1][b], raw[2][b]);
+          w_[2][b] = pk4_sub(raw[2][b], raw[1][b]);
+          w_[3][b] = pk4_sub(raw[1][b], raw[3][b]);
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           float* dst = sm + ((a * 4) * W_TB + ttl) * W_VLD + c4;
-          *reinterpret_cast<floatx4*>(dst + 0 * W_TB * W_VLD) = w_[a][0] - w_[a][2];
-          *reinterpret_cast<floatx4*>(dst + 1 * W_TB * W_VLD) = w_[a][1] + w_[a][2];
-          *reinterpret_cast<floatx4*>(dst + 2 * W_TB * W_VLD) = w_[a][2] - w_[a][1];
-          *reinterpret_cast<floatx4*>(dst + 3 * W_TB * W_VLD) = w_[a][1] - w_[a][3];
+          *reinterpret_cast<floatx4*>(dst + 0 * W_TB * W_VLD) = pk4_sub(w_[a][0], w_[a][2]);
+          *reinterpret_cast<floatx4*>(dst + 1 * W_TB * W_VLD) = pk4_add(w_[a][1], w_[a][2]);
+          *reinterpret_cast<floatx4*>(dst + 2 * W_TB * W_VLD) = pk4_sub(w_[a][2], w_[a][1]);
+          *reinterpret_cast<floatx4*>(dst + 3 * W_TB * W_VLD) = pk4_sub(w_[a][1], w_[a][3]);
         }
       }
       __syncthreads();
       W_STAMP(1);
-      // ---- the wave's four products; the next point's B operand is in flight while the current one multiplies
-      // B operand (U, from L2): double-buffered per transform point, the next point in flight while one multiplies
-      // (keeping the first point of the NEXT chunk in flight across the input transform cost more in spills than
-      // the hidden latency was worth: 218 -> 225 us)
-      floatx4 bv[2][2][4];
-      auto load_b = [&](int c, int buf, int ck_) {
-        const int xi = wave * 4 + c;
+      // the next chunk's patch (of this unit, or chunk 0 of this workgroup's next unit): in flight under the products
+      if (ck + 1 < nchunks) {
+        issue_loads(e_cur, ck + 1);
+      } else {
+        e_cur = tabs[(tbuf ^ 1) * W_TB + ttl];
+        issue_loads(e_cur, 0);
+      }
+      // ---- the wave's four products, computed TRANSPOSED (D[n][tile] = sum_k U[n][k] V[tile][k]: U is the MFMA's A
+      // operand): a lane then holds ONE tile and, in every group of four accumulator registers, four consecutive
+      // output channels — the output transform stores 16 contiguous bytes per lane and needs one destination offset
+      // per lane instead of sixteen.  U (from L2) sits in three rotating slots of (transform point, 32-column
+      // half): the loads run two slots ahead of the MFMAs that consume them
+      floatx4 bv[3][4];
+      auto load_b = [&](int s_) {
+        const int xi = wave * 4 + (s_ >> 1), j = s_ & 1;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            bv[buf][j][q] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
-                rsU, (unsigned)((((long long)xi * Cn + cb * 64 + j * 32 + l31) * Cr + ck_ * W_CK + 16 * h + 4 * q) * 4), 0, 0));
+        for (int q = 0; q < 4; ++q)
+          bv[s_ % 3][q] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+              rsU, (unsigned)((((long long)xi * Cn + cb * 64 + j * 32 + l31) * Cr + ck * W_CK + 16 * h + 4 * q) * 4), 0, 0));
       };
-      load_b(0, 0, ck);
+      load_b(0);
+      load_b(1);
+      floatx4 av[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (c + 1 < 4) load_b(c + 1, (c + 1) & 1, ck);
-        const int xi = wave * 4 + c;
-        const float* Ap = sm + (xi * W_TB + l31) * W_VLD + 16 * h;
-        floatx4 av[4];
+      for (int s_ = 0; s_ < 8; ++s_) {
+        const int c = s_ >> 1, j = s_ & 1;
+        if (s_ + 2 < 8) load_b(s_ + 2);
+        if (j == 0) {
+          const float* Ap = sm + ((wave * 4 + c) * W_TB + l31) * W_VLD + 16 * h;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const floatx4*>(Ap + 4 * q);
+          for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const floatx4*>(Ap + 4 * q);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][e], bv[c & 1][j][q][e], acc[c][j], 0, 0, 0);
+            acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[s_ % 3][q][e], av[q][e], acc[c][j], 0, 0, 0);
       }
       W_STAMP(2);
     }
-    // ---- output transform.  Columns in registers: T[r][0] = M0 + M1 + M2, T[r][1] = M1 - M2 - M3 (r = wave)
+    // ---- output transform.  Columns in registers: T[r][0] = M0 + M1 + M2, T[r][1] = M1 - M2 - M3 (r = wave); rows
+    // across the four waves through LDS (V is dead by then; lane-private 16-byte slots, conflict-free).  Accumulator
+    // layout (transposed products): lane = (tile l31, h), register r <-> channel (r & 3) + 8 (r >> 2) + 4 h of the
+    // 32-column half j.  (With the MFMA's usual orientation — one channel and 16 tiles per lane — a unit took 32
+    // four-byte store instructions per lane, and their issue made the output phase as long as the products.)
     W_STAMP(3);
     floatx16 T0[2], T1[2];
 #pragma unroll
@@ -209,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
       T0[j] = acc[0][j] + acc[1][j] + acc[2][j];
       T1[j] = acc[1][j] - acc[2][j] - acc[3][j];
     }
-    __syncthreads();                           // V is dead: the LDS becomes the exchange buffer T[r][q][j][reg][lane]
+    __syncthreads();                           // V is dead: the LDS becomes the exchange buffer T[r][q][j][reg / 4][lane]
     float* ex = sm;                             // ex[row][q][j][r / 4][lane][r % 4]: 16-byte accesses, conflict-free
     auto ex_at = [&](int row, int q_, int j, int r4) { return ex + (((((row * 2 + q_) * 2 + j) * 4 + r4) * 64 + lane) << 2); };
 #pragma unroll
@@ -223,63 +279,92 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
     // rows across waves: this wave writes output pixel (po, qo) of every tile:
     //   Y[0][q] = T[0][q] + T[1][q] + T[2][q],  Y[1][q] = T[1][q] - T[2][q] - T[3][q]
     const int po = wave >> 1, qo = wave & 1;
-    int ooff[16];                               // destination row offsets (in floats, < 2^29) of the lane's 16 tiles, or -1
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int4 e = tab[(r & 3) + 8 * (r >> 2) + 4 * h];      // MFMA C layout: row = tile
+    int ooff;                                   // destination offset (in floats, < 2^29) of the lane's tile, or -1
+    {
+      const int4 e = tab[l31];
       const int yy = 2 * e.y + po, xx = 2 * e.z + qo;
-      ooff[r] = (e.x >= 0 && yy < H && xx < W) ? ((e.x * H + yy) * W + xx) * Cn : -1;
+      ooff = (e.x >= 0 && yy < H && xx < W) ? ((e.x * H + yy) * W + xx) * Cn + cb * 64 + 4 * h : -1;
     }
+    const bool ok = ooff >= 0;
+    const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // statistics staging: st[wave][tile 32][16 channels] (2 KB per wave, behind the exchange buffer), 16-byte slots
+    // XOR-swizzled by the tile so that the eight lanes of a 16-byte store group and the 32 lanes of a 4-byte load group
+    // hit distinct banks.  One term at a time; LDS operations of a wave execute in order, so no barrier is involved.
+    float* st = sm + 4 * 2 * 2 * 4 * 64 * 4 + wave * (W_TB * 16);
+    const int st_row = l31 * 16, st_sw = ((l31 >> 1) & 3) * 4;
+    const int st_ch = lane & 15, st_tg = lane >> 4;
+    auto col_sums = [&]() {                      // sum over this lane's 8 tiles of channel st_ch of the staged round
+      float s_ = 0.f;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int tile = 8 * st_tg + ((m + st_tg) & 7);
+        s_ += st[tile * 16 + (st_ch ^ (((tile >> 1) & 3) * 4))];
+      }
+      return s_;
+    };
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = cb * 64 + j * 32 + l31;
-      float bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
-      if (EPI & 4) { bsc = p.bnb_scale[col]; bsh = p.bnb_shift[col]; bmu = p.bnb_mean[col]; bis = p.bnb_invstd[col]; }
-      float ad[16], xb[16];
+      floatx4 ad[4], xb[4];
       if (EPI & 2) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ad[r] = ooff[r] >= 0 ? p.addend[ooff[r] + col] : 0.f;
+        for (int g = 0; g < 4; ++g) ad[g] = ok ? *reinterpret_cast<const floatx4*>(p.addend + ooff + j * 32 + 8 * g) : z4;
       }
       if (EPI & 4) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xb[r] = ooff[r] >= 0 ? p.bnb_x[ooff[r] + col] : 0.f;
-      }
-      float yv[16];
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const floatx4 a = *reinterpret_cast<const floatx4*>(ex_at(po, qo, j, r4));        // rows po, po + 1, po + 2
-        const floatx4 b = *reinterpret_cast<const floatx4*>(ex_at(po + 1, qo, j, r4));
-        const floatx4 c = *reinterpret_cast<const floatx4*>(ex_at(po + 2, qo, j, r4));
-        const floatx4 y4 = po == 0 ? a + b + c : a - b - c;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) yv[4 * r4 + e] = y4[e];
+        for (int g = 0; g < 4; ++g) xb[g] = ok ? *reinterpret_cast<const floatx4*>(p.bnb_x + ooff + j * 32 + 8 * g) : z4;
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = yv[r];
-        if (EPI & 2) v += ad[r];
-        if (ooff[r] >= 0) {
-          p.dst[ooff[r] + col] = v;
-          if (EPI & 1) { cs[j] += v; cq[j] = fmaf(v, v, cq[j]); }
-          if (EPI & 4) {
-            const float dm = (!p.bnb_relu || fmaf(xb[r], bsc, bsh) > 0.f) ? v : 0.f;
-            cs[j] += dm;
-            cq[j] = fmaf(dm, (xb[r] - bmu) * bis, cq[j]);
+      for (int gp = 0; gp < 2; ++gp) {
+        floatx4 t0[2], t1[2];
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl) {
+          const int g = 2 * gp + gl;
+          const floatx4 a = *reinterpret_cast<const floatx4*>(ex_at(po, qo, j, g));        // rows po, po + 1, po + 2
+          const floatx4 b = *reinterpret_cast<const floatx4*>(ex_at(po + 1, qo, j, g));
+          const floatx4 c = *reinterpret_cast<const floatx4*>(ex_at(po + 2, qo, j, g));
+          floatx4 v = po == 0 ? a + b + c : a - b - c;
+          if (EPI & 2) v += ad[g];
+          if (ok) *reinterpret_cast<floatx4*>(p.dst + ooff + j * 32 + 8 * g) = v;
+          if (EPI & 5) {
+            t0[gl] = ok ? v : z4;                 // the two terms whose column sums are wanted
+            if (EPI & 1) {
+              t1[gl] = t0[gl] * t0[gl];
+            } else {
+              const int col = cb * 64 + j * 32 + 8 * g + 4 * h;
+              const floatx4 bsc = *reinterpret_cast<const floatx4*>(p.bnb_scale + col), bsh = *reinterpret_cast<const floatx4*>(p.bnb_shift + col);
+              const floatx4 bmu = *reinterpret_cast<const floatx4*>(p.bnb_mean + col), bis = *reinterpret_cast<const floatx4*>(p.bnb_invstd + col);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                t0[gl][i] = (!p.bnb_relu || fmaf(xb[g][i], bsc[i], bsh[i]) > 0.f) ? t0[gl][i] : 0.f;
+                t1[gl][i] = t0[gl][i] * ((xb[g][i] - bmu[i]) * bis[i]);
+              }
+            }
           }
+        }
+        if (EPI & 5) {            // round r = 2 j + gp: channels 16 r .. 16 r + 15 of this column block
+          const int r = 2 * j + gp;
+          *reinterpret_cast<floatx4*>(st + st_row + ((4 * h) ^ st_sw)) = t0[0];
+          *reinterpret_cast<floatx4*>(st + st_row + ((8 + 4 * h) ^ st_sw)) = t0[1];
+          cs[r] += col_sums();
+          *reinterpret_cast<floatx4*>(st + st_row + ((4 * h) ^ st_sw)) = t1[0];
+          *reinterpret_cast<floatx4*>(st + st_row + ((8 + 4 * h) ^ st_sw)) = t1[1];
+          cq[r] += col_sums();
         }
       }
     }
   }
   W_STAMP(4);
-  if ((EPI & 5) && p.stats) {   // one partial row [2][Cn] per workgroup: half-waves, then the four waves in fixed order
+  if ((EPI & 5) && p.stats) {   // one partial row [2][Cn] per workgroup: the four tile groups of a wave, then the four waves
     __syncthreads();
     float* red = sm;            // [2][4][64]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float a = cs[j] + __shfl_xor(cs[j], 32, 64), b = cq[j] + __shfl_xor(cq[j], 32, 64);
-      if (h == 0) {
-        red[wave * 64 + j * 32 + l31] = a;
-        red[256 + wave * 64 + j * 32 + l31] = b;
+    for (int r = 0; r < 4; ++r) {
+      float a = cs[r], b = cq[r];
+      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+      if (lane < 16) {
+        red[wave * 64 + 16 * r + lane] = a;
+        red[256 + wave * 64 + 16 * r + lane] = b;
       }
     }
     __syncthreads();
@@ -313,7 +398,6 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
 //   epilogue: G^T . G in registers — columns j inside a wave, rows i as two partial sums; the e = 1 waves hand theirs
 //   over through LDS, the e = 0 waves write the block as dw[n][3][3][c] into this split's slab; wgrad_reduce_kernel
 //   (csrc/conv.hip) sums the slabs in fixed order.
-typedef float floatx2 __attribute__((ext_vector_type(2)));
 constexpr int WW_TK = 8;                               // tiles per LDS stage (GEMM-K of a stage)
 constexpr int WW_HALF = WW_TK * 16 * 64;               // floats of V (or dM) in one stage: [tile][xi][64 channels]
 constexpr int WW_STAGE = 2 * WW_HALF;                  // V | dM
@@ -330,20 +414,6 @@ struct WinoWgradArgs {
   unsigned mgTPF, mgTW;                 // multiply-shift division by TH * TW and TW
   int shTPF, shTW;
 };
-
-// Packed fp32 adds as inline assembly: every VALU instruction of a wave costs ~2.2 ns of its SIMD's MFMA time
-// (tools/mfma_shadow: the fp32 MFMA runs at the vector rate, on the same lanes), a packed add costs the same as a
-// scalar one — and the compiler UNPACKS v_pk_add_f32 wherever it sits behind an MFMA (two instructions for one).
-__device__ __forceinline__ floatx2 pk_add(floatx2 a, floatx2 b) {
-  floatx2 r;
-  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
-  floatx2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 
 // ROLE 0 (waves 0-3): input-transform threads, V = B^T d B of (tile, channel pair); ROLE 1 (waves 4-7): gradient-
 // transform threads, dM' = |A| dY |A|^T of (tile, output-channel pair) — the signs of A's last row (A[3] = [0,-1]) are
