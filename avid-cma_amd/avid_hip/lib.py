@@ -117,6 +117,10 @@ SIGNATURES = {
     "avid_nce_fwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _f, _i, _vp, _vp, _sz, _vp]),
     "avid_nce_bwd": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "avid_bank_update": (_i, [_i, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp]),
+    "avid_xmodal_fused_workspace_bytes": (_sz, [_i, _i]),
+    "avid_xmodal_fused": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _sz, _vp, _vp]),
+    "avid_bank_update2": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     "avid_cma_negatives": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avid_cma_topk_workspace_bytes": (_sz, [_i64, _i, _i]),
     "avid_cma_topk": (_i, [_i64, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -1034,6 +1034,58 @@ def bank_update(bank, y, emb, momentum):
              _p(emb.contiguous()), float(momentum), DeviceErrors.get(bank.device).ptr(), _stream())
 
 
+def bank_update_pair(bank0, bank1, y, emb0, emb1, momentum0, momentum1):
+    """``bank_update`` of both banks in one launch (criterions/avid.py:118-129), bit-identical to two calls."""
+    _need_cuda(bank0, bank1, y, emb0, emb1)
+    lib.call("avid_bank_update2", y.shape[0], bank0.shape[1], bank0.shape[0], _p(bank0), _p(bank1), _p(y.contiguous()),
+             _p(emb0.contiguous()), _p(emb1.contiguous()), float(momentum0), float(momentum1),
+             DeviceErrors.get(bank0.device).ptr(), _stream())
+
+
+FUSED_CRITERION = os.environ.get("AVID_FUSED_CRITERION", "1") == "1"
+
+
+class _XModalFused(Function):
+    """The whole cross-modal criterion of a steady-state step in one kernel (``avid_xmodal_fused``): returns
+    (total loss, losses[4], v_hat, a_hat); the gradient of the total loss with respect to both raw embeddings is formed
+    in the forward pass (Z is a constant) and only scaled by the upstream gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, v_emb, a_emb, y, idx, bank_v, bank_a, Z, inv_T, coeff, ws):
+        _need_cuda(v_emb, a_emb, y, idx, bank_v, bank_a, Z, ws)
+        v_emb, a_emb, y, idx = v_emb.contiguous(), a_emb.contiguous(), y.contiguous(), idx.contiguous()
+        bs, D = v_emb.shape
+        K = idx.shape[1]
+        if y.dtype != torch.int64 or idx.dtype != torch.int64 or not bank_v.is_contiguous() or not bank_a.is_contiguous():
+            raise AvidHipError("xmodal_fused: y / idx must be int64 and the banks contiguous")
+        dev = v_emb.device
+        hats = torch.empty((2, bs, D), dtype=torch.float32, device=dev)
+        grads = torch.empty((2, bs, D), dtype=torch.float32, device=dev)
+        losses = torch.empty(4, dtype=torch.float32, device=dev)
+        lib.call("avid_xmodal_fused", bs, K, D, bank_v.shape[0], _p(v_emb), _p(a_emb), _p(y), _p(idx), _p(bank_v),
+                 _p(bank_a), float(inv_T), _p(Z), float(coeff), _p(hats[0]), _p(hats[1]), _p(losses), _p(grads[0]),
+                 _p(grads[1]), _p(ws), ws.numel(), DeviceErrors.get(dev).ptr(), _stream())
+        ctx.save_for_backward(grads)
+        total = losses[3]
+        ctx.mark_non_differentiable(losses, hats)
+        return total, losses, hats
+
+    @staticmethod
+    def backward(ctx, dtotal, _dl, _dh):
+        (grads,) = ctx.saved_tensors
+        g = grads * dtotal                      # one launch for both embeddings
+        return g[0], g[1], None, None, None, None, None, None, None, None
+
+
+def xmodal_fused_workspace(device, bs, K):
+    """Zero-filled scratch of ``avid_xmodal_fused`` (its device tickets re-arm themselves): one per criterion object."""
+    return torch.zeros(int(lib.raw("avid_xmodal_fused_workspace_bytes")(int(bs), int(K))), dtype=torch.uint8, device=device)
+
+
+def xmodal_fused(v_emb, a_emb, y, idx, bank_v, bank_a, Z, inv_T, coeff, ws):
+    return _XModalFused.apply(v_emb, a_emb, y, idx, bank_v, bank_a, Z, inv_T, coeff, ws)
+
+
 def cma_negatives(positive_set, y, rand_idx):
     _need_cuda(positive_set, y, rand_idx)
     bs, K = rand_idx.shape

@@ -127,6 +127,8 @@ class GradBuckets:
         self.works = []
         self.hooks = []
         self.comm_stream = None
+        self.measure = False          # bench.py: event-time the compute stream's wait for the collectives in finish()
+        self.wait_events = []
         self.producers = [set() for _ in self.bounds]     # streams that issued gradients of each bucket
         # Autograd hooks only where the kernels do not report their gradients themselves (ops.GradSlots, the
         # CUDA path): 141 tensor hooks cost ~0.4 ms of backward per step on the single-rank check.  A gradient
@@ -187,6 +189,16 @@ class GradBuckets:
         with torch.cuda.stream(cs):
             self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
 
+    def exposed_wait_ms(self):
+        """Mean time per step the compute stream spent waiting for the gradient collectives in ``finish()`` since
+        ``measure`` was switched on (synchronises; clears the record)."""
+        if not self.wait_events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.wait_events]
+        self.wait_events = []
+        return sum(ms) / len(ms)
+
     def finish(self):
         """Launch whatever did not fire (unused parameters, gradients that came through autograd) and make the
         current stream wait for all buckets."""
@@ -197,8 +209,15 @@ class GradBuckets:
                 if left > 0:
                     self.producers[b].clear()        # not all producers are known: wait for both towers
                 self._launch(b)                      # (a COMPLETE bucket is still unlaunched in late-bucket mode)
+            timed = self.measure and self.flat.grad.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             for w in self.works:
                 w.wait()                             # the current (compute) stream waits for the collective
+            if timed:
+                e1.record()
+                self.wait_events.append((e0, e1))
         self.works = []
         self.pending = list(self.counts)
         self.launched = [False] * len(self.bounds)

@@ -84,6 +84,31 @@ class AVIDSimilarityMemoryBank(nn.Module):
         ops.poll_device_errors(y.device)      # starts the (asynchronous) read-back of this step's error word
         return scores
 
+    def fused_ok(self, video_emb, audio_emb):
+        """The one-kernel steady-state path (ops.xmodal_fused): cross-modal scores only, 128-d embeddings on the GPU."""
+        return (ops.FUSED_CRITERION and self.xModal and not self.wModal and video_emb.is_cuda and video_emb.dim() == 2
+                and video_emb.shape[1] == 128 and self.view1_mem.shape[1] == 128
+                and video_emb.dtype == torch.float32 and audio_emb.dtype == torch.float32)
+
+    def forward_fused(self, video_emb, audio_emb, y, Z, coeff):
+        """avid.py:47-80 + nce.py:38-58 for both cross-modal score sets with the partition constant ``Z`` frozen: one
+        kernel for normalize -> gather (both banks, shared indices) -> scores / T -> NCE terms AND their gradient with
+        respect to the embeddings, then ONE bank-update launch.  Returns (total loss, losses[4])."""
+        K = int(self.num_negatives)
+        ops.poll_device_errors(y.device)
+        with torch.no_grad():
+            idx = self.sample_negatives(y, K)
+        ws = getattr(self, "_fused_ws", None)
+        key = (y.shape[0], K, video_emb.device)
+        if ws is None or self._fused_key != key:
+            ws = self._fused_ws = ops.xmodal_fused_workspace(video_emb.device, y.shape[0], K)
+            self._fused_key = key
+        total, losses, hats = ops.xmodal_fused(video_emb, audio_emb, y, idx, self.view1_mem, self.view2_mem, Z,
+                                               1.0 / self.temperature, coeff, ws)
+        self.update_memory(hats[0], hats[1], y)
+        ops.poll_device_errors(y.device)
+        return total, losses
+
     def sample_negatives(self, y, K):
         """avid.py:82-86 — uniform over [0,N) \\ {y}; draw + "avoid self" in one kernel."""
         bs = y.shape[0]
@@ -110,8 +135,11 @@ class AVIDSimilarityMemoryBank(nn.Module):
         audio_mom = float(self.momentum[1])
         v_all, a_all, y_all = gather_update_records(video_emb, audio_emb, y)
         with torch.no_grad():
-            ops.bank_update(self.view1_mem, y_all, v_all, video_mom)
-            ops.bank_update(self.view2_mem, y_all, a_all, audio_mom)
+            if self.view1_mem.is_cuda and self.view1_mem.shape[1] <= 512:
+                ops.bank_update_pair(self.view1_mem, self.view2_mem, y_all, v_all, a_all, video_mom, audio_mom)
+            else:
+                ops.bank_update(self.view1_mem, y_all, v_all, video_mom)
+                ops.bank_update(self.view2_mem, y_all, a_all, audio_mom)
 
     def __repr__(self):
         repr_dict = {
@@ -159,6 +187,14 @@ class AVID(nn.Module):
 
     def forward(self, emb1, emb2, target):
         tb_log = {}
+        # steady state (Z frozen after the first batch, nce.py:22-24) with cross-modal scores only: one fused kernel
+        if self.nce_average.fused_ok(emb1, emb2) and self.criterion.z_ready():
+            total_loss, losses = self.nce_average.forward_fused(emb1, emb2, target, self.criterion.avg_exp_score,
+                                                                self.xModal_coeff)
+            tb_log['Loss/v2a'], tb_log['Loss/a2v'] = losses[0], losses[1]
+            tb_log['Loss/xModal'] = losses[2]
+            tb_log['Loss/wModal'] = 0
+            return total_loss, tb_log
         scores = self.nce_average(emb1, emb2, target)
 
         xModal_loss, wModal_loss = 0., 0

@@ -29,11 +29,16 @@ class NCECriterion(nn.Module):
         self._z_ready = None
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def compute_partition_function(self, scores_neg):
-        """NOTE: takes the raw negative scores (the exp is fused into the reduction kernel)."""
+    def z_ready(self):
+        """Z is frozen (nce.py:22-24 ``if self.avg_exp_score > 0``).  The host looks at the buffer once — after
+        construction or ``load_state_dict`` — and never again."""
         if self._z_ready is None:
             self._z_ready = bool(self.avg_exp_score.item() > 0)
-        if self._z_ready:
+        return self._z_ready
+
+    def compute_partition_function(self, scores_neg):
+        """NOTE: takes the raw negative scores (the exp is fused into the reduction kernel)."""
+        if self.z_ready():
             return self.avg_exp_score
         with torch.no_grad():
             Z = ops.mean_exp(scores_neg)

@@ -2757,7 +2757,14 @@ static WgradPlan wgrad_plan(const avid_conv_desc* d) {
   }
   const long long tiles = (long long)pl.kt_tiles * pl.n_tiles;
   const long long chunks = ceil_div(M, 32);
-  long long want = (2 * 256) / tiles;   // 4-wave workgroups, two per CU
+  // 4-wave workgroups, two per CU; AVID_WG_SLOTS (default 512 = the whole chip) is how many of them one launch aims to fill
+  static int slots = 0;
+  if (!slots) {
+    const char* e = getenv("AVID_WG_SLOTS");
+    slots = e ? atoi(e) : 512;
+    if (slots < 1) slots = 512;
+  }
+  long long want = slots / tiles;
   long long max_split = chunks / 4 > 0 ? chunks / 4 : 1;  // >= 4 chunks (128 rows) per split (conv4x temporal: 56 -> 42 us vs 8)
   long long ns = want < 1 ? 1 : (want > max_split ? max_split : want);
   if (ns > 512) ns = 512;

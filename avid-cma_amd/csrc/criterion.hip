@@ -304,9 +304,9 @@ __global__ void nce_bwd_kernel(const float* __restrict__ spos, const float* __re
 // ---------------------------------------------------------------------------------------------
 // bank[y[i]] = normalize(m * bank[y[i]] + (1-m) * emb[i]); last duplicate wins. One wave per sample.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bank_update_kernel(float* __restrict__ bank, const long long* __restrict__ y,
-                                                          const float* __restrict__ emb, float mom, int B, int D,
-                                                          long long N, int* __restrict__ err) {
+__device__ __forceinline__ void bank_update_rows(float* __restrict__ bank, const long long* __restrict__ y,
+                                                 const float* __restrict__ emb, float mom, int B, int D, long long N,
+                                                 int* __restrict__ err) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= B) return;
@@ -331,6 +331,201 @@ __global__ __launch_bounds__(256) void bank_update_kernel(float* __restrict__ ba
   const float nrm = fmaxf(sqrtf(ss), 1e-12f);
   cnt = 0;
   for (int d = lane; d < D && cnt < 8; d += 64, ++cnt) p[d] = v[cnt] / nrm;
+}
+
+__global__ __launch_bounds__(256) void bank_update_kernel(float* __restrict__ bank, const long long* __restrict__ y,
+                                                          const float* __restrict__ emb, float mom, int B, int D,
+                                                          long long N, int* __restrict__ err) {
+  bank_update_rows(bank, y, emb, mom, B, D, N, err);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused cross-modal criterion (criterions/avid.py:52-71 + criterions/nce.py:38-58 with the partition constant already
+// frozen, nce.py:22-24): normalise both embeddings, gather the SAME rows of both banks, scores / T, the NCE terms —
+// and, because Z is a constant after the first batch, the gradient with respect to the embeddings in the same pass,
+// while a gathered row is still in registers:  d emb_hat = sum_j (dL / ds_j) row_j / T,  then the backward of
+// F.normalize.  No score tensors, no snapshot of the gathered rows (the unfused path keeps one because the banks are
+// updated before backward runs, criterions/avid.py:78), no second gather.
+//   grid (splits of the K + 1 rows, sample); block = 4 waves x 16 rows (x 2 banks) in flight, as bank_scores_fwd_kernel.
+//   Every block leaves its partial gradients / loss terms in ws; xmodal_finish_kernel (second launch, one block per
+//   sample) folds them in split order and applies the normalisation's backward; the last of its blocks folds the
+//   per-sample losses in sample order: fixed summation order, one re-armed ticket (the scratch is zeroed once by the
+//   caller).  (A first version folded inside the first kernel behind two device-scope fences per block and per-sample
+//   tickets: 129 us for the 1088 blocks of a step instead of ~25.)
+// ---------------------------------------------------------------------------------------------
+struct XModalArgs {
+  const float* v_emb; const float* a_emb;          // raw embeddings [bs][128]
+  const long long* y; const long long* idx;        // [bs], [bs][K]
+  const float* bank_v; const float* bank_a;        // view1_mem (video), view2_mem (audio)
+  const float* Z;
+  float* v_hat; float* a_hat;                      // normalised embeddings [bs][128]
+  float* losses;                                   // [4]: L_v2a, L_a2v, (L_v2a + L_a2v) / 2, coeff * that
+  float* dv; float* da;                            // d(total) / d(raw embedding) [bs][128]
+  float* part_g;                                   // [bs][S][2][128]
+  double* part_l;                                  // [bs][S][2]
+  double* samp_l;                                  // [bs][2]
+  unsigned* tickets;                               // [bs + 1]
+  float* norms;                                    // [2][bs]: |v_emb|, |a_emb| (clamped as F.normalize does)
+  int* err;
+  long long N;
+  int bs, K, S;
+  float inv_T, coeff;
+};
+
+__global__ __launch_bounds__(256) void xmodal_fused_kernel(const XModalArgs p) {
+  constexpr int D = 128, RPW = SC_ROWS_PER_BLOCK / 4;
+  __shared__ float sh_g[4][2][D];
+  __shared__ double sh_l[4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, split = blockIdx.x, R = p.K + 1;
+  // normalised embeddings (every wave computes them: 2 floats per lane)
+  float ev[2], ea[2], nv, na;
+  {
+    const float v0 = p.v_emb[(long long)b * D + lane], v1 = p.v_emb[(long long)b * D + 64 + lane];
+    const float a0 = p.a_emb[(long long)b * D + lane], a1 = p.a_emb[(long long)b * D + 64 + lane];
+    nv = fmaxf(sqrtf(wave_sum(v0 * v0 + v1 * v1)), 1e-12f);
+    na = fmaxf(sqrtf(wave_sum(a0 * a0 + a1 * a1)), 1e-12f);
+    ev[0] = v0 / nv; ev[1] = v1 / nv; ea[0] = a0 / na; ea[1] = a1 / na;
+    if (split == 0 && wave == 0) {
+      p.v_hat[(long long)b * D + lane] = ev[0]; p.v_hat[(long long)b * D + 64 + lane] = ev[1];
+      p.a_hat[(long long)b * D + lane] = ea[0]; p.a_hat[(long long)b * D + 64 + lane] = ea[1];
+      if (lane == 0) { p.norms[b] = nv; p.norms[p.bs + b] = na; }
+    }
+  }
+  const float KZ = (float)p.K * p.Z[0];
+  const int j0 = split * SC_ROWS_PER_BLOCK, j1 = min(j0 + SC_ROWS_PER_BLOCK, R);
+  const int jw = j0 + wave * RPW;
+  // row j = 0 is the positive (the sample's own row y), rows 1..K the negatives idx[b][j - 1]
+  long long mine = 0;
+  if (lane < RPW && jw + lane < j1) {
+    mine = jw + lane == 0 ? p.y[b] : p.idx[(long long)b * p.K + jw + lane - 1];
+    if (mine < 0 || mine >= p.N) {
+      if (p.err) atomicOr(p.err, AVID_DEVERR_BANK_INDEX);
+      mine = mine < 0 ? 0 : p.N - 1;
+    }
+  }
+  float ra[RPW][2], rv[RPW][2];          // audio-bank rows (scored against the video embedding) and video-bank rows
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const long long row = __shfl(mine, u, 64);
+    const float* pa = p.bank_a + row * D;
+    const float* pv = p.bank_v + row * D;
+    ra[u][0] = pa[lane]; ra[u][1] = pa[64 + lane];
+    rv[u][0] = pv[lane]; rv[u][1] = pv[64 + lane];
+  }
+  float gv[2] = {0.f, 0.f}, ga[2] = {0.f, 0.f};      // d L_v2a / d v_hat, d L_a2v / d a_hat (x T, unscaled)
+  double lv = 0, la = 0;
+#pragma unroll
+  for (int u = 0; u < RPW; ++u) {
+    const int j = jw + u;
+    const float s1 = wave_sum(ra[u][0] * ev[0] + ra[u][1] * ev[1]) * p.inv_T;     // v2a: video embedding . audio bank
+    const float s2 = wave_sum(rv[u][0] * ea[0] + rv[u][1] * ea[1]) * p.inv_T;     // a2v
+    if (j < j1) {
+      const float e1 = expf(s1), e2 = expf(s2);
+      float g1, g2;
+      if (j == 0) {            // -log(e / (e + KZ));  d / ds = -KZ / (e + KZ)
+        lv += (double)(-logf(e1 / (e1 + KZ))); la += (double)(-logf(e2 / (e2 + KZ)));
+        g1 = -(KZ / (e1 + KZ)); g2 = -(KZ / (e2 + KZ));
+      } else {                 // -log(KZ / (e + KZ));  d / ds = e / (e + KZ)
+        lv += (double)(-logf(KZ / (e1 + KZ))); la += (double)(-logf(KZ / (e2 + KZ)));
+        g1 = e1 / (e1 + KZ); g2 = e2 / (e2 + KZ);
+      }
+      gv[0] = fmaf(g1, ra[u][0], gv[0]); gv[1] = fmaf(g1, ra[u][1], gv[1]);
+      ga[0] = fmaf(g2, rv[u][0], ga[0]); ga[1] = fmaf(g2, rv[u][1], ga[1]);
+    }
+  }
+  sh_g[wave][0][lane] = gv[0]; sh_g[wave][0][64 + lane] = gv[1];
+  sh_g[wave][1][lane] = ga[0]; sh_g[wave][1][64 + lane] = ga[1];
+  if (lane == 0) { sh_l[wave][0] = lv; sh_l[wave][1] = la; }
+  __syncthreads();
+  float* pg = p.part_g + ((long long)b * p.S + split) * 2 * D;
+  {
+    const int t = threadIdx.x;                       // 256 threads = 2 x 128 gradient components
+    pg[t] = ((&sh_g[0][0][0])[t] + (&sh_g[1][0][0])[t]) + ((&sh_g[2][0][0])[t] + (&sh_g[3][0][0])[t]);   // [which][d] contiguous
+  }
+  if (threadIdx.x == 0) {
+    double* pl = p.part_l + ((long long)b * p.S + split) * 2;
+    pl[0] = (sh_l[0][0] + sh_l[1][0]) + (sh_l[2][0] + sh_l[3][0]);
+    pl[1] = (sh_l[0][1] + sh_l[1][1]) + (sh_l[2][1] + sh_l[3][1]);
+  }
+}
+
+// second launch of the fused criterion: one block per sample folds the S partial gradients in split order (the kernel
+// boundary makes them visible: no fences around the 1088 producer blocks), applies the backward of F.normalize and
+// leaves the sample's two loss terms; the last of the bs blocks (device ticket, re-armed) folds those in sample order.
+__global__ __launch_bounds__(256) void xmodal_finish_kernel(const XModalArgs p) {
+  constexpr int D = 128;
+  __shared__ float sh_dot[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, which = t >> 7, d = t & 127;
+  const int b = blockIdx.x;
+  const float eh = (which == 0 ? p.v_hat : p.a_hat)[(long long)b * D + d];      // as the main kernel normalised it
+  const float nrm = p.norms[which * p.bs + b];
+  const float* pg = p.part_g + (long long)b * p.S * 2 * D + t;
+  float g = 0.f;
+  int sidx = 0;
+  for (; sidx + 4 <= p.S; sidx += 4) {               // four independent loads per trip, summed in split order
+    const float g0 = pg[(long long)sidx * 2 * D], g1 = pg[(long long)(sidx + 1) * 2 * D];
+    const float g2 = pg[(long long)(sidx + 2) * 2 * D], g3 = pg[(long long)(sidx + 3) * 2 * D];
+    g += g0; g += g1; g += g2; g += g3;
+  }
+  for (; sidx < p.S; ++sidx) g += pg[(long long)sidx * 2 * D];
+  // d total / d score = coeff * 1/2 * 1/bs * dL/ds;  d emb_hat = that * row / T
+  g *= p.coeff * 0.5f / (float)p.bs * p.inv_T;
+  // dx = (dy - y <y, dy>) / norm
+  const float dot = wave_sum(g * eh);
+  if (lane == 0) sh_dot[wave] = dot;
+  __syncthreads();
+  const float full = sh_dot[which * 2] + sh_dot[which * 2 + 1];
+  (which == 0 ? p.dv : p.da)[(long long)b * D + d] = (g - eh * full) / nrm;
+  if (wave != 0) return;
+  // the sample's loss terms: lanes 0..S-1 fetch the partials, fixed-order sum by lane 0
+  double l0 = 0, l1 = 0;
+  {
+    const double* pl = p.part_l + (long long)b * p.S * 2;
+    double a0 = 0, a1 = 0;
+    for (int base = 0; base < p.S; base += 64) {
+      const int i = base + lane;
+      const double v0 = i < p.S ? pl[2 * i] : 0.0, v1 = i < p.S ? pl[2 * i + 1] : 0.0;
+      for (int k = 0; k < 64 && base + k < p.S; ++k) { a0 += __shfl(v0, k, 64); a1 += __shfl(v1, k, 64); }
+    }
+    l0 = a0; l1 = a1;
+  }
+  unsigned last = 0;
+  if (lane == 0) {
+    __hip_atomic_store(p.samp_l + 2 * b, l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p.samp_l + 2 * b + 1, l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = atomicAdd(&p.tickets[0], 1u) == (unsigned)p.bs - 1 ? 1u : 0u;
+  }
+  last = __shfl(last, 0, 64);
+  if (!last) return;
+  __threadfence();
+  double t0 = 0, t1 = 0;
+  for (int base = 0; base < p.bs; base += 64) {      // 64 samples per trip in flight, summed in sample order
+    const int i = base + lane;
+    const double v0 = i < p.bs ? __hip_atomic_load(p.samp_l + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    const double v1 = i < p.bs ? __hip_atomic_load(p.samp_l + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    for (int k = 0; k < 64 && base + k < p.bs; ++k) { t0 += __shfl(v0, k, 64); t1 += __shfl(v1, k, 64); }
+  }
+  if (lane == 0) {
+    const float L0 = (float)(t0 / (double)p.bs), L1 = (float)(t1 / (double)p.bs);
+    p.losses[0] = L0; p.losses[1] = L1;
+    const float xl = L0 / 2.f + L1 / 2.f;            // criterions/avid.py:221-222
+    p.losses[2] = xl;
+    p.losses[3] = xl * p.coeff;
+    __hip_atomic_store(&p.tickets[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm
+  }
+}
+
+// both banks in one launch (criterions/avid.py:118-129): blockIdx.y picks the bank
+__global__ __launch_bounds__(256) void bank_update2_kernel(float* __restrict__ bank0, float* __restrict__ bank1,
+                                                           const long long* __restrict__ y, const float* __restrict__ emb0,
+                                                           const float* __restrict__ emb1, float mom0, float mom1, int B,
+                                                           int D, long long N, int* __restrict__ err) {
+  if (blockIdx.y == 0)
+    bank_update_rows(bank0, y, emb0, mom0, B, D, N, err);
+  else
+    bank_update_rows(bank1, y, emb1, mom1, B, D, N, err);
 }
 
 // criterions/avid_cma.py:196-209
@@ -497,3 +692,47 @@ extern "C" int avid_cma_negatives(int bs, int K, int P, int64_t N, const int32_t
                      P, (long long)N, err);
   return check_launch("cma_negatives");
 }
+
+extern "C" size_t avid_xmodal_fused_workspace_bytes(int bs, int K) {
+  const size_t S = (size_t)ceil_div(K + 1, SC_ROWS_PER_BLOCK);
+  return (size_t)bs * S * 2 * 128 * 4 + (size_t)bs * S * 2 * 8 + (size_t)bs * 2 * 8 + ((size_t)bs + 1) * 4 + (size_t)bs * 2 * 4 + 64;
+}
+
+extern "C" int avid_xmodal_fused(int bs, int K, int D, int64_t N, const float* v_emb, const float* a_emb, const int64_t* y,
+                                 const int64_t* idx, const float* bank_v, const float* bank_a, float inv_T, const float* Z,
+                                 float coeff, float* v_hat, float* a_hat, float* losses, float* dv, float* da, void* ws,
+                                 size_t ws_bytes, int32_t* err, avid_stream_t stream) {
+  AVID_REQUIRE(bs > 0 && K > 0 && N > 0 && v_emb && a_emb && y && idx && bank_v && bank_a && Z && v_hat && a_hat && losses &&
+                   dv && da && ws, AVID_E_BADARG, "xmodal_fused: bad argument");
+  AVID_REQUIRE(D == 128, AVID_E_UNSUPPORTED, "xmodal_fused: D=%d unsupported (128 only; use the unfused ops)", D);
+  AVID_REQUIRE(ws_bytes >= avid_xmodal_fused_workspace_bytes(bs, K), AVID_E_BADARG, "xmodal_fused: workspace too small");
+  XModalArgs a;
+  a.v_emb = v_emb; a.a_emb = a_emb; a.y = (const long long*)y; a.idx = (const long long*)idx;
+  a.bank_v = bank_v; a.bank_a = bank_a; a.Z = Z; a.v_hat = v_hat; a.a_hat = a_hat; a.losses = losses; a.dv = dv; a.da = da;
+  a.S = (int)ceil_div(K + 1, SC_ROWS_PER_BLOCK);
+  char* w = static_cast<char*>(ws);                 // (zero-filled once by the caller: the tickets re-arm themselves)
+  a.part_l = reinterpret_cast<double*>(w); w += (size_t)bs * a.S * 2 * 8;
+  a.samp_l = reinterpret_cast<double*>(w); w += (size_t)bs * 2 * 8;
+  a.part_g = reinterpret_cast<float*>(w); w += (size_t)bs * a.S * 2 * 128 * 4;
+  a.tickets = reinterpret_cast<unsigned*>(w); w += ((size_t)bs + 1) * 4;
+  a.norms = reinterpret_cast<float*>(w);
+  a.err = err; a.N = N; a.bs = bs; a.K = K; a.inv_T = inv_T; a.coeff = coeff;
+  hipStream_t s = (hipStream_t)stream;
+  // bytes: the gathered rows of both banks, read once
+  ScopedTimer t(s, "xmodal_fused_kernel", 2.0 * 2.0 * 2.0 * bs * (K + 1) * 128, 2.0 * 4.0 * bs * (K + 1) * 128.0);
+  hipLaunchKernelGGL(xmodal_fused_kernel, dim3((unsigned)a.S, (unsigned)bs), dim3(256), 0, s, a);
+  int rc = check_launch("xmodal_fused");
+  if (rc) return rc;
+  hipLaunchKernelGGL(xmodal_finish_kernel, dim3((unsigned)bs), dim3(256), 0, s, a);
+  return check_launch("xmodal_finish");
+}
+
+extern "C" int avid_bank_update2(int B, int D, int64_t N, float* bank0, float* bank1, const int64_t* y, const float* emb0,
+                                 const float* emb1, float momentum0, float momentum1, int32_t* err, avid_stream_t stream) {
+  AVID_REQUIRE(B > 0 && N > 0 && bank0 && bank1 && y && emb0 && emb1, AVID_E_BADARG, "bank_update2: bad argument");
+  AVID_REQUIRE(D > 0 && D <= 512, AVID_E_UNSUPPORTED, "bank_update2: D=%d unsupported", D);
+  hipLaunchKernelGGL(bank_update2_kernel, dim3((unsigned)ceil_div(B, 4), 2), dim3(256), 0, (hipStream_t)stream, bank0, bank1,
+                     (const long long*)y, emb0, emb1, momentum0, momentum1, B, D, (long long)N, err);
+  return check_launch("bank_update2");
+}
+

@@ -33,6 +33,7 @@ import torch.distributed as dist  # noqa: E402
 
 FWD_GFLOP_PER_CLIP = 6.418      # 2*MAC of every conv + linear at the benchmark shapes
 STEP_GFLOP_PER_CLIP = 17.83     # fwd + bwd (3x fwd minus the two never-needed stem input gradients)
+R2P1D_FWD_GFLOP_PER_CLIP = 6.159   # the video tower's forward alone
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0
 
@@ -107,10 +108,13 @@ def extra_configs(engine, model, video, audio, dev, lib, steps=10, warmup=3):
     k = lib.timing_report()
     lib.timing_enable(False)
     model.overlap_towers, ops.DEFER_WGRAD = overlap, defer
-    bsf = k.get("bank_scores_fwd_kernel")
+    # the fused criterion kernel (normalize -> gather both banks -> scores -> NCE -> gradient): its algorithmic bytes
+    # are the gathered rows of both banks, READ once (no snapshot is written any more)
+    xf = k.get("xmodal_fused_kernel")
     res["cfg5"] = {"bank_rows": N5, "clips_s": round(clips5, 1),
-                   "bank_gather_GBs": round(bsf["bytes"] / (bsf["ms"] * 1e-3) / 1e9, 1) if bsf else None,
-                   "bank_scores_fwd_us": round(bsf["ms"] / bsf["launches"] * 1e3, 2) if bsf else None}
+                   "bank_gather_read_GBs": round(xf["bytes"] / (xf["ms"] * 1e-3) / 1e9, 1) if xf else None,
+                   "bank_gather_read_bytes_per_step": int(xf["bytes"] / xf["launches"]) if xf else None,
+                   "xmodal_fused_us": round(xf["ms"] / xf["launches"] * 1e3, 2) if xf else None}
     del crit5
     torch.cuda.empty_cache()
     # ---- config 4: configs/main/avid-cma/kinetics/InstX-N1024-PosW-N64-Top32.yaml:47-62
@@ -128,6 +132,75 @@ def extra_configs(engine, model, video, audio, dev, lib, steps=10, warmup=3):
     res["cfg4"] = {"bank_rows": N4, "clips_s": round(clips4, 1), "find_correspondences_s": round(find_s, 3),
                    "search_TFLOPs": round(4.0 * N4 * N4 * 128 / find_s / 1e12, 1)}
     return res
+
+
+def reference_loop(model, crit, video, audio, ids, dev, steps=10, warmup=4):
+    """clips/s of the REFERENCE's loop shape on the same kernels (main-avid.py:155-180, utils/main_utils.py:112,250):
+    torch DistributedDataParallel around the model (one-rank group), torch.optim.Adam, and the host synchronisation
+    ``loss.item()`` between the criterion and ``zero_grad / backward / step`` — what a user of the unmodified driver gets,
+    against ``TrainStep`` (flat buffers, fused Adam, gradients written in place, helper streams, no host sync)."""
+    from torch.nn.parallel import DistributedDataParallel
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    overlap, model.overlap_towers = model.overlap_towers, False      # (DDP's reducer knows one stream)
+    try:
+        ddp = DistributedDataParallel(model, device_ids=[dev.index])
+        opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-5)
+
+        def one(i):
+            v, a = ddp(video, audio)
+            loss, _ = crit(v, a, ids[i % ids.shape[0]])
+            val = loss.item()                         # main-avid.py:174 (meters), before the backward pass
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return val
+        for i in range(warmup):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(warmup + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        del ddp, opt
+    finally:
+        model.overlap_towers = overlap
+        if own_group:
+            dist.destroy_process_group()
+    return {"clips_s": round(video.shape[0] * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "what": "torch DDP (1 rank) + torch.optim.Adam + loss.item() per step, same model / criterion kernels"}
+
+
+def forward_roofline(model, video, lib, reps=3):
+    """The R(2+1)D forward alone (BASELINE.json's target is quoted on it): HIP-event time of its MFMA kernels on one
+    stream; direct-form flops (6.159 GFLOP / clip) and the multiply-adds really executed (the Winograd
+    layers execute 16 / 36 of theirs)."""
+    with torch.no_grad():
+        model.video_model(video)
+        torch.cuda.synchronize()
+        lib.timing_enable(True)
+        for _ in range(reps):
+            model.video_model(video)
+        torch.cuda.synchronize()
+        k = lib.timing_report()
+        lib.timing_enable(False)
+    mf = {n: v for n, v in k.items() if v["flops"] > 0}
+    ms = sum(v["ms"] for v in mf.values()) / reps
+    executed = sum(v["flops"] for v in mf.values()) / reps
+    direct = R2P1D_FWD_GFLOP_PER_CLIP * 1e9 * video.shape[0]
+    all_ms = sum(v["ms"] for v in k.values()) / reps
+    return {"mfma_kernels_ms": round(ms, 3), "all_kernels_ms": round(all_ms, 3),
+            "direct_form": {"gflop_per_clip": R2P1D_FWD_GFLOP_PER_CLIP, "achieved": round(direct / (ms * 1e-3) / 1e12, 2),
+                            "frac": round(direct / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "executed": {"gflop_per_clip": round(executed / video.shape[0] / 1e9, 3),
+                         "achieved": round(executed / (ms * 1e-3) / 1e12, 2),
+                         "frac": round(executed / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "note": "frac of the 157.3 TFLOP/s fp32-MFMA peak over the video tower's forward MFMA kernels (stem, implicit "
+                    "GEMM, Winograd); direct_form prices every layer at 2*M*N*K, executed at the multiply-adds issued"}
 
 
 def main():
@@ -199,6 +272,37 @@ def main():
     for i in range(args.warmup):
         engine.step(video, audio, ids[i])
     sync()
+    # ---- distributed mode, chosen on the spot (only real peers can price it):
+    #   "early"         : every gradient bucket is all-reduced as soon as it is complete, weight gradients on the compute streams
+    #   "late"          : weight gradients trail on helper streams, every bucket is launched from GradBuckets.finish()
+    #   "early_trailing": trailing weight-gradient streams AND buckets launched as they complete
+    # three steps each, max over ranks, the fastest runs the timed region (AVID_DIST_MODE=<name> pins it)
+    dist_info = None
+    if use_dist:
+        def timed_steps(n=3):
+            sync()
+            t = time.perf_counter()
+            for i in range(n):
+                engine.step(video, audio, ids[i % total])
+            sync()
+            tt = torch.tensor([(time.perf_counter() - t) / n * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        modes = {}
+        forced = os.environ.get("AVID_DIST_MODE", "")
+        def set_mode(mode):
+            os.environ["AVID_DEFER_DIST"] = "0" if mode == "early" else "1"
+            os.environ["AVID_EARLY_BUCKETS"] = "1" if mode == "early_trailing" else "0"
+        for mode in ("early", "late", "early_trailing"):
+            if forced and forced != mode:
+                continue
+            set_mode(mode)
+            timed_steps(2)                      # settle (stream creation, RCCL channel setup for this pattern)
+            modes[mode] = timed_steps(3)
+        best = min(modes, key=modes.get)
+        set_mode(best)
+        dist_info = {"dist_mode": best, "dist_mode_ms": {k: round(v, 3) for k, v in modes.items()}}
+        engine.buckets.measure = True
     # Per-kernel HIP-event pass (events on the launch stream, library-side): a few eager steps of the same
     # workload OUTSIDE the timed region, so the instrumentation does not perturb `value`.
     # The pass runs single-stream (tower overlap off) so an event pair brackets exactly one kernel.
@@ -241,6 +345,19 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # per-rank facts for the record: device, host issue time, exposed wait for the gradient collectives
+        exposed = engine.buckets.exposed_wait_ms()
+        engine.buckets.measure = False
+        mine = torch.tensor([float(torch.cuda.current_device()), host_issue_ms, -1.0 if exposed is None else exposed],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dist_info.update({"rccl_world": dist.get_world_size(), "backend": dist.get_backend(),
+                          "devices": [int(t[0]) for t in allr],
+                          "host_issue_ms_per_rank": [round(float(t[1]), 3) for t in allr],
+                          "allreduce_exposed_ms_per_rank": [round(float(t[2]), 3) for t in allr],
+                          "bucket_count": len(engine.buckets.bounds),
+                          "gradient_bytes": int(engine.flat.numel * 4)})
     loss_val = float(loss)
 
     if rank == 0:
@@ -248,7 +365,7 @@ def main():
         clips = bs * world * args.steps / dt
         # every MFMA kernel of the step: implicit-GEMM forward / dgrad, weight gradients, the two LDS-patch stems
         mfma = {k: v for k, v in kern.items()
-                if v["flops"] > 0 and ("igemm" in k or "wgrad" in k or k.startswith("stem_") or k.startswith(("wino_kernel", "winot_kernel")))}
+                if v["flops"] > 0 and ("igemm" in k or "wgrad" in k or k.startswith("stem_") or k.startswith("wino_"))}
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         d = mfma[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -273,7 +390,7 @@ def main():
                        "per_gpu_batch": bs, "global_batch": bs * world, "bank_rows": args.bank,
                        "negatives": args.negatives, "parallelism": f"dp{world}", "optimizer": "adam(2e-4, wd 1e-5)",
                        "hipgraph": use_graph, "host_issue_ms_per_step": round(host_issue_ms, 3),
-                       "loss": round(loss_val, 5)},
+                       "loss": round(loss_val, 5), **(dist_info or {})},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
@@ -282,9 +399,16 @@ def main():
                          # every MFMA kernel of the step (the dominant one is whichever has the most time: the forward
                          # `...,0>` and the input-gradient `...,1>` instantiations of the 128x64 tile are within 2 % of
                          # each other, the latter also carries the fused BatchNorm-backward sums)
-                         "mfma_kernels": {k: {"ms_per_step": round(v["ms"] / kern_steps, 3),
-                                              "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                              "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                         "flop_accounting": "achieved / frac of every kernel = multiply-adds the kernel EXECUTES; the "
+                                            "Winograd kernels (wino_*) execute 16/36 of the direct form's: their "
+                                            "direct_equivalent figure prices the same launches at 2*M*N*K; "
+                                            "step_algorithmic and r2p1d_forward.direct_form are direct-form",
+                         "mfma_kernels": {k: dict({"ms_per_step": round(v["ms"] / kern_steps, 3),
+                                                   "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                                   "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                                   "flops": "executed"},
+                                                  **({"direct_equivalent": round(2.25 * v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                                     if k.startswith("wino_") else {}))
                                           for k, v in sorted(mfma.items(), key=lambda kv: -kv[1]["ms"])},
                          "all_conv_kernels": {"ms_per_step": round(conv_ms, 3), "achieved": round(conv_tf, 2),
                                               "frac": round(conv_tf / PEAK_F32_MFMA_TFLOPS, 4)},
@@ -303,10 +427,22 @@ def main():
                 print(f"{k:34s} {v['launches'] / kern_steps:11.1f} {v['ms'] / kern_steps:9.3f} "
                       f"{100 * v['ms'] / tot:6.1f} {tf:9.2f} {gb:10.1f}", file=sys.stderr)
             print(f"timed kernels {tot / kern_steps:.3f} ms/step of {ms:.3f} ms wall", file=sys.stderr)
+        out["roofline"]["r2p1d_forward"] = forward_roofline(model, video, lib)
         if world == 1 and not args.no_extra:
             out["extra"] = extra_configs(engine, model, video, audio, dev, lib)
+            engine.criterion = crit
+            out["extra"]["reference_loop"] = reference_loop(model, crit, video, audio, ids, dev)
+            out["extra"]["reference_loop"]["vs_trainstep"] = round(out["extra"]["reference_loop"]["clips_s"] / clips, 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        # RCCL prints a version banner through C stdio when a communicator is first created: flush it BEFORE the JSON
+        # line so that the line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

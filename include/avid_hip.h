@@ -265,6 +265,28 @@ int avid_nce_bwd(int bs, int P, int K, const float* spos, int ld_pos, const floa
 int avid_bank_update(int B, int D, int64_t N, float* bank, const int64_t* y, const float* emb,
                      float momentum, int32_t* err, avid_stream_t stream);
 
+/* Fused cross-modal criterion for the steady state (partition constant Z already frozen, criterions/nce.py:22-24):
+ * criterions/avid.py:52-71 (F.normalize of both embeddings; gather of row y and of the K negative rows idx from BOTH
+ * banks; bmm / T: v2a = video embedding . audio bank, a2v = audio embedding . video bank) + criterions/nce.py:38-58 for
+ * both score sets + the backward of all of it with respect to the two raw embeddings, formed in the same pass while a
+ * gathered row is in registers (the banks are updated before backward runs, avid.py:78 — the unfused ops keep a
+ * snapshot of the gathered rows for that; here none is needed).
+ *   v_emb, a_emb [bs][128] raw embeddings; y [bs], idx [bs][K] int64; bank_v = view1_mem, bank_a = view2_mem;
+ *   v_hat, a_hat [bs][128]: the normalised embeddings (input of the bank update / its all-gather);
+ *   losses [4]: L_v2a, L_a2v, L_v2a / 2 + L_a2v / 2 (avid.py:221-222), coeff * that (the total loss);
+ *   dv, da [bs][128]: d(total) / d(v_emb), d(total) / d(a_emb) for an upstream gradient of 1.
+ * ws: avid_xmodal_fused_workspace_bytes(bs, K) bytes, ZERO-FILLED ONCE by the caller and then owned by this op (device
+ * tickets that re-arm themselves); one per stream that may run the op concurrently.  Fixed summation order, no
+ * floating-point atomics.  D must be 128.  err: device error word (AVID_DEVERR_BANK_INDEX), may be NULL. */
+size_t avid_xmodal_fused_workspace_bytes(int bs, int K);
+int avid_xmodal_fused(int bs, int K, int D, int64_t N, const float* v_emb, const float* a_emb, const int64_t* y,
+                      const int64_t* idx, const float* bank_v, const float* bank_a, float inv_T, const float* Z,
+                      float coeff, float* v_hat, float* a_hat, float* losses, float* dv, float* da, void* ws,
+                      size_t ws_bytes, int32_t* err, avid_stream_t stream);
+/* avid_bank_update for both banks in one launch (criterions/avid.py:118-129): bank0 <- emb0 (momentum0), bank1 <- emb1; bit-identical to two avid_bank_update calls. */
+int avid_bank_update2(int B, int D, int64_t N, float* bank0, float* bank1, const int64_t* y, const float* emb0,
+                      const float* emb1, float momentum0, float momentum1, int32_t* err, avid_stream_t stream);
+
 /* memory_sampling remap — criterions/avid_cma.py:196-209.  positive_set int32 [N][P] (rows sorted);
  * pos_out [bs][P] = positive_set[y];  neg_out[b][k] = r + #{j : r >= pos_j - j}, r = rand_idx[b][k]. */
 int avid_cma_negatives(int bs, int K, int P, int64_t N, const int32_t* positive_set, const int64_t* y,

@@ -532,6 +532,66 @@ def test_bank_update(gpu_device):
     np.testing.assert_allclose(b1.cpu()[y].norm(dim=1).numpy(), 1.0, rtol=1e-6)
 
 
+@pytest.mark.parametrize("bs,K,N", [(6, 1024, 5000), (64, 1024, 240000), (3, 70, 300)])
+def test_xmodal_fused_vs_unfused_ops_and_fp64(bs, K, N, gpu_device):
+    """ops.xmodal_fused (normalize -> gather both banks -> scores / T -> NCE -> gradient, one kernel) against (a) the
+    chain of unfused ops it replaces and (b) the same arithmetic in float64 on the CPU (criterions/avid.py:52-71,
+    criterions/nce.py:38-58 with a frozen Z): losses 2e-6, gradients 2e-5 of their scale; normalised embeddings 1e-6;
+    repeated calls bit-identical (fixed summation order, re-armed tickets); bank_update_pair == two bank_update."""
+    from avid_hip import ops
+    gen = torch.Generator().manual_seed(bs * 1000 + K)
+    v1 = F.normalize(torch.randn(N, 128, generator=gen), dim=1)
+    v2 = F.normalize(torch.randn(N, 128, generator=gen), dim=1)
+    ve = torch.randn(bs, 128, generator=gen) * 2
+    ae = torch.randn(bs, 128, generator=gen) * 0.5
+    y = torch.randperm(N, generator=gen)[:bs]
+    idx = torch.randint(0, N - 1, (bs, K), generator=gen)
+    idx = idx + (idx >= y[:, None]).long()
+    Z, coeff, T_ = torch.tensor(0.83), 0.75, 0.07
+    # (b) float64
+    vr, ar = ve.double().requires_grad_(True), ae.double().requires_grad_(True)
+    vh, ah = F.normalize(vr, dim=1), F.normalize(ar, dim=1)
+    rows = torch.cat([y[:, None], idx], 1)
+    s_v2a = torch.bmm(v2.double()[rows], vh.unsqueeze(2)).squeeze(-1) / T_
+    s_a2v = torch.bmm(v1.double()[rows], ah.unsqueeze(2)).squeeze(-1) / T_
+    l1, _ = O.nce_loss(s_v2a[:, :1], s_v2a[:, 1:], Z.double())
+    l2, _ = O.nce_loss(s_a2v[:, :1], s_a2v[:, 1:], Z.double())
+    tot = (l1 / 2 + l2 / 2) * coeff
+    tot.backward()
+    # (a) device
+    b1, b2 = v1.to(gpu_device), v2.to(gpu_device)
+    vd, ad = ve.to(gpu_device).requires_grad_(True), ae.to(gpu_device).requires_grad_(True)
+    ws = ops.xmodal_fused_workspace(gpu_device, bs, K)
+    outs = [ops.xmodal_fused(vd, ad, y.to(gpu_device), idx.to(gpu_device), b1, b2, Z.to(gpu_device), 1 / T_, coeff, ws)
+            for _ in range(3)]
+    total, losses, hats = outs[0]
+    assert all(torch.equal(o[0], total) and torch.equal(o[1], losses) and torch.equal(o[2], hats) for o in outs[1:])
+    (total * 2.0).backward()                                         # the upstream gradient scales the stored one
+    np.testing.assert_allclose(losses.cpu().numpy(), [float(l1), float(l2), float(l1 / 2 + l2 / 2), float(tot)], rtol=2e-6)
+    assert relerr(hats[0], vh.detach()) < 1e-6 and relerr(hats[1], ah.detach()) < 1e-6
+    assert relerr(vd.grad, 2.0 * vr.grad) < 2e-5 and relerr(ad.grad, 2.0 * ar.grad) < 2e-5
+    # unfused chain on the device
+    vu, au = ve.to(gpu_device).requires_grad_(True), ae.to(gpu_device).requires_grad_(True)
+    vhu, ahu = ops.l2_normalize(vu), ops.l2_normalize(au)
+    rows_d = rows.to(gpu_device)
+    su1 = ops.bank_scores(vhu, b2, rows_d, 1 / T_)
+    su2 = ops.bank_scores(ahu, b1, rows_d, 1 / T_)
+    lu = (ops.nce_loss(*ops.split_scores(su1, 1), Z.to(gpu_device)) / 2 + ops.nce_loss(*ops.split_scores(su2, 1), Z.to(gpu_device)) / 2) * coeff
+    (lu * 2.0).backward()
+    np.testing.assert_allclose(float(total), float(lu), rtol=2e-6)
+    assert relerr(vd.grad, vu.grad) < 2e-5 and relerr(ad.grad, au.grad) < 2e-5
+    # both banks in one launch == two launches, bit for bit (incl. a duplicate id)
+    y2 = y.clone()
+    if bs > 2:
+        y2[2] = y2[0]
+    p1, p2, q1, q2 = b1.clone(), b2.clone(), b1.clone(), b2.clone()
+    ops.bank_update_pair(p1, p2, y2.to(gpu_device), hats[0], hats[1], 0.5, 0.9)
+    ops.bank_update(q1, y2.to(gpu_device), hats[0], 0.5)
+    ops.bank_update(q2, y2.to(gpu_device), hats[1], 0.9)
+    assert torch.equal(p1, q1) and torch.equal(p2, q2)
+    ops.check_device_errors(gpu_device)
+
+
 def test_cma_negatives_bit_exact(golden, gpu_device):
     from avid_hip import ops
     g = golden("cma")

@@ -76,21 +76,29 @@ def _set_banks(crit, rank):
 
 
 class _RecordUpdates:
-    """Wraps ops.bank_update: keeps (y_all, emb_all, rows before) of every call."""
+    """Wraps ops.bank_update / ops.bank_update_pair: keeps (y_all, emb_all, rows before) of every bank's update, in
+    the order view1_mem, view2_mem."""
 
     def __init__(self):
         from avid_hip import ops
-        self.ops, self.orig, self.calls = ops, ops.bank_update, []
+        self.ops, self.orig, self.orig_pair, self.calls = ops, ops.bank_update, ops.bank_update_pair, []
 
     def __enter__(self):
         def wrapped(bank, y, emb, momentum):
             self.calls.append((y.clone().cpu(), emb.clone().cpu(), bank[y].clone().cpu()))
             return self.orig(bank, y, emb, momentum)
+
+        def wrapped_pair(bank0, bank1, y, emb0, emb1, m0, m1):
+            self.calls.append((y.clone().cpu(), emb0.clone().cpu(), bank0[y].clone().cpu()))
+            self.calls.append((y.clone().cpu(), emb1.clone().cpu(), bank1[y].clone().cpu()))
+            return self.orig_pair(bank0, bank1, y, emb0, emb1, m0, m1)
         self.ops.bank_update = wrapped
+        self.ops.bank_update_pair = wrapped_pair
         return self
 
     def __exit__(self, *exc):
         self.ops.bank_update = self.orig
+        self.ops.bank_update_pair = self.orig_pair
         return False
 
 
@@ -171,6 +179,8 @@ def _ddp_job(rank, world, out):
     crit = _criterion(dev, rank)
     _set_banks(crit, rank)
     crit.criterion.avg_exp_score.fill_(float(os.environ["TWO_RANK_Z"]))
+    from avid_hip import ops
+    ops.FUSED_CRITERION = False          # compared bit for bit with _single(), which runs the unfused criterion ops
     ddp = DDP(m, device_ids=[0])
     video, audio = _inputs()
     v = video[rank * BS:(rank + 1) * BS].to(dev)
@@ -229,8 +239,15 @@ def _single(gpu_device, rank, Z):
     v = video[rank * BS:(rank + 1) * BS].to(gpu_device)
     a = audio[rank * BS:(rank + 1) * BS].to(gpu_device)
     y = torch.tensor(IDS[0][rank * BS:(rank + 1) * BS], dtype=torch.int64, device=gpu_device)
-    with _RecordUpdates() as rec:
-        loss = eng.forward_backward(v, a, y)
+    # (the two-rank job's step 0 estimates Z and therefore runs the unfused criterion ops; with Z preset this run would
+    # take the fused kernel, whose loss differs in the last bits — compare like with like)
+    from avid_hip import ops
+    fused, ops.FUSED_CRITERION = ops.FUSED_CRITERION, False
+    try:
+        with _RecordUpdates() as rec:
+            loss = eng.forward_backward(v, a, y)
+    finally:
+        ops.FUSED_CRITERION = fused
     return {"loss": float(loss), "grad": eng.flat.grad.clone(), "Z": crit.criterion.avg_exp_score.clone().cpu(),
             "emb": [c[1] for c in rec.calls], "eng": eng, "model": m}
 
