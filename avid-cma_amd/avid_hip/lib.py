@@ -42,6 +42,11 @@ class ConvDesc(C.Structure):
         "st", "sh", "sw", "pt", "ph", "pw", "x_channel_first")]
 
 
+class WgradItem(C.Structure):
+    """Mirror of ``avid_wgrad_item`` (include/avid_hip.h)."""
+    _fields_ = [("d", ConvDesc), ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p)]
+
+
 def build_library(verbose=False):
     """Compile csrc/*.hip for gfx950 into avid_hip/libavid_hip.so (hipcc cross-compiles without a GPU)."""
     proc = subprocess.run(["make", "-C", _PKG, "-j8"], capture_output=True, text=True)
@@ -85,6 +90,9 @@ SIGNATURES = {
     "avid_weight_transpose_batched": (_i, [_i, _vp, _i64, _vp]),
     "avid_conv_wgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_wgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avid_conv_wgrad_groupable": (_i, [_dp]),
+    "avid_conv_wgrad_group_workspace_bytes": (_sz, [_i, C.POINTER(WgradItem)]),
+    "avid_conv_wgrad_group": (_i, [_i, C.POINTER(WgradItem), _vp, _sz, _vp]),
     "avid_conv_kernel_name": (_i, [_dp, _i, C.c_char_p, _i]),
     "avid_wino_configure": (_i, [_i, _i64, _i]),
     "avid_bn_workspace_bytes": (_sz, [_i64, _i]),

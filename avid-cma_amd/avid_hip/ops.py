@@ -60,6 +60,86 @@ def join_deferred_wgrads():
         _DEFER_USED.clear()
 
 
+# ------------------------------------------------------------------------------------------------
+# grouped weight gradients: the small layers' wgrads of a backward pass are queued (per compute stream) and launched a
+# dozen at a time as ONE persistent kernel (avid_conv_wgrad_group) — only where the gradients land in the flat buffer
+# (GradSlots armed by parallel.TrainStep), because the launch happens later than the autograd node that produced dy
+# ------------------------------------------------------------------------------------------------
+GROUP_WGRAD = int(os.environ.get("AVID_GROUP_WGRAD", "1"))
+GROUP_MAX = 12
+_GROUP_PENDING = {}        # compute stream handle -> [(desc, x, dy, dst, slot)]
+_GROUP_WS_BYTES = {}       # tuple of layer geometries -> workspace bytes
+
+
+def _group_key(device):
+    return (device.index, _raw_stream(device.index) if _raw_stream is not None
+            else torch.cuda.current_stream(device).cuda_stream)
+
+
+def queue_wgrad(d, x, dy, dst, slot):
+    key = _group_key(x.device)
+    lst = _GROUP_PENDING.setdefault(key, [])
+    lst.append((d, x, dy, dst, slot))
+    if len(lst) >= GROUP_MAX:
+        flush_wgrad_group(x.device)
+
+
+def flush_wgrad_group(device=None, all_streams=False):
+    """Launch the queued weight gradients of the current stream (``all_streams``: of every stream, each on its own —
+    the caller has made the current stream wait for them or will) and report their parameters as ready."""
+    keys = list(_GROUP_PENDING) if all_streams else [_group_key(device)]
+    for key in keys:
+        lst = _GROUP_PENDING.get(key)
+        if not lst:
+            continue
+        _GROUP_PENDING[key] = []
+        _launch_wgrad_group(lst, key)
+
+
+def _launch_wgrad_group(lst, key):
+    n = len(lst)
+    items = (lib.WgradItem * n)()
+    for i, (d, x, dy, dst, _) in enumerate(lst):
+        items[i].d = d
+        items[i].x, items[i].dy, items[i].dw = x.data_ptr(), dy.data_ptr(), dst.data_ptr()
+    geo = tuple(id(t[0]) for t in lst)              # (descriptors are cached per layer geometry: ids are stable)
+    nb = _GROUP_WS_BYTES.get(geo)
+    if nb is None:
+        nb = _GROUP_WS_BYTES[geo] = lib.raw("avid_conv_wgrad_group_workspace_bytes")(n, items)
+    dev = lst[0][1].device
+    cur_handle = _group_key(dev)[1]
+    if cur_handle == key[1]:
+        stream_ctx = None
+    else:                                           # flushing another compute stream's queue: launch it over there
+        stream_ctx = torch.cuda.stream(torch.cuda.ExternalStream(key[1], device=dev))
+
+    def launch():
+        capturing = torch.cuda.is_current_stream_capturing()
+        if (_DEFER_ON and (DEFER_IN_CAPTURE or not capturing)):
+            main, trail = wgrad_stream(dev)
+            trail.wait_stream(main)                 # every dy of the group is complete on its compute stream
+            with torch.cuda.stream(trail):
+                ws = workspace(dev, nb)
+                lib.call("avid_conv_wgrad_group", n, items, _p(ws), ws.numel(), _stream())
+            if not capturing:
+                for _, x, dy, _, _ in lst:
+                    x.record_stream(trail)
+                    dy.record_stream(trail)
+            _DEFER_USED.add(trail)
+        else:
+            ws = workspace(dev, nb)
+            lib.call("avid_conv_wgrad_group", n, items, _p(ws), ws.numel(), _stream())
+        for t in lst:
+            _grad_done(t[4])
+    if stream_ctx is None:
+        launch()
+    else:
+        ext = torch.cuda.ExternalStream(key[1], device=dev)
+        with stream_ctx:
+            launch()
+        torch.cuda.current_stream(dev).wait_stream(ext)       # (a late flush of the other tower's queue)
+
+
 class deferred_wgrads:
     """``with ops.deferred_wgrads(): loss.backward()`` — weight gradients may trail on helper streams inside; they
     are joined on exit."""
@@ -75,6 +155,7 @@ class deferred_wgrads:
 
     def __exit__(self, *exc):
         global _DEFER_ON
+        flush_wgrad_group(all_streams=True)        # (while the trailing streams are still on)
         _DEFER_ON = self.prev
         join_deferred_wgrads()
         return False
@@ -219,6 +300,7 @@ def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
                lib.raw("avid_conv_wgrad_workspace_bytes")(C.byref(d)),
                lib.raw("avid_conv_fwd_stats_rows")(C.byref(d)))
         d.bn_bwd_rows = 0 if channel_first else lib.raw("avid_conv_dgrad_bn_rows")(C.byref(d))
+        d.groupable = bool(lib.raw("avid_conv_wgrad_groupable")(C.byref(d)))
         _DESC_CACHE[key] = hit
     return hit
 
@@ -496,7 +578,17 @@ class _ConvCL(Function):
         side = None
         deferred = False
         capturing = torch.cuda.is_current_stream_capturing()
-        if (need_dw and _DEFER_ON and _SLOTS is not None and (DEFER_IN_CAPTURE or not capturing)
+        grouped = False
+        if need_dw and GROUP_WGRAD and _SLOTS is not None and d.groupable and _SLOTS.has_slot(w.data_ptr()):
+            # a small layer: its weight gradient rides in the next grouped launch of this compute stream
+            g, slot = _grad_dst(w.data_ptr(), like=w)
+            if g.stride() != w.stride() and not weight_layout_ok(g):
+                raise AvidHipError("conv: the weight-gradient tensor does not have the [Cout][k][Cin] layout")
+            queue_wgrad(d, x, dy, g, slot)
+            dw = None
+            need_dw = False
+            grouped = True
+        elif (need_dw and _DEFER_ON and _SLOTS is not None and (DEFER_IN_CAPTURE or not capturing)
                 and _SLOTS.has_slot(w.data_ptr())):
             main, trail = wgrad_stream(x.device)
             trail.wait_stream(main)            # dy (after the ReLU mask) is complete
@@ -537,7 +629,10 @@ class _ConvCL(Function):
                         _grad_done(slot)
                         return None
                     return g
-                if deferred and _SLOTS.has_slot(res_w.data_ptr()):
+                if GROUP_WGRAD and _SLOTS is not None and dr.groupable and _SLOTS.has_slot(res_w.data_ptr()):
+                    g, slot = _grad_dst(res_w.data_ptr(), like=res_w)
+                    queue_wgrad(dr, x, d_res, g, slot)
+                elif deferred and _SLOTS.has_slot(res_w.data_ptr()):
                     main, trail = wgrad_stream(x.device)
                     trail.wait_stream(main)
                     with torch.cuda.stream(trail):
@@ -567,7 +662,7 @@ class _ConvCL(Function):
                 if dw is not None:
                     dw.record_stream(torch.cuda.current_stream())
                 dy.record_stream(side)
-        elif need_dw and not deferred:
+        elif need_dw and not deferred and not grouped:
             dw = run_wgrad()
         if ctx.has_addend and ctx.needs_input_grad[2]:
             dadd = dy

@@ -1364,6 +1364,8 @@ struct WgradArgs {
   long long ssB, ssT, ssH, ssW, ssC;
   unsigned mgW, mgH, mgT;        // multiply-shift division by Wd, Hd, Td
   int shW, shH, shT;
+  int out_ld, out_koff;          // row pitch / first column of a tile's destination row (0 / 0: K, 0 — slabs [Cd][K])
+  long long out_split;           // elements between the slabs of two splits (0: Cd * K)
 };
 
 constexpr int WG_LD = 64 + 4;
@@ -1384,8 +1386,7 @@ constexpr int WG_LD = 64 + 4;
 constexpr int WG_TABC = 32;   // chunks (of 32 pixel rows) covered by one fill of the row table: 1024 rows, 8 KB
 
 template <int NB, int KC>
-__global__ __launch_bounds__(256, 2) void wgrad_tab_kernel(const WgradArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void wgrad_tab_body(const WgradArgs& p, const unsigned lid, float* smem) {
   constexpr int DW = 64 * NB + 4;                 // dy tile row (floats)
   constexpr int BUF = 32 * (DW + KC * WG_LD);     // one stage
   uint2* tab = reinterpret_cast<uint2*>(smem + 2 * BUF);
@@ -1396,7 +1397,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tab_kernel(const WgradArgs p) {
   const int K = ntaps * p.Cs;
   const int cpt = p.Cs / 64, nchunks = ntaps * cpt;
 
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);   // dw tiles of one pixel range stay on one XCD
   const int bx = (int)(lid % (unsigned)p.tiles), by = (int)(lid / (unsigned)p.tiles);
   const int ktile = bx % p.kt_tiles, ntile = bx / p.kt_tiles;
   const int n0 = ntile * 64 * NB;
@@ -1560,7 +1560,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tab_kernel(const WgradArgs p) {
     u ^= 1;
   }
 
-  float* o = p.out + (long long)by * p.Cd * K;
+  const int ld = p.out_ld ? p.out_ld : K;
+  float* o = p.out + (long long)by * (p.out_split ? p.out_split : (long long)p.Cd * K) + p.out_koff;
 #pragma unroll
   for (int t = 0; t < NB; ++t)
 #pragma unroll
@@ -1570,9 +1571,90 @@ __global__ __launch_bounds__(256, 2) void wgrad_tab_kernel(const WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm * 32 * NB + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        o[(long long)n * K + kcol] = acc[t][j][r];
+        o[(long long)n * ld + kcol] = acc[t][j][r];
       }
     }
+}
+
+template <int NB, int KC>
+__global__ __launch_bounds__(256, 2) void wgrad_tab_kernel(const WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  wgrad_tab_body<NB, KC>(p, xcd_remap(blockIdx.x, gridDim.x), smem);   // dw tiles of one pixel range stay on one XCD
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouped weight gradients: the small layers of the network (conv3x-5x temporal / strided / residual layers, the audio
+// blocks, the heads: 128 x 128 dw tiles, a few dozen to a few hundred pixel chunks each) in ONE persistent launch over
+// a table of layers.  A launch per layer had to cut every layer into enough K-splits to fill the chip by itself (3 - 14
+// slabs per layer, 1.77x the algorithmic HBM traffic, a reduce launch each) and paid a ramp and a drain per layer; with
+// the layers of a stage in one grid the planner sizes the items of ALL layers to one common number of chunks, most
+// layers need no split at all (their tiles are written straight into the gradient buffer) and the few slabs left are
+// summed by one grouped reduce.
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_GROUP_MAX = 12;
+struct WgradGroupArgs {
+  WgradArgs layer[WG_GROUP_MAX];
+  int item0[WG_GROUP_MAX + 1];       // first item of every layer; item0[n] = number of items
+  int n;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const WgradGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int total = g.item0[g.n];
+  for (int item = (int)blockIdx.x; item < total; item += (int)gridDim.x) {
+    int l = 0;
+    while (l + 1 < g.n && item >= g.item0[l + 1]) ++l;
+    wgrad_tab_body<2, 2>(g.layer[l], (unsigned)(item - g.item0[l]), smem);
+    __syncthreads();                 // the next item refills the row table and both stages
+  }
+}
+
+struct WgradGroupReduce {
+  const float* part[WG_GROUP_MAX];
+  float* dw[WG_GROUP_MAX];
+  long long n[WG_GROUP_MAX];         // elements of one slab
+  int nsplit[WG_GROUP_MAX];
+  int Kp[WG_GROUP_MAX], K[WG_GROUP_MAX], koff[WG_GROUP_MAX];    // slab row [Kp] -> dw row [K] at column koff (Kp == K: plain)
+  int count;
+};
+
+// the slabs of every split (or tap-trimmed) layer of a group, summed in split order (blockIdx.y = layer); the kernel
+// walks dw, so the columns of dead temporal taps are written as zeros
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(const WgradGroupReduce r) {
+  __shared__ floatx4 sh[8][32];
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5, y = blockIdx.y;
+  const long long n4 = r.n[y] >> 2;                       // float4 elements of dw
+  const int nsplit = r.nsplit[y];
+  const int k4 = r.K[y] >> 2, kp4 = r.Kp[y] >> 2, ko4 = r.koff[y] >> 2;
+  const long long slab4 = (n4 / k4) * kp4;
+  const floatx4* p4 = reinterpret_cast<const floatx4*>(r.part[y]);
+  for (long long base = (long long)blockIdx.x * 32; base < n4; base += (long long)gridDim.x * 32) {
+    const long long i = base + e;
+    floatx4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+    if (i < n4) {
+      const long long row = i / k4;
+      const int c = (int)(i - row * k4);
+      if (c >= ko4 && c < ko4 + kp4) {
+        const long long j = row * kp4 + (c - ko4);
+        int k = sl;
+        for (; k + 24 < nsplit; k += 32) {
+          const floatx4 v0 = p4[(long long)k * slab4 + j], v1 = p4[(long long)(k + 8) * slab4 + j],
+                        v2 = p4[(long long)(k + 16) * slab4 + j], v3 = p4[(long long)(k + 24) * slab4 + j];
+          s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; k < nsplit; k += 8) s0 += p4[(long long)k * slab4 + j];
+      }
+    }
+    __syncthreads();
+    sh[sl][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && i < n4) {
+      floatx4 t = sh[0][e];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += sh[k][e];
+      reinterpret_cast<floatx4*>(r.dw[y])[i] = t;
+    }
+  }
 }
 
 // gather-path wgrad (stems): 64(n) x 64(k) tile, k -> tap table in LDS
@@ -2778,6 +2860,25 @@ static WgradPlan wgrad_plan(const avid_conv_desc* d) {
   return pl;
 }
 
+// kernel arguments of one layer (d: the layer with its dead temporal taps already trimmed)
+static void fill_wgrad_args(WgradArgs& a, const avid_conv_desc* d, const float* x, const float* dy, float* out,
+                            const WgradPlan& pl) {
+  memset(&a, 0, sizeof(a));
+  a.src = x; a.dy = dy; a.out = out;
+  a.B = d->B; a.Ts = d->Ti; a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Cin;
+  a.Td = d->To; a.Hd = d->Ho; a.Wd = d->Wo; a.Cd = d->Cout;
+  a.kt = d->kt; a.kh = d->kh; a.kw = d->kw;
+  a.st = d->st; a.sh = d->sh; a.sw = d->sw;
+  a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
+  a.M = d->B * d->To * d->Ho * d->Wo;
+  a.nsplit = pl.nsplit; a.chunks_per_split = pl.cps; a.kt_tiles = pl.kt_tiles;
+  a.tiles = pl.kt_tiles * pl.n_tiles;
+  magic_for(a.Wd, a.mgW, a.shW);
+  magic_for(a.Hd, a.mgH, a.shH);
+  magic_for(a.Td, a.mgT, a.shT);
+  fill_src_strides(d, a.ssB, a.ssT, a.ssH, a.ssW, a.ssC);
+}
+
 extern "C" size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   const Trim tr = trim_taps(d);      // (a trimmed layer always goes through slabs: the reduce scatters them into dw)
@@ -2815,20 +2916,7 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
                "conv_wgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   WgradArgs a;
-  a.src = x; a.dy = dy;
-  a.out = (pl.nsplit == 1 && !tr.on) ? dw : static_cast<float*>(ws);
-  a.B = d->B; a.Ts = d->Ti; a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Cin;
-  a.Td = d->To; a.Hd = d->Ho; a.Wd = d->Wo; a.Cd = d->Cout;
-  a.kt = d->kt; a.kh = d->kh; a.kw = d->kw;
-  a.st = d->st; a.sh = d->sh; a.sw = d->sw;
-  a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
-  a.M = d->B * d->To * d->Ho * d->Wo;
-  a.nsplit = pl.nsplit; a.chunks_per_split = pl.cps; a.kt_tiles = pl.kt_tiles;
-  a.tiles = pl.kt_tiles * pl.n_tiles;
-  magic_for(a.Wd, a.mgW, a.shW);
-  magic_for(a.Hd, a.mgH, a.shH);
-  magic_for(a.Td, a.mgT, a.shT);
-  fill_src_strides(d, a.ssB, a.ssT, a.ssH, a.ssW, a.ssC);
+  fill_wgrad_args(a, d, x, dy, (pl.nsplit == 1 && !tr.on) ? dw : static_cast<float*>(ws), pl);
   dim3 grid((unsigned)(pl.kt_tiles * pl.n_tiles), (unsigned)pl.nsplit);
   dim3 grid_pp((unsigned)(pl.kt_tiles * pl.n_tiles), (unsigned)((pl.nsplit + 1) / 2));   // two splits per workgroup
   {
@@ -2877,6 +2965,163 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
     rc = check_launch("wgrad_reduce");
   }
   return rc;
+}
+
+// ---- grouped weight gradients (wgrad_group_kernel)
+extern "C" int avid_conv_wgrad_groupable(const avid_conv_desc* d) {
+  if (!d || validate(d)) return 0;
+  if (stem_wgrad_supported(d) || wino_wgrad_supported(d)) return 0;
+  const Trim tr = trim_taps(d);
+  const WgradPlan pl = wgrad_plan(&tr.d);
+  return pl.vec && pl.NB == 2 && pl.KC == 2;
+}
+
+struct GroupLayer {
+  Trim tr;
+  WgradPlan pl;       // kt_tiles / n_tiles of the trimmed layer; nsplit / cps chosen by the group planner
+  long long chunks;
+  bool slab;          // through a slab + the grouped reduce (K-split, or dead taps whose dw columns must be zeroed)
+  size_t slab_off;    // floats into ws
+};
+
+// One common item size for all layers of the group: C pixel chunks (of 32 rows) per item.  Estimated time in chunk units
+// (a chunk of a 128 x 128 tile = 64 MFMAs per wave, ~2 us): rounds of items over the chip's 512 workgroup slots, each
+// item C chunks + ~1.5 for its set-up and its stores, + the slab traffic of the split layers at ~4 TB/s.
+static int plan_group(int n, const avid_wgrad_item* items, GroupLayer* L, int* item0, size_t* ws_floats, int* order) {
+  const int slots = 2 * device_cus();
+  long long maxc = 1;
+  for (int l = 0; l < n; ++l) {
+    L[l].tr = trim_taps(&items[l].d);
+    L[l].pl = wgrad_plan(&L[l].tr.d);
+    const avid_conv_desc* d = &L[l].tr.d;
+    L[l].chunks = ceil_div((long long)d->B * d->To * d->Ho * d->Wo, 32);
+    if (L[l].chunks > maxc) maxc = L[l].chunks;
+  }
+  auto splits_for = [&](int l, long long C) {
+    const avid_conv_desc* d = &L[l].tr.d;
+    long long ns = ceil_div(L[l].chunks, C);
+    // 32-bit byte offsets inside one split (as wgrad_plan): (batch items touched) * bytes per input item < 2 GiB
+    const long long pix_out = (long long)d->To * d->Ho * d->Wo, per_b_in = (long long)d->Ti * d->Hi * d->Wi * d->Cin * 4;
+    while (ns < L[l].chunks && (ceil_div(L[l].chunks, ns) * 32 / pix_out + 2) * per_b_in >= (1ll << 31)) ns *= 2;
+    if (ns > L[l].chunks) ns = L[l].chunks;
+    if (ns > 512) ns = 512;
+    return ns;
+  };
+  double best = 1e300;
+  long long bestC = maxc;
+  for (long long C = maxc; C >= 2; C = C > 48 ? C - C / 12 : C - 1) {
+    double nitems = 0, slab_bytes = 0, work = 0, biggest = 0;
+    for (int l = 0; l < n; ++l) {
+      const long long ns = splits_for(l, C), tiles = (long long)L[l].pl.kt_tiles * L[l].pl.n_tiles;
+      const double cost = (double)ceil_div(L[l].chunks, ns) + 1.5;
+      nitems += (double)tiles * ns;
+      work += (double)tiles * ns * cost;
+      if (cost > biggest) biggest = cost;
+      if (ns > 1) slab_bytes += 2.0 * 4.0 * ns * items[l].d.Cout * L[l].tr.d.kt * items[l].d.kh * items[l].d.kw * items[l].d.Cin;
+    }
+    // items are dealt round-robin in order of decreasing cost: the last workgroup finishes about one average item after
+    // the mean load, and never before the biggest item
+    double t = work / slots + 0.5 * work / nitems;
+    if (t < biggest) t = biggest;
+    t += slab_bytes / 4e12 / 2e-6;
+    if (t < best) { best = t; bestC = C; }
+  }
+  size_t off = 0;
+  for (int l = 0; l < n; ++l) {
+    const long long ns = splits_for(l, bestC);
+    L[l].pl.cps = (int)ceil_div(L[l].chunks, ns);
+    L[l].pl.nsplit = (int)ceil_div(L[l].chunks, L[l].pl.cps);
+    L[l].slab = L[l].pl.nsplit > 1 || L[l].tr.on;
+    L[l].slab_off = off;
+    if (L[l].slab)
+      off += (size_t)L[l].pl.nsplit * items[l].d.Cout * L[l].tr.d.kt * items[l].d.kh * items[l].d.kw * items[l].d.Cin;
+    order[l] = l;
+  }
+  for (int a = 1; a < n; ++a)                      // table order: decreasing item cost (insertion sort, stable)
+    for (int b = a; b > 0 && L[order[b]].pl.cps > L[order[b - 1]].pl.cps; --b) {
+      const int tmp = order[b]; order[b] = order[b - 1]; order[b - 1] = tmp;
+    }
+  int it = 0;
+  for (int k = 0; k < n; ++k) {
+    const int l = order[k];
+    item0[k] = it;
+    it += L[l].pl.kt_tiles * L[l].pl.n_tiles * L[l].pl.nsplit;
+  }
+  item0[n] = it;
+  *ws_floats = off;
+  return AVID_OK;
+}
+
+extern "C" size_t avid_conv_wgrad_group_workspace_bytes(int n, const avid_wgrad_item* items) {
+  if (n <= 0 || n > WG_GROUP_MAX || !items) return 0;
+  GroupLayer L[WG_GROUP_MAX];
+  int item0[WG_GROUP_MAX + 1], order[WG_GROUP_MAX];
+  size_t fl = 0;
+  for (int l = 0; l < n; ++l)
+    if (!avid_conv_wgrad_groupable(&items[l].d)) return 0;
+  plan_group(n, items, L, item0, &fl, order);
+  return sizeof(float) * fl + 256;
+}
+
+extern "C" int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* ws, size_t ws_bytes,
+                                     avid_stream_t stream) {
+  AVID_REQUIRE(n > 0 && n <= WG_GROUP_MAX && items, AVID_E_BADARG, "conv_wgrad_group: 1..%d layers", WG_GROUP_MAX);
+  for (int l = 0; l < n; ++l) {
+    AVID_REQUIRE(items[l].x && items[l].dy && items[l].dw, AVID_E_BADARG, "conv_wgrad_group: null pointer (layer %d)", l);
+    AVID_REQUIRE(avid_conv_wgrad_groupable(&items[l].d), AVID_E_UNSUPPORTED,
+                 "conv_wgrad_group: layer %d does not run on wgrad_tab_kernel<2,2> (avid_conv_wgrad_groupable)", l);
+  }
+  GroupLayer L[WG_GROUP_MAX];
+  WgradGroupArgs g;
+  size_t fl = 0;
+  int order[WG_GROUP_MAX];
+  plan_group(n, items, L, g.item0, &fl, order);
+  AVID_REQUIRE(fl == 0 || (ws && ws_bytes >= sizeof(float) * fl), AVID_E_BADARG, "conv_wgrad_group: workspace too small");
+  g.n = n;
+  WgradGroupReduce r;
+  memset(&r, 0, sizeof(r));
+  double flops = 0, bytes = 0, red_bytes = 0;
+  long long max_n4 = 0;
+  for (int k = 0; k < n; ++k) {
+    const int l = order[k];                            // table slot k holds layer l
+    const avid_conv_desc* d = &L[l].tr.d;
+    const int tap = d->kh * d->kw * d->Cin, Kp = d->kt * tap, K = L[l].tr.kt_full * tap, koff = L[l].tr.dt0 * tap;
+    float* slab = static_cast<float*>(ws) + L[l].slab_off;
+    fill_wgrad_args(g.layer[k], d, items[l].x, items[l].dy, L[l].slab ? slab : items[l].dw, L[l].pl);
+    if (L[l].slab) {
+      const int y = r.count++;
+      r.part[y] = slab; r.dw[y] = items[l].dw;
+      r.n[y] = (long long)d->Cout * K;                 // dw elements (the reduce walks dw: dead-tap columns get zeros)
+      r.nsplit[y] = L[l].pl.nsplit;
+      r.Kp[y] = Kp; r.K[y] = K; r.koff[y] = koff;
+      if (r.n[y] / 4 > max_n4) max_n4 = r.n[y] / 4;
+      red_bytes += 4.0 * ((double)d->Cout * Kp * L[l].pl.nsplit + (double)d->Cout * K);
+    }
+    const double M = (double)d->B * d->To * d->Ho * d->Wo;
+    flops += 2.0 * M * d->Cout * Kp;
+    bytes += 4.0 * ((double)d->B * d->Ti * d->Hi * d->Wi * d->Cin + M * d->Cout + (double)d->Cout * Kp);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = sizeof(float) * 2 * 32 * (64 * 2 + 4 + 2 * WG_LD) + sizeof(uint2) * WG_TABC * 32;
+  static bool set = false;
+  if (!set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    set = true;
+  }
+  int grid = g.item0[n];
+  if (grid > 2 * device_cus()) grid = 2 * device_cus();
+  {
+    ScopedTimer t(s, "wgrad_group_kernel", flops, bytes);
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)grid), dim3(256), lds, s, g);
+  }
+  int rc = check_launch("wgrad_group");
+  if (rc || r.count == 0) return rc;
+  long long gx = ceil_div(max_n4, 32);
+  if (gx > 512) gx = 512;
+  ScopedTimer t(s, "wgrad_group_reduce_kernel", 0.0, red_bytes);
+  hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3((unsigned)gx, (unsigned)r.count), dim3(256), 0, s, r);
+  return check_launch("wgrad_group_reduce");
 }
 
 extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* buf, int len) {

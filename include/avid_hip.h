@@ -137,6 +137,23 @@ size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d);
 int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,
                     size_t ws_bytes, avid_stream_t stream);
 
+/* The weight gradients of up to 12 layers in ONE persistent launch (+ one grouped reduce): the small layers of a stage
+ * (conv3x-5x temporal / strided / residual convolutions, audio blocks, heads — backward of models/network_blocks.py:
+ * 18,20,37,42,49 and models/av_wrapper.py:25).  A launch per layer has to K-split every layer until it fills the chip
+ * alone; in a group the items of all layers share one size and most layers need no split (their dw is written
+ * directly).  Only layers for which avid_conv_wgrad_groupable() is 1 (128-wide dw tiles, not a stem, not on the
+ * Winograd path).  Every dw is fully written (dead temporal taps as zeros).  Results equal avid_conv_wgrad's up to the
+ * summation order over pixel chunks. */
+typedef struct avid_wgrad_item {
+  avid_conv_desc d;
+  const float* x;
+  const float* dy;
+  float* dw;
+} avid_wgrad_item;
+int avid_conv_wgrad_groupable(const avid_conv_desc* d);
+size_t avid_conv_wgrad_group_workspace_bytes(int n, const avid_wgrad_item* items);
+int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* ws, size_t ws_bytes, avid_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm (train / eval) over a channels-last [M, C] view, fused ReLU.
  * Replaces nn.BatchNorm3d/2d + nn.ReLU: models/network_blocks.py:19,21,36,38,41,43,54-59,

@@ -170,6 +170,71 @@ def test_bn_backward_partials_from_dgrad(shape, cmid, cout, k, pad, stride, gpu_
             assert relerr(b, a) < 2e-5
 
 
+GROUP_LAYERS = [
+    # Cin, Cout, k, stride, pad, (B, T, H, W): the small layers of the model at a small batch + the shapes that take the
+    # special paths inside a group: dead temporal taps (T = 1), strided, 1x1x1 residual, a linear layer, a K-split one
+    (512, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (16, 1, 4, 4)),       # dead taps: only the centre tap is live
+    (256, 512, (1, 3, 3), (1, 2, 2), (0, 1, 1), (8, 2, 7, 7)),
+    (256, 512, (1, 1, 1), (2, 2, 2), (0, 0, 0), (8, 2, 7, 7)),
+    (512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 1, 4, 4)),
+    (512, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (40, 1, 1, 1)),       # a head's linear layer
+    (128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (4, 4, 14, 14)),      # many pixel chunks: gets K-split inside the group
+    (64, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (3, 4, 9, 11)),
+    (128, 256, (3, 1, 1), (2, 1, 1), (1, 0, 0), (5, 4, 7, 7)),
+    (256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 2, 7, 7)),
+    (128, 128, (3, 1, 1), (2, 1, 1), (1, 0, 0), (8, 2, 4, 4)),        # T = 2 -> 1: the first tap is dead
+    (64, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0), (3, 4, 10, 12)),
+    (512, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (64, 1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("count", [12, 5, 1])
+def test_grouped_weight_gradients(count, gpu_device):
+    """avid_conv_wgrad_group (one persistent launch over a table of layers + one grouped reduce) against float64
+    conv3d weight gradients (5e-5 of each gradient's scale, as the per-layer kernel) — dead temporal taps come out as
+    exact zeros — and against avid_conv_wgrad layer by layer (1e-5: same products, another summation order over pixel
+    chunks); a second launch is bit-identical."""
+    import ctypes as C
+    from avid_hip import lib, ops
+    layers = GROUP_LAYERS[:count]
+    items = (lib.WgradItem * count)()
+    keep, refs, singles, outs = [], [], [], []
+    for i, (cin, cout, k, stride, pad, (B, Ti, Hi, Wi)) in enumerate(layers):
+        x = T(detgen.det_normalish(f"grp:{i}:x", (B, cin, Ti, Hi, Wi)))
+        w = T(detgen.det_param(f"grp:{i}:w.weight", (cout, cin) + k))
+        wr = w.double().requires_grad_(True)
+        yr = F.conv3d(x.double(), wr, stride=stride, padding=pad)
+        gy = T(detgen.det_uniform(f"grp:{i}:gy", tuple(yr.shape)))
+        (yr * gy.double()).sum().backward()
+        refs.append(wr.grad)
+        xd, gyd = cl(x).to(gpu_device), cl(gy).to(gpu_device)
+        d, _, _, nbw, _ = ops._desc_cached((B, Ti, Hi, Wi), cin, cout, k, stride, pad, False)
+        assert d.groupable
+        dw = ops.make_weight(cout, cin, *k).to(gpu_device).fill_(float("nan"))     # every element must be written
+        one = ops.make_weight(cout, cin, *k).to(gpu_device)
+        ws = ops.workspace(gpu_device, nbw)
+        lib.call("avid_conv_wgrad", C.byref(d), ops._p(xd), ops._p(gyd), ops._p(one), ops._p(ws), ws.numel(), ops._stream())
+        singles.append(one)
+        items[i].d = d
+        items[i].x, items[i].dy, items[i].dw = xd.data_ptr(), gyd.data_ptr(), dw.data_ptr()
+        keep += [xd, gyd]
+        outs.append(dw)
+    nb = lib.raw("avid_conv_wgrad_group_workspace_bytes")(count, items)
+    ws = torch.empty(max(int(nb), 16), dtype=torch.uint8, device=gpu_device)
+    lib.call("avid_conv_wgrad_group", count, items, ops._p(ws), ws.numel(), ops._stream())
+    first = [o.clone() for o in outs]
+    for o in outs:
+        o.fill_(float("nan"))
+    lib.call("avid_conv_wgrad_group", count, items, ops._p(ws), ws.numel(), ops._stream())
+    for i, (o, ref, one) in enumerate(zip(outs, refs, singles)):
+        assert torch.equal(o, first[i])
+        assert relerr(o, ref) < 5e-5, (i, relerr(o, ref))
+        assert relerr(o, one) < 1e-5, (i, relerr(o, one))
+        dead = (ref == 0).all(0).all(0).all(-1).all(-1) if ref.dim() == 5 else None     # temporal taps that only meet padding
+        if dead is not None and bool(dead.any()):
+            assert bool((o.cpu()[:, :, dead] == 0).all())
+
+
 def test_conv_transpose_detecting(gpu_device):
     """A = identity-like with ASYMMETRIC weights: catches a row<->col swap in the MFMA C-write."""
     from avid_hip import ops
