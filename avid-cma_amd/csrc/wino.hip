@@ -235,6 +235,8 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
       };
       load_b(0);
       load_b(1);
+      // (s_setprio 3 around the products — so that the co-resident workgroup's transform only fills gaps — made the
+      // kernel 22 % SLOWER: 177 -> 217 us on conv2x; the transforming workgroup then never gets to its own products)
       floatx4 av[4];
 #pragma unroll
       for (int s_ = 0; s_ < 8; ++s_) {
