@@ -83,7 +83,7 @@ SIGNATURES = {
     "avid_timing_report": (_i, [C.c_char_p, _sz]),
     "avid_conv_fwd_workspace_bytes": (_sz, [_dp]),
     "avid_conv_fwd_stats_rows": (_i, [_dp]),
-    "avid_conv_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "avid_conv_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "avid_conv_dgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_dgrad_bn_rows": (_i, [_dp]),
     "avid_conv_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -94,6 +94,7 @@ SIGNATURES = {
     "avid_conv_wgrad_group_workspace_bytes": (_sz, [_i, C.POINTER(WgradItem)]),
     "avid_conv_wgrad_group": (_i, [_i, C.POINTER(WgradItem), _vp, _sz, _vp]),
     "avid_conv_kernel_name": (_i, [_dp, _i, C.c_char_p, _i]),
+    "avid_conv_uses_wino": (_i, [_dp, _i]),
     "avid_wino_configure": (_i, [_i, _i64, _i]),
     "avid_bn_workspace_bytes": (_sz, [_i64, _i]),
     "avid_bn_fwd_train": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),

@@ -301,6 +301,8 @@ def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
                lib.raw("avid_conv_fwd_stats_rows")(C.byref(d)))
         d.bn_bwd_rows = 0 if channel_first else lib.raw("avid_conv_dgrad_bn_rows")(C.byref(d))
         d.groupable = bool(lib.raw("avid_conv_wgrad_groupable")(C.byref(d)))
+        d.wino_fwd = bool(lib.raw("avid_conv_uses_wino")(C.byref(d), 0))
+        d.wino_dgrad = bool(lib.raw("avid_conv_uses_wino")(C.byref(d), 1))
         _DESC_CACHE[key] = hit
     return hit
 
@@ -425,10 +427,37 @@ class TransposedWeights:
             self.map[p.data_ptr()] = wt
             self.max_elems = max(self.max_elems, p.numel())
         self.table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+        # Winograd-transformed weights U of every 3x3 layer that CAN take that path (whether it does depends on the
+        # activation's size, known at call time): one launch per step instead of one per forward / input-gradient call.
+        # OFF by default (AVID_WINO_PRE=1 turns it on): removing the 14 small transform launches from the chain made the
+        # step SLOWER on every box tried (11.91 -> 12.35 ms, alternating runs) — the per-call transform leaves U hot in
+        # the L2 of the kernel that reads it 5 us later, a transform at the start of the step does not.
+        wino = [p for p in ws if _kdims(p) == (1, 3, 3) and p.shape[0] <= 128 and p.shape[1] <= 128] \
+            if os.environ.get("AVID_WINO_PRE", "0") == "1" else []
+        self.n_wino, self.umap = len(wino) * 2, {}
+        if wino:
+            self.ubuf = torch.empty(sum(16 * p.shape[0] * p.shape[1] for p in wino) * 2, dtype=torch.float32, device=dev)
+            recs, off = [], 0
+            for p in wino:
+                for mode in (1, 2):
+                    u = self.ubuf[off:off + 16 * p.shape[0] * p.shape[1]]
+                    off += u.numel()
+                    recs.append(struct.pack("<QQiiii", p.data_ptr(), u.data_ptr(), p.shape[0], 9, p.shape[1], mode))
+                    self.umap[(p.data_ptr(), mode)] = u
+            self.utable = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
+            self.umax = max(p.shape[0] * p.shape[1] for p in wino)
 
     def refresh(self):
         if self.n:
             lib.call("avid_weight_transpose_batched", self.n, _p(self.table), self.max_elems, _stream())
+
+    def refresh_wino(self):
+        """The Winograd transforms of the current weights (needed from the first Winograd layer of the FORWARD on)."""
+        if self.n_wino:
+            lib.call("avid_weight_transpose_batched", self.n_wino, _p(self.utable), self.umax, _stream())
+
+    def armed_wino(self):
+        return _ArmWino(self)
 
     def armed(self):
         return _ArmTransposed(self)
@@ -449,7 +478,30 @@ class _ArmTransposed:
         return False
 
 
+class _ArmWino:
+    def __init__(self, tw):
+        self.tw = tw
+
+    def __enter__(self):
+        global _WINO_U
+        self.prev, _WINO_U = _WINO_U, self.tw.umap if self.tw.n_wino else None
+        return self.tw
+
+    def __exit__(self, *exc):
+        global _WINO_U
+        _WINO_U = self.prev
+        return False
+
+
 _TRANSPOSED = None
+_WINO_U = None
+
+
+def _u_for(w, mode):
+    """This weight's Winograd transform (mode 1 forward, 2 input gradient) if a TrainStep keeps one current."""
+    if _WINO_U is None:
+        return None
+    return _WINO_U.get((w.data_ptr(), mode))
 
 
 def _wt_for(w):
@@ -504,7 +556,8 @@ class _ConvCL(Function):
         stats = None
         if want_stats and srows > 0 and bias is None and not relu:
             stats = torch.empty((srows, 2, cout), dtype=torch.float32, device=x.device)
-        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(addend), _p(bias), int(relu), _p(y), _p(stats), _p(ws),
+        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(_u_for(w, 1) if d.wino_fwd else None), _p(addend), _p(bias),
+                 int(relu), _p(y), _p(stats), _p(ws),
                  ws.numel() if ws is not None else 0, _stream())
         ctx.d, ctx.relu, ctx.channel_first = d, relu, channel_first
         ctx.has_addend, ctx.has_bias = addend is not None, bias is not None
@@ -521,7 +574,7 @@ class _ConvCL(Function):
             dr, nbr, _, ctx.nb_wgrad_r, _ = _desc_cached((B, Ti, Hi, Wi), cin, res_w.shape[0], (1, 1, 1), rs, (0, 0, 0), False)
             y_res = torch.empty((B, dr.To, dr.Ho, dr.Wo, res_w.shape[0]), dtype=torch.float32, device=x.device)
             wsr = workspace(x.device, nbr) if nbr else None
-            lib.call("avid_conv_fwd", C.byref(dr), _p(x), _p(res_w), None, None, 0, _p(y_res), None, _p(wsr),
+            lib.call("avid_conv_fwd", C.byref(dr), _p(x), _p(res_w), None, None, None, 0, _p(y_res), None, _p(wsr),
                      wsr.numel() if wsr is not None else 0, _stream())
             ctx.dr, ctx.res_stride = dr, rs
         ctx.save_for_backward(x, w, y if relu else None, res_w)
@@ -654,7 +707,8 @@ class _ConvCL(Function):
                 s4 = src.stats4
                 fuse = lib.BnBwdFuse(_p(src.x), _p(s4[2]), _p(s4[3]), _p(s4[0]), _p(s4[1]), int(src.relu),
                                      _p(src.partials))
-            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_wt_for(w)), _p(add), add_stride, _p(dx),
+            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_u_for(w, 2) if d.wino_dgrad else _wt_for(w)), _p(add),
+                     add_stride, _p(dx),
                      C.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), st)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)

@@ -306,14 +306,22 @@ class TrainStep:
                 self.twt.refresh()
         else:
             self.flat.zero_grad()
-        video_emb, audio_emb = self.model(video, audio)
+        if self.twt is not None and self.twt.n_wino:
+            # the Winograd transforms of the current weights, one launch (the weights cannot change before backward:
+            # this method owns the step), used by the forward and the input-gradient kernels of those layers
+            self.twt.refresh_wino()
+            with self.twt.armed_wino():
+                video_emb, audio_emb = self.model(video, audio)
+        else:
+            video_emb, audio_emb = self.model(video, audio)
         loss, _ = self.criterion(video_emb, audio_emb, index)
         if self.twt is not None:
             if helper is not None:
                 torch.cuda.current_stream().wait_stream(helper)
             else:
                 self.twt.refresh()                   # after the forward: whatever the weights are now
-            with self.twt.armed(), self.slots.armed(), ops.deferred_wgrads(enabled=self._defer_ok()):
+            with self.twt.armed(), self.twt.armed_wino(), self.slots.armed(), \
+                    ops.deferred_wgrads(enabled=self._defer_ok()):
                 loss.backward()
         else:
             loss.backward()

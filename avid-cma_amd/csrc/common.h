@@ -59,9 +59,8 @@ int stem_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* 
 bool wino_supported(const avid_conv_desc* d, int mode);
 size_t wino_ws_bytes(const avid_conv_desc* d, int mode);
 int wino_grid(const avid_conv_desc* d, int mode);
-int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* w, float* dst, const float* addend,
-              float* stats, const avid_bn_bwd_fuse* bn, void* ws, hipStream_t s);
-
+int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* w, const float* u_pre, float* dst,
+              const float* addend, float* stats, const avid_bn_bwd_fuse* bn, void* ws, hipStream_t s);
 // Winograd weight gradient of the same layers: slabs [nsplit][Cout][9][Cin] in ws (nsplit == 1: dw itself)
 bool wino_wgrad_supported(const avid_conv_desc* d);
 size_t wino_wgrad_ws_bytes(const avid_conv_desc* d);
@@ -91,5 +90,40 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + pos;
 }
+
+// U[(xi * Cn + n) * Cr + k] = (G g G^T)[xi / 4][xi % 4],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], for the elements
+// i = first, first + stride, ... of the Cn x Cr (n, k) pairs.  flip = 0: g[a][b] = w[n][a][b][k] (forward); flip = 1:
+// g[a][b] = w[k][2-a][2-b][n] (input gradient).  Shared by wino_weight_kernel and weight_transpose_batched_kernel.
+__device__ __forceinline__ void wino_weight_elements(const float* __restrict__ w, float* __restrict__ U, int Cn, int Cr, int Cin, int flip,
+                                     long long first, long long stride) {
+  for (long long i = first; i < (long long)Cn * Cr; i += stride) {
+    const int k = (int)(i % Cr), n = (int)(i / Cr);
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        g[a][b] = flip ? w[(((long long)k * 3 + (2 - a)) * 3 + (2 - b)) * Cin + n] : w[(((long long)n * 3 + a) * 3 + b) * Cin + k];
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      t[0][b] = g[0][b];
+      t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+      t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+      t[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]),
+                  u3 = t[a][2];
+      const long long o = ((long long)(a * 4) * Cn + n) * Cr + k, st = (long long)Cn * Cr;
+      U[o] = u0;
+      U[o + st] = u1;
+      U[o + 2 * st] = u2;
+      U[o + 3 * st] = u3;
+    }
+  }
+}
+
 
 }  // namespace avid

@@ -1601,7 +1601,18 @@ struct WgradGroupArgs {
 __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const WgradGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int total = g.item0[g.n];
-  for (int item = (int)blockIdx.x; item < total; item += (int)gridDim.x) {
+  // Workgroup -> item: plain round-robin over the cost-sorted items balances the load, but the hardware deals consecutive
+  // workgroups to the 8 XCDs in turn, so the dw tiles of one pixel range (consecutive items, which re-read the same x and
+  // dy rows) would all sit on different L2s; a contiguous eighth of every round per XCD (xcd_remap) keeps them together
+  // but hands XCD 0 the 64 most expensive items of every round (1.05 -> 1.26 ms).  Octets: 8 consecutive items stay on one
+  // XCD, the octets of a round go to the XCDs in turn.
+  const unsigned G = gridDim.x;
+  unsigned first = blockIdx.x;
+  if (G % 64 == 0) {
+    const unsigned xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;          // pos-th workgroup of this XCD
+    first = ((pos >> 3) * 8 + xcd) * 8 + (pos & 7);
+  }
+  for (int item = (int)first; item < total; item += (int)G) {
     int l = 0;
     while (l + 1 < g.n && item >= g.item0[l + 1]) ++l;
     wgrad_tab_body<2, 2>(g.layer[l], (unsigned)(item - g.item0[l]), smem);
@@ -1819,6 +1830,11 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const avid_wt_desc* __restrict__ descs) {
   __shared__ float tile[32][33];
   const avid_wt_desc d = descs[blockIdx.y];
+  if (d.mode != 0) {     // Winograd-transformed weights of a 3x3 layer (wino.hip): mode 1 forward, 2 input gradient
+    wino_weight_elements(d.w, d.wt, d.mode == 1 ? d.Cout : d.Cin, d.mode == 1 ? d.Cin : d.Cout, d.Cin, d.mode == 2,
+                         (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+    return;
+  }
   const int tco = (d.Cout + 31) / 32, tci = (d.Cin + 31) / 32;
   const long long ntile = (long long)tco * tci * d.ntaps;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
@@ -2643,7 +2659,7 @@ extern "C" int avid_conv_fwd_stats_rows(const avid_conv_desc* d) {
   return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cout)) : 0);
 }
 
-extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* addend,
+extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* u, const float* addend,
                              const float* bias, int relu, float* y, float* bn_partials, void* ws, size_t ws_bytes,
                              avid_stream_t stream) {
   int rc = validate(d);
@@ -2653,10 +2669,10 @@ extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const floa
     return stem_fwd(d, x, w, y, bn_partials, ws, (hipStream_t)stream);
   if (wino_supported(d, 0) && !bias && !relu) {
     // (avid_conv_fwd_stats_rows promised this kernel's rows: without its workspace the partials would not match)
-    AVID_REQUIRE(!bn_partials || (ws && ws_bytes >= wino_ws_bytes(d, 0)), AVID_E_BADARG,
+    AVID_REQUIRE(!bn_partials || u || (ws && ws_bytes >= wino_ws_bytes(d, 0)), AVID_E_BADARG,
                  "conv_fwd: BatchNorm partials of this layer need the planned workspace (avid_conv_fwd_workspace_bytes)");
-    if (ws && ws_bytes >= wino_ws_bytes(d, 0))
-      return wino_conv(d, 0, x, w, y, addend, bn_partials, nullptr, ws, (hipStream_t)stream);
+    if (u || (ws && ws_bytes >= wino_ws_bytes(d, 0)))
+      return wino_conv(d, 0, x, w, u, y, addend, bn_partials, nullptr, ws, (hipStream_t)stream);
   }
   const Trim tr = trim_taps(d);
   ConvArgs a;
@@ -2767,8 +2783,8 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
   AVID_REQUIRE(d->st <= 2 && d->sh <= 2 && d->sw <= 2, AVID_E_UNSUPPORTED, "conv_dgrad: stride > 2");
   AVID_REQUIRE(ws_bytes >= dgrad_wt_bytes(d), AVID_E_BADARG, "conv_dgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  if (wino_supported(d, 1) && !sparse_add && ws_bytes >= wino_ws_bytes(d, 1))
-    return wino_conv(d, 1, dy, w, dx, addend, nullptr, bn, ws, s);
+  if (wino_supported(d, 1) && !sparse_add && (wt_in || ws_bytes >= wino_ws_bytes(d, 1)))
+    return wino_conv(d, 1, dy, w, wt_in, dx, addend, nullptr, bn, ws, s);   // (wt_in: this layer's pre-transformed U)
   const int ntaps = d->kt * d->kh * d->kw;
   const float* wt = wt_in;
   if (!wt) {
@@ -3122,6 +3138,12 @@ extern "C" int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* 
   ScopedTimer t(s, "wgrad_group_reduce_kernel", 0.0, red_bytes);
   hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3((unsigned)gx, (unsigned)r.count), dim3(256), 0, s, r);
   return check_launch("wgrad_group_reduce");
+}
+
+extern "C" int avid_conv_uses_wino(const avid_conv_desc* d, int which) {
+  if (!d || validate(d)) return 0;
+  if (which == 2) return wino_wgrad_supported(d) ? 1 : 0;
+  return (which == 0 || which == 1) && wino_supported(d, which) ? 1 : 0;
 }
 
 extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* buf, int len) {

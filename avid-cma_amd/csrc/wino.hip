@@ -50,33 +50,8 @@ struct WinoArgs {
 // flip = 0: g[a][b] = w[n][a][b][k] (forward);  flip = 1: g[a][b] = w[k][2-a][2-b][n] (input gradient)
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cn,
                                                           int Cr, int Cin, int flip) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)Cn * Cr) return;
-  const int k = (int)(i % Cr), n = (int)(i / Cr);
-  float g[3][3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-      g[a][b] = flip ? w[(((long long)k * 3 + (2 - a)) * 3 + (2 - b)) * Cin + n] : w[(((long long)n * 3 + a) * 3 + b) * Cin + k];
-  float t[4][3];
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    t[0][b] = g[0][b];
-    t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-    t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-    t[3][b] = g[2][b];
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]),
-                u3 = t[a][2];
-    const long long o = ((long long)(a * 4) * Cn + n) * Cr + k, st = (long long)Cn * Cr;
-    U[o] = u0;
-    U[o + st] = u1;
-    U[o + 2 * st] = u2;
-    U[o + 3 * st] = u3;
-  }
+  wino_weight_elements(w, U, Cn, Cr, Cin, flip, (long long)blockIdx.x * blockDim.x + threadIdx.x,
+                       (long long)gridDim.x * blockDim.x);
 }
 
 #ifdef AVID_WINO_TRACE
@@ -715,8 +690,8 @@ static void wino_launch(const WinoArgs& a, int grid, hipStream_t s) {
 }
 
 // src / dst are x / y (mode 0) or dy / dx (mode 1); ws holds U (wino_ws_bytes)
-int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* w, float* dst, const float* addend,
-              float* stats, const avid_bn_bwd_fuse* bn, void* ws, hipStream_t s) {
+int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* w, const float* u_pre, float* dst,
+              const float* addend, float* stats, const avid_bn_bwd_fuse* bn, void* ws, hipStream_t s) {
   WinoArgs a;
   memset(&a, 0, sizeof(a));
   a.src = src; a.dst = dst; a.addend = addend;
@@ -727,15 +702,18 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
   a.ncb = a.Cn / 64;
   a.ntiles = (long long)a.F * a.TH * a.TW;
   a.units = (int)(ceil_div(a.ntiles, W_TB) * a.ncb);
-  float* U = static_cast<float*>(ws);
-  a.U = U;
-  {
+  int rc = AVID_OK;
+  if (u_pre) {            // transformed once per step by avid_weight_transpose_batched (mode 1 / 2 descriptors)
+    a.U = u_pre;
+  } else {
+    float* U = static_cast<float*>(ws);
+    a.U = U;
     const long long n = (long long)a.Cn * a.Cr;
     ScopedTimer t(s, "wino_weight_kernel", 0.0, 4.0 * n * 25);
     hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, w, U, a.Cn, a.Cr, d->Cin, mode);
+    rc = check_launch("wino_weight");
+    if (rc) return rc;
   }
-  int rc = check_launch("wino_weight");
-  if (rc) return rc;
   int epi = 0;
   if (mode == 0 && stats) { epi = 1; a.stats = stats; }
   if (addend) epi |= 2;

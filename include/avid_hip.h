@@ -76,13 +76,17 @@ size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d);
  * avid_conv_fwd_stats_rows(d) (0 = this layer cannot produce them), written by the conv epilogue so that
  * avid_bn_fwd_train can skip its statistics pass over y.  Needs bias == NULL and relu == 0. */
 int avid_conv_fwd_stats_rows(const avid_conv_desc* d);
-int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* addend,
+/* u (or NULL): for a layer on the Winograd path (avid_conv_uses_wino(d, 0)), its weights already transformed by
+ * avid_weight_transpose_batched (a mode-1 descriptor, current for this w): the call then skips its own transform launch.
+ * Ignored by every other layer. */
+int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* u, const float* addend,
                   const float* bias, int relu, float* y, float* bn_partials, void* ws, size_t ws_bytes,
                   avid_stream_t stream);
 
 /* dx = conv_transpose(dy, w) [+ addend].  ws: scratch for the transposed weights (+ split-K slabs).
- * wt: the weights already repacked as [Cin][taps][Cout] by avid_weight_transpose_batched (current for
- * this w), or NULL to repack inside the call (one extra small launch per layer). */
+ * wt: the weights already repacked by avid_weight_transpose_batched (current for this w) — as [Cin][taps][Cout], or,
+ * for a layer whose input gradient runs on the Winograd path (avid_conv_uses_wino(d, 1)), its mode-2 transform — or NULL
+ * to repack inside the call (one extra small launch per layer). */
 size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d);
 /* bn (or NULL): dx is the COMPLETE gradient of the output of a training-mode BatchNorm(+ReLU) whose input was
  * bn->x (shape of dx) — the usual conv <- ReLU <- BN chain of models/network_blocks.py:30-60.  The dgrad epilogue
@@ -116,13 +120,18 @@ int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, co
 typedef struct avid_wt_desc {
   const float* w;
   float* wt;
-  int32_t Cout, ntaps, Cin, reserved;
+  int32_t Cout, ntaps, Cin;
+  int32_t mode; /* 0: wt[Cin][taps][Cout]; 3x3 layers on the Winograd path (ntaps = 9): 1: wt = U[16][Cout][Cin] for the
+                   forward (pass it as `u` to avid_conv_fwd), 2: wt = U[16][Cin][Cout] with flipped taps for the input
+                   gradient (pass it as `wt` to avid_conv_dgrad) */
 } avid_wt_desc;
 int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_dev, int64_t max_elems, avid_stream_t stream);
 
 /* Which kernel instantiation a descriptor dispatches to (which: 0 fwd, 1 dgrad, 2 wgrad), e.g.
  * "igemm_kernel<4,1,1,2,1>" — lets bench.py attribute HIP-event timings to rocprofv3 kernel names. */
 int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* buf, int len);
+/* 1 if this layer's forward (which 0) / input gradient (1) / weight gradient (2) runs on the Winograd kernels. */
+int avid_conv_uses_wino(const avid_conv_desc* d, int which);
 
 /* Dispatch switches of the Winograd path (defaults: on, layers of >= 24576 output pixels, <= 128 output channels;
  * environment AVID_WINO / AVID_WINO_MIN_M / AVID_WINO_MAXC).  A negative argument returns that switch to its

@@ -41,7 +41,7 @@ def test_error_convention():
     from avid_hip import lib
     assert lib.version() >= 100
     d = lib.ConvDesc()          # all zeros -> AVID_E_SHAPE, message set, no kernel launched
-    rc = lib.raw("avid_conv_fwd")(ctypes.byref(d), None, None, None, None, 0, None, None, None, 0, None)
+    rc = lib.raw("avid_conv_fwd")(ctypes.byref(d), None, None, None, None, None, 0, None, None, None, 0, None)
     assert rc < 0 and "conv" in lib.last_error()
     with pytest.raises(lib.AvidHipError):
         lib.call("avid_l2norm_fwd", 0, 0, None, None, None, None)
