@@ -430,8 +430,8 @@ class TransposedWeights:
         # Winograd-transformed weights U of every 3x3 layer that CAN take that path (whether it does depends on the
         # activation's size, known at call time): one launch per step instead of one per forward / input-gradient call.
         # OFF by default (AVID_WINO_PRE=1 turns it on): removing the 14 small transform launches from the chain made the
-        # step SLOWER on every box tried (11.91 -> 12.35 ms, alternating runs) — the per-call transform leaves U hot in
-        # the L2 of the kernel that reads it 5 us later, a transform at the start of the step does not.
+        # step SLOWER (11.91 -> 12.35 ms, alternating runs on one box) although every kernel's own duration is unchanged
+        # in the single-stream timing pass — a scheduling effect between the chain and the trailing streams, not found.
         wino = [p for p in ws if _kdims(p) == (1, 3, 3) and p.shape[0] <= 128 and p.shape[1] <= 128] \
             if os.environ.get("AVID_WINO_PRE", "0") == "1" else []
         self.n_wino, self.umap = len(wino) * 2, {}
