@@ -1596,6 +1596,7 @@ struct WgradGroupArgs {
   WgradArgs layer[WG_GROUP_MAX];
   int item0[WG_GROUP_MAX + 1];       // first item of every layer; item0[n] = number of items
   int n;
+  unsigned run;                      // consecutive items that stay on one XCD
 };
 
 __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const WgradGroupArgs g) {
@@ -1604,13 +1605,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const WgradGroupArg
   // Workgroup -> item: plain round-robin over the cost-sorted items balances the load, but the hardware deals consecutive
   // workgroups to the 8 XCDs in turn, so the dw tiles of one pixel range (consecutive items, which re-read the same x and
   // dy rows) would all sit on different L2s; a contiguous eighth of every round per XCD (xcd_remap) keeps them together
-  // but hands XCD 0 the 64 most expensive items of every round (1.05 -> 1.26 ms).  Octets: 8 consecutive items stay on one
-  // XCD, the octets of a round go to the XCDs in turn.
+  // but hands XCD 0 the 64 most expensive items of every round (1.05 -> 1.26 ms).  Runs: g.run consecutive items stay on
+  // one XCD, the runs of a round go to the XCDs in turn.
   const unsigned G = gridDim.x;
   unsigned first = blockIdx.x;
-  if (G % 64 == 0) {
+  if (G % (8u * g.run) == 0) {
     const unsigned xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;          // pos-th workgroup of this XCD
-    first = ((pos >> 3) * 8 + xcd) * 8 + (pos & 7);
+    first = ((pos / g.run) * 8 + xcd) * g.run + pos % g.run;
   }
   for (int item = (int)first; item < total; item += (int)G) {
     int l = 0;
@@ -3094,6 +3095,15 @@ extern "C" int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* 
   plan_group(n, items, L, g.item0, &fl, order);
   AVID_REQUIRE(fl == 0 || (ws && ws_bytes >= sizeof(float) * fl), AVID_E_BADARG, "conv_wgrad_group: workspace too small");
   g.n = n;
+  {
+    static int run = 0;               // AVID_WG_GROUP_RUN: 8 / 16 / 32 / 64
+    if (!run) {
+      const char* e = getenv("AVID_WG_GROUP_RUN");
+      run = e ? atoi(e) : 32;         // measured (3 launches per step): 8: 494 MB per launch 1.076 ms; 16: 428 MB 1.070 ms;
+      if (run != 8 && run != 16 && run != 32 && run != 64) run = 32;   // 32: 389 MB 1.080 ms; 64: 377 MB 1.254 ms (278 MB algorithmic)
+    }
+    g.run = (unsigned)run;
+  }
   WgradGroupReduce r;
   memset(&r, 0, sizeof(r));
   double flops = 0, bytes = 0, red_bytes = 0;
@@ -3126,7 +3136,13 @@ extern "C" int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* 
     set = true;
   }
   int grid = g.item0[n];
-  if (grid > 2 * device_cus()) grid = 2 * device_cus();
+  static int grid_cap = 0;              // AVID_WG_GROUP_GRID: experiment knob (workgroups of a grouped launch; default 2 per CU)
+  if (!grid_cap) {
+    const char* e = getenv("AVID_WG_GROUP_GRID");
+    grid_cap = e ? atoi(e) : 2 * device_cus();
+    if (grid_cap < 64) grid_cap = 2 * device_cus();
+  }
+  if (grid > grid_cap) grid = grid_cap;
   {
     ScopedTimer t(s, "wgrad_group_kernel", flops, bytes);
     hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)grid), dim3(256), lds, s, g);

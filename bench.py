@@ -142,8 +142,12 @@ def reference_loop(model, crit, video, audio, ids, dev, steps=10, warmup=4):
     from torch.nn.parallel import DistributedDataParallel
     own_group = not dist.is_initialized()
     if own_group:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     overlap, model.overlap_towers = model.overlap_towers, False      # (DDP's reducer knows one stream)
     try:
@@ -427,14 +431,28 @@ def main():
                 print(f"{k:34s} {v['launches'] / kern_steps:11.1f} {v['ms'] / kern_steps:9.3f} "
                       f"{100 * v['ms'] / tot:6.1f} {tf:9.2f} {gb:10.1f}", file=sys.stderr)
             print(f"timed kernels {tot / kern_steps:.3f} ms/step of {ms:.3f} ms wall", file=sys.stderr)
-        out["roofline"]["r2p1d_forward"] = forward_roofline(model, video, lib)
+        # (side measurements must never cost the line: a failure is reported inside it)
+        try:
+            out["roofline"]["r2p1d_forward"] = forward_roofline(model, video, lib)
+        except Exception as e:                              # noqa: BLE001
+            out["roofline"]["r2p1d_forward"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_extra:
-            out["extra"] = extra_configs(engine, model, video, audio, dev, lib)
+            try:
+                out["extra"] = extra_configs(engine, model, video, audio, dev, lib)
+            except Exception as e:                          # noqa: BLE001
+                out["extra"] = {"error": repr(e)[:300]}
             engine.criterion = crit
-            out["extra"]["reference_loop"] = reference_loop(model, crit, video, audio, ids, dev)
-            out["extra"]["reference_loop"]["vs_trainstep"] = round(out["extra"]["reference_loop"]["clips_s"] / clips, 3)
+            try:
+                ref = reference_loop(model, crit, video, audio, ids, dev)
+                ref["vs_trainstep"] = round(ref["clips_s"] / clips, 3)
+            except Exception as e:                          # noqa: BLE001
+                ref = {"error": repr(e)[:300]}
+            out["extra"]["reference_loop"] = ref
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:                          # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)[:300]}
         # RCCL prints a version banner through C stdio when a communicator is first created: flush it BEFORE the JSON
         # line so that the line is the last thing on stdout
         try:
