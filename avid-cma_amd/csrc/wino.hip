@@ -44,6 +44,7 @@ struct WinoArgs {
   int F, H, W, TH, TW, Cr, Cn, ncb;
   long long ntiles;
   int units;                            // tile blocks x column blocks, column block fastest
+  int xcd_local;                        // XCD-contiguous unit order (AVID_WINO_XCD, default 1)
 };
 
 // U[(xi * Cn + n) * Cr + k] = (G g G^T)[xi / 4][xi % 4],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
@@ -102,7 +103,23 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
   // through a small LDS staging area per wave (below); this lane then owns channel  16 r + (lane & 15)  of round r =
   // 2 j + (g >> 1) for the tiles 8 (lane >> 4) .. + 7 of every unit
   float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
-  const int cb = (int)(blockIdx.x % p.ncb);          // the grid is a multiple of ncb: one column block per workgroup
+  // Workgroup (q, cb): column block cb = lid % ncb, tile blocks q, q + G', q + 2 G', ... (G' = grid / ncb).  The logical id
+  // lid gives XCD k a contiguous eighth of every round: consecutive tile blocks are neighbouring tiles, whose 4x4 patches
+  // overlap by two rows / columns — dealt in hardware order they sit on eight different L2s and every input pixel is
+  // fetched from memory up to four times (counter traffic 2.0x the algorithmic bytes).  The blocks of the last, partial
+  // round are spread over the XCDs one by one (block j of it -> XCD j % 8), or XCD 0 would do them all.
+  const bool xl = p.xcd_local && gridDim.x % (8 * p.ncb) == 0;
+  const int lid = xl ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int cb = lid % p.ncb, q = lid / p.ncb, Gq = (int)gridDim.x / p.ncb;
+  const int nblk = p.units / p.ncb;
+  const int fullq = xl ? nblk / Gq * Gq : nblk;      // first tile block of the partial round
+  const int qlast = fullq + (q % (Gq / 8)) * 8 + q / (Gq / 8);
+  auto blk_after = [&](int blk) {                    // this workgroup's next tile block (>= nblk: none)
+    if (blk >= fullq) return nblk;
+    const int nx = blk + Gq;
+    return nx < fullq ? nx : qlast;
+  };
+  const int blk0 = q < fullq ? q : (xl ? qlast : q);
 #ifdef AVID_WINO_TRACE
   long long tprev_ = wall_clock64();
   if (threadIdx.x == 0) for (int i = 0; i < 8; ++i) g_wino_trace[blockIdx.x * 8 + i] = 0;
@@ -111,11 +128,11 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
   // divisions per tile are done once, by 32 lanes, instead of by every thread of the transform and 16 times per lane
   // of the epilogue (~1000 VALU instructions per wave and unit, on the matrix pipe's time)
   int4* tabs = reinterpret_cast<int4*>(sm + W_LDS_FLOATS);
-  auto fill_tab = [&](int unit, int buf) {
+  auto fill_tab = [&](int blk, int buf) {
     if (tid < W_TB) {
-      const long long t = (long long)(unit / p.ncb) * W_TB + tid;
+      const long long t = (long long)blk * W_TB + tid;
       int4 e = {-1, 0, 0, 0};
-      if (unit < p.units && t < p.ntiles) {
+      if (blk < nblk && t < p.ntiles) {
         const int f = (int)(t / TPF), rem = (int)(t - (long long)f * TPF);
         e.x = f; e.y = rem / TW; e.z = rem - e.y * TW;
       }
@@ -147,12 +164,12 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
                                                     b == 0 ? 0 : (b - 1) * (int)px_b, 0));
     }
   };
-  fill_tab(blockIdx.x, 0);
+  fill_tab(blk0, 0);
   __syncthreads();
   int4 e_cur = tabs[ttl];
   issue_loads(e_cur, 0);
   int uidx = 0;
-  for (int unit = blockIdx.x; unit < p.units; unit += gridDim.x) {
+  for (int blk = blk0; blk < nblk; blk = blk_after(blk)) {
     W_STAMP(0);
     floatx16 acc[4][2];
 #pragma unroll
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
     ++uidx;
     for (int ck = 0; ck < nchunks; ++ck) {
       __syncthreads();                         // the previous chunk's / unit's LDS reads are done
-      if (ck == 0) fill_tab(unit + gridDim.x, tbuf ^ 1);      // (visible behind the next barrier; nobody reads that buffer now)
+      if (ck == 0) fill_tab(blk_after(blk), tbuf ^ 1);      // (visible behind the next barrier; nobody reads that buffer now)
       {
         // V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]: column by column, then row by row
         floatx4 w_[4][4];
@@ -702,6 +719,11 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
   a.ncb = a.Cn / 64;
   a.ntiles = (long long)a.F * a.TH * a.TW;
   a.units = (int)(ceil_div(a.ntiles, W_TB) * a.ncb);
+  {
+    static int xl = -1;
+    if (xl < 0) xl = wino_env("AVID_WINO_XCD", 1);
+    a.xcd_local = xl;
+  }
   int rc = AVID_OK;
   if (u_pre) {            // transformed once per step by avid_weight_transpose_batched (mode 1 / 2 descriptors)
     a.U = u_pre;
