@@ -60,6 +60,13 @@ def join_deferred_wgrads():
         _DEFER_USED.clear()
 
 
+# NOTE: a deferred / queued weight gradient READS dy and x after the autograd node that produced dy has
+# returned, on a trailing stream or in a later grouped launch.  The same dy tensor may be handed on to autograd (as the
+# gradient of a fused addend, or as the dy of the BatchNorm upstream).  That is safe because every consumer of it in the
+# shipped models only reads it; a user graph in which autograd ACCUMULATES IN PLACE into that tensor (a second consumer
+# of the addend whose gradient arrives first and is then added to) could race with the trailing read: record_stream only
+# guards the allocation.  Deferral and grouping are therefore confined to steps driven by parallel.TrainStep (GradSlots
+# armed), whose models have single-consumer gradients; elsewhere weight gradients run in line.
 # ------------------------------------------------------------------------------------------------
 # grouped weight gradients: the small layers' wgrads of a backward pass are queued (per compute stream) and launched a
 # dozen at a time as ONE persistent kernel (avid_conv_wgrad_group) — only where the gradients land in the flat buffer
