@@ -74,6 +74,7 @@ def join_deferred_wgrads():
 # ------------------------------------------------------------------------------------------------
 GROUP_WGRAD = int(os.environ.get("AVID_GROUP_WGRAD", "1"))
 GROUP_MAX = 12
+GROUP_MIN_FLUSH = 4        # queued layers that are flushed when a layer with its own weight-gradient launch comes by
 _GROUP_PENDING = {}        # compute stream handle -> [(desc, x, dy, dst, slot)]
 _GROUP_WS_BYTES = {}       # tuple of layer geometries -> workspace bytes
 
@@ -648,6 +649,12 @@ class _ConvCL(Function):
             dw = None
             need_dw = False
             grouped = True
+        elif need_dw and GROUP_WGRAD and len(_GROUP_PENDING.get(_group_key(x.device), ())) >= GROUP_MIN_FLUSH:
+            # a large layer (own launch): the small layers queued so far go first — their gradient buckets should not wait
+            # for the end of the backward pass
+            flush_wgrad_group(x.device)
+        if grouped:
+            pass
         elif (need_dw and _DEFER_ON and _SLOTS is not None and (DEFER_IN_CAPTURE or not capturing)
                 and _SLOTS.has_slot(w.data_ptr())):
             main, trail = wgrad_stream(x.device)
