@@ -73,8 +73,9 @@ def join_deferred_wgrads():
 # (GradSlots armed by parallel.TrainStep), because the launch happens later than the autograd node that produced dy
 # ------------------------------------------------------------------------------------------------
 GROUP_WGRAD = int(os.environ.get("AVID_GROUP_WGRAD", "1"))
-GROUP_MAX = 12
-GROUP_MIN_FLUSH = 4        # queued layers that are flushed when a layer with its own weight-gradient launch comes by
+GROUP_MAX = min(12, max(1, int(os.environ.get("AVID_GROUP_MAX", "12"))))
+# queued layers that are flushed when a layer with its own weight-gradient launch comes by
+GROUP_MIN_FLUSH = int(os.environ.get("AVID_GROUP_MIN_FLUSH", "4"))
 _GROUP_PENDING = {}        # compute stream handle -> [(desc, x, dy, dst, slot)]
 _GROUP_WS_BYTES = {}       # tuple of layer geometries -> workspace bytes
 
