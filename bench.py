@@ -306,6 +306,26 @@ def main():
         best = min(modes, key=modes.get)
         set_mode(best)
         dist_info = {"dist_mode": best, "dist_mode_ms": {k: round(v, 3) for k, v in modes.items()}}
+        # optional fourth arm (AVID_BENCH_GRAPH_AB=1; off by default: a capture that fails on one rank of the driver's
+        # only multi-GPU run would cost the whole line): the captured step, whose gradients are reduced by ONE collective
+        # behind the backward pass (parallel.GradBuckets.finish) — one-rank RCCL group: 12.03 ms vs 12.19 ms eager
+        if args.graph < 0 and os.environ.get("AVID_BENCH_GRAPH_AB", "0") == "1":
+            try:
+                engine.capture(video, audio, ids[0])
+                engine.replay(index=ids[0])
+                sync()
+                t = time.perf_counter()
+                for i in range(3):
+                    engine.replay(index=ids[i % total])
+                sync()
+                tt = torch.tensor([(time.perf_counter() - t) / 3 * 1e3], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dist_info["dist_mode_ms"]["graph"] = round(float(tt.item()), 3)
+                if float(tt.item()) < 0.99 * modes[best]:
+                    use_graph = True
+                    dist_info["dist_mode"] = "graph"
+            except Exception as e:                          # noqa: BLE001
+                dist_info["graph_ab_error"] = repr(e)[:200]
         engine.buckets.measure = True
     # Per-kernel HIP-event pass (events on the launch stream, library-side): a few eager steps of the same
     # workload OUTSIDE the timed region, so the instrumentation does not perturb `value`.
@@ -322,7 +342,7 @@ def main():
     kern = lib.timing_report()
     lib.timing_enable(False)
     model.overlap_towers, ops.DEFER_WGRAD = overlap, defer
-    if use_graph:
+    if use_graph and engine.graph is None:
         engine.capture(video, audio, ids[0])
         engine.replay(index=ids[0])
     sync()
