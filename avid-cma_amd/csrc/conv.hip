@@ -2039,6 +2039,7 @@ static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_o
     case 0: k.BM = 128; k.BN = 128; break;
     case 1: k.BM = 128; k.BN = 64; break;
     case 2: k.BM = 256; k.BN = 128; per_cu = 1; break;
+    case 4: k.BM = 128; k.BN = 64; break;           // two waves with 64 x 64 wave tiles (AVID_PK_ALT=4: VERDICT r2 #8)
     default: k.BM = 256; k.BN = 64; per_cu = 1; break;
   }
   const int ntn = Cd / k.BN;
@@ -2088,7 +2089,7 @@ static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_o
 static PkPlan plan_pk(long long M, int Cd, int nk, int mode) {
   double c0, c1;
   const int alt = pk_alt();
-  if (Cd % 128 != 0) return plan_pk_tile(M, Cd, nk, alt == 1 ? 3 : 1, &c0, mode);
+  if (Cd % 128 != 0) return plan_pk_tile(M, Cd, nk, alt == 1 ? 3 : (alt == 4 ? 4 : 1), &c0, mode);
   if (alt == 1) return plan_pk_tile(M, Cd, nk, 2, &c0, mode);
   if (alt == 2) return plan_pk_tile(M, Cd, nk, 1, &c0, mode);
   const PkPlan wide = plan_pk_tile(M, Cd, nk, 0, &c0, mode);
@@ -2147,7 +2148,7 @@ static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
   const double flops = MODE == 1 ? 2.0 * srcpix * a.Cd * K : 2.0 * a.M * a.Cd * K;
   ScopedTimer t(s, name, flops,
                 4.0 * (srcpix * a.Cs + (double)a.Cd * K + (double)a.M * a.Cd * (1 + (a.addend ? 1 : 0) + (a.bnb_x ? 1 : 0))));
-  constexpr bool MAIN = (WM * WN == 4);   // the 4-wave tiles every layer runs on; the 8-wave A/B tiles keep the generic epilogue
+  constexpr bool MAIN = (WM * WN == 4) || (WM == 2 && WN == 1);   // the tiles layers run on; the 8-wave A/B tiles keep the generic epilogue
   const int epi = MAIN ? epi_code<MODE>(a) : EPI_ANY;
   switch (epi) {
     case 0: launch_pk_e<WM, WN, TM, TN, MODE, STRIDED, MAIN ? 0 : EPI_ANY>(a, grid, lds, s); break;
@@ -2436,6 +2437,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
       case 0: rc = launch_pk<2, 2, 2, 2, MODE>(k, pk.grid, s); break;
       case 1: rc = launch_pk<4, 1, 1, 2, MODE>(k, pk.grid, s); break;
       case 2: rc = launch_pk<4, 2, 2, 2, MODE>(k, pk.grid, s); break;
+      case 4: rc = launch_pk<2, 1, 2, 2, MODE>(k, pk.grid, s); break;
       default: rc = launch_pk<4, 2, 2, 1, MODE>(k, pk.grid, s); break;
     }
     if (rc || pk.f == 1) return rc;
@@ -3171,7 +3173,7 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
   const int ktl = tr.d.kt;           // live temporal taps
   auto pk_name = [&](long long M, int Cd, int nk, int mode) {
     const PkPlan pk = plan_pk(M, Cd, nk, mode);
-    static const char* kPk[] = {"2,2,2,2", "4,1,1,2", "4,2,2,2", "4,2,2,1"};
+    static const char* kPk[] = {"2,2,2,2", "4,1,1,2", "4,2,2,2", "4,2,2,1", "2,1,2,2"};
     snprintf(buf, len, "igemm_pk_kernel<%s,%d> full=%d tail_units=%d f=%d", kPk[pk.tile], mode, pk.full, pk.tail_units, pk.f);
   };
   if (which == 0) {
