@@ -643,8 +643,8 @@ static int wino_cus() {      // per device: a process may touch more than one
 
 // The switches of this path: AVID_WINO / AVID_WINO_MIN_M / AVID_WINO_MAXC from the environment, unless
 // avid_wino_configure() (include/avid_hip.h) has overridden them — tests force small fixtures through the kernel.
-struct WinoCfg { int on; long long min_m; int max_c; bool loaded; int wg_on; long long wg_min_m; int wg_max_c; };
-static WinoCfg g_wino_cfg = {1, 24576, 128, false, 1, 24576, 128};
+struct WinoCfg { int on; long long min_m; int max_c; bool loaded; int wg_on; long long wg_min_m; int wg_max_c; long long min_work, wg_min_work; };
+static WinoCfg g_wino_cfg = {1, 6000, 256, false, 1, 6000, 256, 1000000, 1000000};
 static int g_wino_override[3] = {-1, -1, -1};
 
 static const WinoCfg& wino_cfg() {
@@ -652,12 +652,21 @@ static const WinoCfg& wino_cfg() {
   if (!c.loaded) {
     c.on = g_wino_override[0] >= 0 ? g_wino_override[0] : wino_env("AVID_WINO", 1);
     // (25088 pixels: 32 vs 33 us forward, 31 vs 39 us input gradient; 16000: 33.5 vs 28.6)
-    c.min_m = g_wino_override[1] >= 0 ? g_wino_override[1] : wino_env("AVID_WINO_MIN_M", 24576);
-    c.max_c = g_wino_override[2] >= 0 ? g_wino_override[2] : wino_env("AVID_WINO_MAXC", 128);
+    // Where the fused kernel beats the direct one (tools/conv_bench.py, batch 64, round 3): conv2x / conv3x (64 / 128
+    // channels, 401408 / 50176 pixels) 1.6x, conv4x (256 channels, 6272 pixels: 196 of 512 workgroup slots) 84 -> 69 us
+    // forward and 91 -> 70 us input gradient, audio block 1 (64 channels, 16000 pixels) 28 -> 26 and 34 -> 27 us; it
+    // loses on audio block 2 (128 channels, 4160 pixels: 31 -> 39 us), block 3 (256, 1344: 36 -> 66) and conv5x (512 channels,
+    // 1024 pixels: 59 -> 120).  Rule: >= min_m pixels, <= max_c output channels, pixels x max(channels) >= min_work.
+    c.min_m = g_wino_override[1] >= 0 ? g_wino_override[1] : wino_env("AVID_WINO_MIN_M", 6000);
+    c.max_c = g_wino_override[2] >= 0 ? g_wino_override[2] : wino_env("AVID_WINO_MAXC", 256);
+    c.min_work = g_wino_override[1] >= 0 ? 0 : wino_env("AVID_WINO_MIN_WORK", 1000000);
     // the weight-gradient kernel follows the same switches unless its own are set
     c.wg_on = c.on && wino_env("AVID_WINO_WGRAD", 1);
-    c.wg_min_m = g_wino_override[1] >= 0 ? g_wino_override[1] : wino_env("AVID_WINO_WGRAD_MIN_M", (int)c.min_m);
-    c.wg_max_c = g_wino_override[2] >= 0 ? g_wino_override[2] : wino_env("AVID_WINO_WGRAD_MAXC", c.max_c);
+    // (weight gradient, same rule: conv4x 89 -> 67 us, audio block 1 35 -> 29 us per layer; the smaller layers ride in
+    // the grouped launch at the same ~100 TFLOP/s the Winograd kernel would give them)
+    c.wg_min_m = g_wino_override[1] >= 0 ? g_wino_override[1] : wino_env("AVID_WINO_WGRAD_MIN_M", 6000);
+    c.wg_max_c = g_wino_override[2] >= 0 ? g_wino_override[2] : wino_env("AVID_WINO_WGRAD_MAXC", 256);
+    c.wg_min_work = g_wino_override[1] >= 0 ? 0 : wino_env("AVID_WINO_WGRAD_MIN_WORK", 1000000);
     c.loaded = true;
   }
   return c;
@@ -672,7 +681,7 @@ bool wino_supported(const avid_conv_desc* d, int mode) {
   const int Cr = mode ? d->Cout : d->Cin, Cn = mode ? d->Cin : d->Cout;
   if (Cr % W_CK || Cn % 64 || Cn > c.max_c) return false;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
-  if (M < c.min_m) return false;
+  if (M < c.min_m || M * (Cr > Cn ? Cr : Cn) < c.min_work) return false;
   const long long big = M * (Cr > Cn ? Cr : Cn) * 4;
   return big < (1ll << 31);
 }
@@ -773,7 +782,7 @@ bool wino_wgrad_supported(const avid_conv_desc* d) {
   if (d->pt != 0 || d->ph != 1 || d->pw != 1) return false;
   if (d->Cin % 64 || d->Cout % 64 || d->Cin > c.wg_max_c || d->Cout > c.wg_max_c) return false;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
-  if (M < c.wg_min_m) return false;
+  if (M < c.wg_min_m || M * (d->Cin > d->Cout ? d->Cin : d->Cout) < c.wg_min_work) return false;
   return M * (d->Cin > d->Cout ? d->Cin : d->Cout) * 4 < (1ll << 31);
 }
 

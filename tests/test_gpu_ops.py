@@ -58,8 +58,12 @@ CONV_CASES = [
     # layer (25088 pixels at batch 32; models/network_blocks.py:35,40) and an odd-extent sibling (ragged tiles)
     ("wino_128x128", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (32, 4, 14, 14)),
     ("wino_128x128_odd", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (9, 4, 27, 29)),
+    # 256 channels (conv4x at the benchmark batch: 6272 pixels): four column blocks x eight reduction chunks, fewer tile
+    # blocks than workgroup slots; and the smallest 64-channel layer the dispatch rule admits (audio block 1: 16000 pixels)
+    ("wino_256x256", 256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (8, 2, 21, 19)),
+    ("wino_64x64_audio", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (64, 1, 10, 25)),
 ]
-WINO_CASES = {"big_128x64", "big_unbalanced", "wino_128x128", "wino_128x128_odd"}
+WINO_CASES = {"big_128x64", "big_unbalanced", "wino_128x128", "wino_128x128_odd", "wino_256x256", "wino_64x64_audio"}
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
@@ -94,7 +98,7 @@ def test_conv_fwd_dgrad_wgrad(case, gpu_device, kernel_log):
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 9, 11), (4, 8, 48, 48), (5, 7, 45, 47), (64, 1, 4, 4)])
-@pytest.mark.parametrize("cout", [64, 128])
+@pytest.mark.parametrize("cout", [64, 128, 256])
 @pytest.mark.parametrize("cin", [64, 128])
 def test_conv_bn_partials(shape, cout, cin, gpu_device):
     """BatchNorm partial sums written by the conv epilogue / the split-K reduce: their column totals must be
@@ -129,6 +133,7 @@ def test_conv_bn_partials(shape, cout, cin, gpu_device):
     ((3, 5, 9, 9), 64, 64, (3, 1, 1), (1, 0, 0), (2, 1, 1)),          # temporal stride, odd extent
     ((6, 8, 27, 29), 64, 64, (1, 3, 3), (0, 1, 1), (1, 1, 1)),        # Winograd input gradient (>= 32768 pixels), odd extents
     ((5, 4, 45, 47), 128, 128, (1, 3, 3), (0, 1, 1), (1, 1, 1)),      # Winograd, two 64-column blocks, 4 reduction chunks
+    ((8, 2, 21, 19), 256, 256, (1, 3, 3), (0, 1, 1), (1, 1, 1)),      # Winograd at 256 channels (conv4x): 4 column blocks, 8 chunks
     ((3, 7, 40, 41), 64, 64, (3, 1, 1), (1, 0, 0), (1, 1, 1)),        # large temporal layer, odd frame count
 ])
 def test_bn_backward_partials_from_dgrad(shape, cmid, cout, k, pad, stride, gpu_device):
