@@ -24,7 +24,8 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libavid_hip.so")
+# AVID_HIP_LIB: a development switch (tools/build_variant.sh) — A/B of two builds of the library on one GPU box
+LIB_PATH = os.environ.get("AVID_HIP_LIB") or os.path.join(_HERE, "libavid_hip.so")
 
 AVID_OK = 0
 
@@ -96,6 +97,7 @@ SIGNATURES = {
     "avid_conv_kernel_name": (_i, [_dp, _i, C.c_char_p, _i]),
     "avid_conv_uses_wino": (_i, [_dp, _i]),
     "avid_wino_configure": (_i, [_i, _i64, _i]),
+    "avid_wino2_configure": (_i, [_i]),
     "avid_bn_workspace_bytes": (_sz, [_i64, _i]),
     "avid_bn_fwd_train": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "avid_bn_fwd_eval": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),

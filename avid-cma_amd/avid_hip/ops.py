@@ -310,8 +310,8 @@ def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
                lib.raw("avid_conv_fwd_stats_rows")(C.byref(d)))
         d.bn_bwd_rows = 0 if channel_first else lib.raw("avid_conv_dgrad_bn_rows")(C.byref(d))
         d.groupable = bool(lib.raw("avid_conv_wgrad_groupable")(C.byref(d)))
-        d.wino_fwd = bool(lib.raw("avid_conv_uses_wino")(C.byref(d), 0))
-        d.wino_dgrad = bool(lib.raw("avid_conv_uses_wino")(C.byref(d), 1))
+        d.wino_fwd = int(lib.raw("avid_conv_uses_wino")(C.byref(d), 0))        # 0, 1 (wino_kernel) or 2 (wino2_kernel)
+        d.wino_dgrad = int(lib.raw("avid_conv_uses_wino")(C.byref(d), 1))
         _DESC_CACHE[key] = hit
     return hit
 
@@ -320,6 +320,13 @@ def wino_configure(enabled=-1, min_pixels=-1, max_channels=-1):
     """Dispatch switches of the Winograd kernels (``avid_wino_configure``; negative = environment / default) — and
     drop the per-layer plans cached here, which depend on them."""
     lib.call("avid_wino_configure", int(enabled), int(min_pixels), int(max_channels))
+    _DESC_CACHE.clear()
+
+
+def wino2_configure(min_rounds_x10=-1):
+    """Which Winograd forward / input-gradient kernel a layer takes (``avid_wino2_configure``): 0 = always
+    ``wino2_kernel``, negative = environment / default (layers with >= 1.5 rounds of 64-tile units)."""
+    lib.call("avid_wino2_configure", int(min_rounds_x10))
     _DESC_CACHE.clear()
 
 
@@ -565,7 +572,7 @@ class _ConvCL(Function):
         stats = None
         if want_stats and srows > 0 and bias is None and not relu:
             stats = torch.empty((srows, 2, cout), dtype=torch.float32, device=x.device)
-        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(_u_for(w, 1) if d.wino_fwd else None), _p(addend), _p(bias),
+        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(_u_for(w, 1) if d.wino_fwd == 1 else None), _p(addend), _p(bias),
                  int(relu), _p(y), _p(stats), _p(ws),
                  ws.numel() if ws is not None else 0, _stream())
         ctx.d, ctx.relu, ctx.channel_first = d, relu, channel_first
@@ -722,7 +729,7 @@ class _ConvCL(Function):
                 s4 = src.stats4
                 fuse = lib.BnBwdFuse(_p(src.x), _p(s4[2]), _p(s4[3]), _p(s4[0]), _p(s4[1]), int(src.relu),
                                      _p(src.partials))
-            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_u_for(w, 2) if d.wino_dgrad else _wt_for(w)), _p(add),
+            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p((_u_for(w, 2) if d.wino_dgrad == 1 else None) if d.wino_dgrad else _wt_for(w)), _p(add),
                      add_stride, _p(dx),
                      C.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), st)
         if side is not None:

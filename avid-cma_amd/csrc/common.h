@@ -57,6 +57,7 @@ int stem_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* 
 
 // wino.hip: Winograd F(2x2, 3x3) forward / input gradient of the (1,3,3) stride-1 layers (mode 0 / 1)
 bool wino_supported(const avid_conv_desc* d, int mode);
+int wino_variant(const avid_conv_desc* d, int mode);      // 1: wino_kernel, 2: wino2_kernel (the layout of a pre-transformed U follows it)
 size_t wino_ws_bytes(const avid_conv_desc* d, int mode);
 int wino_grid(const avid_conv_desc* d, int mode);
 int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* w, const float* u_pre, float* dst,
@@ -94,8 +95,11 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
 // U[(xi * Cn + n) * Cr + k] = (G g G^T)[xi / 4][xi % 4],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], for the elements
 // i = first, first + stride, ... of the Cn x Cr (n, k) pairs.  flip = 0: g[a][b] = w[n][a][b][k] (forward); flip = 1:
 // g[a][b] = w[k][2-a][2-b][n] (input gradient).  Shared by wino_weight_kernel and weight_transpose_batched_kernel.
+// U in the operand-fragment order of the kernel that consumes it (one contiguous KB per wave load instruction):
+// frag = 2 (wino_kernel):  U[xi][n / 32][k / 32][q = (k % 16) / 4][lane = 32 ((k % 32) / 16) + n % 32][k % 4]
+// frag = 1 (wino2_kernel): U[xi][n / 64][(n % 64) / 32][k / 16][q = (k % 8) / 4][lane = 32 ((k % 16) / 8) + n % 32][k % 4]
 __device__ __forceinline__ void wino_weight_elements(const float* __restrict__ w, float* __restrict__ U, int Cn, int Cr, int Cin, int flip,
-                                     long long first, long long stride) {
+                                     long long first, long long stride, int frag) {
   for (long long i = first; i < (long long)Cn * Cr; i += stride) {
     const int k = (int)(i % Cr), n = (int)(i / Cr);
     float g[3][3];
@@ -116,7 +120,18 @@ __device__ __forceinline__ void wino_weight_elements(const float* __restrict__ w
     for (int a = 0; a < 4; ++a) {
       const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]),
                   u3 = t[a][2];
-      const long long o = ((long long)(a * 4) * Cn + n) * Cr + k, st = (long long)Cn * Cr;
+      const long long st = (long long)Cn * Cr;
+      long long o;
+      if (frag == 2) {
+        const int kk = k & 31;
+        o = (long long)(a * 4) * st +
+            ((((long long)(n >> 5) * (Cr >> 5) + (k >> 5)) * 4 + ((kk & 15) >> 2)) * 64 + ((kk >> 4) * 32 + (n & 31))) * 4 + (kk & 3);
+      } else {
+        const int kk = k & 15;
+        o = (long long)(a * 4) * st +
+            ((((long long)(n >> 6) * 2 + ((n >> 5) & 1)) * (Cr >> 4) + (k >> 4)) * 2 + ((kk & 7) >> 2)) * 256 +
+            (((kk >> 3) * 32 + (n & 31)) << 2) + (kk & 3);
+      }
       U[o] = u0;
       U[o + st] = u1;
       U[o + 2 * st] = u2;

@@ -1831,9 +1831,10 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const avid_wt_desc* __restrict__ descs) {
   __shared__ float tile[32][33];
   const avid_wt_desc d = descs[blockIdx.y];
-  if (d.mode != 0) {     // Winograd-transformed weights of a 3x3 layer (wino.hip): mode 1 forward, 2 input gradient
-    wino_weight_elements(d.w, d.wt, d.mode == 1 ? d.Cout : d.Cin, d.mode == 1 ? d.Cin : d.Cout, d.Cin, d.mode == 2,
-                         (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+  if (d.mode != 0) {     // Winograd-transformed weights of a 3x3 layer (wino.hip): mode 1 / 3 forward, 2 / 4 input gradient;
+    const bool fwd = d.mode & 1;       // 1, 2 in wino_kernel's fragment order, 3, 4 in wino2_kernel's
+    wino_weight_elements(d.w, d.wt, fwd ? d.Cout : d.Cin, fwd ? d.Cin : d.Cout, d.Cin, !fwd,
+                         (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, d.mode <= 2 ? 2 : 1);
     return;
   }
   const int tco = (d.Cout + 31) / 32, tci = (d.Cin + 31) / 32;
@@ -3161,7 +3162,7 @@ extern "C" int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* 
 extern "C" int avid_conv_uses_wino(const avid_conv_desc* d, int which) {
   if (!d || validate(d)) return 0;
   if (which == 2) return wino_wgrad_supported(d) ? 1 : 0;
-  return (which == 0 || which == 1) && wino_supported(d, which) ? 1 : 0;
+  return (which == 0 || which == 1) && wino_supported(d, which) ? wino_variant(d, which) : 0;
 }
 
 extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* buf, int len) {

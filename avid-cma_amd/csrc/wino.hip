@@ -22,11 +22,16 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace avid {
 
 constexpr int W_TB = 32, W_CK = 32, W_VLD = W_CK + 4;
 constexpr int W_LDS_FLOATS = 16 * W_TB * W_VLD;
+#ifndef AVID_W_LATE
+#define AVID_W_LATE -1     // (>= 0: issue the next chunk's patch loads after product slot N instead of before the products: no difference, 174-175 us on conv2x either way)
+#endif
+constexpr int W_LATE = AVID_W_LATE;
 constexpr int W_TAB_INTS = 2 * W_TB * 4;          // double-buffered tile table: (frame or -1, ti, tj, -) per tile of a unit
 
 struct WinoArgs {
@@ -45,14 +50,15 @@ struct WinoArgs {
   long long ntiles;
   int units;                            // tile blocks x column blocks, column block fastest
   int xcd_local;                        // XCD-contiguous unit order (AVID_WINO_XCD, default 1)
+  int v2;                               // host only: launch wino2_kernel (units are 64-tile blocks then)
 };
 
 // U[(xi * Cn + n) * Cr + k] = (G g G^T)[xi / 4][xi % 4],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 // flip = 0: g[a][b] = w[n][a][b][k] (forward);  flip = 1: g[a][b] = w[k][2-a][2-b][n] (input gradient)
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cn,
-                                                          int Cr, int Cin, int flip) {
+                                                          int Cr, int Cin, int flip, int frag) {
   wino_weight_elements(w, U, Cn, Cr, Cin, flip, (long long)blockIdx.x * blockDim.x + threadIdx.x,
-                       (long long)gridDim.x * blockDim.x);
+                       (long long)gridDim.x * blockDim.x, frag);
 }
 
 #ifdef AVID_WINO_TRACE
@@ -68,6 +74,7 @@ extern "C" int avid_debug_wino_trace(long long* host) {
 // (tools/mfma_shadow: the fp32 MFMA runs at the vector rate, on the same lanes), a packed add costs the same as a
 // scalar one — and the compiler UNPACKS v_pk_add_f32 wherever it sits behind an MFMA (two instructions for one).
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4_t __attribute__((__vector_size__(4 * sizeof(unsigned))));
 __device__ __forceinline__ floatx2 pk_add(floatx2 a, floatx2 b) {
   floatx2 r;
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -206,24 +213,31 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
       __syncthreads();
       W_STAMP(1);
       // the next chunk's patch (of this unit, or chunk 0 of this workgroup's next unit): in flight under the products
-      if (ck + 1 < nchunks) {
-        issue_loads(e_cur, ck + 1);
-      } else {
-        e_cur = tabs[(tbuf ^ 1) * W_TB + ttl];
-        issue_loads(e_cur, 0);
-      }
+      auto issue_next = [&]() {
+        if (ck + 1 < nchunks) {
+          issue_loads(e_cur, ck + 1);
+        } else {
+          e_cur = tabs[(tbuf ^ 1) * W_TB + ttl];
+          issue_loads(e_cur, 0);
+        }
+      };
+      if (W_LATE < 0) issue_next();
       // ---- the wave's four products, computed TRANSPOSED (D[n][tile] = sum_k U[n][k] V[tile][k]: U is the MFMA's A
       // operand): a lane then holds ONE tile and, in every group of four accumulator registers, four consecutive
       // output channels — the output transform stores 16 contiguous bytes per lane and needs one destination offset
       // per lane instead of sixteen.  U (from L2) sits in three rotating slots of (transform point, 32-column
       // half): the loads run two slots ahead of the MFMAs that consume them
       floatx4 bv[3][4];
+      // U in fragment order (wino_weight_elements, frag = 2): a wave's load instruction reads ONE contiguous KB.  As
+      // U[xi][n][k] it read 2 x 16 bytes of 32 rows, which the texture addresser serves at one lane per cycle — 107 ns
+      // per instruction beside the MFMAs against 13-27 ns (tools/mfma_shadow): 256 such loads per CU and chunk kept the
+      // addresser as busy as the matrix pipe.
       auto load_b = [&](int s_) {
         const int xi = wave * 4 + (s_ >> 1), j = s_ & 1;
+        const unsigned vo = (unsigned)(lane * 16 + ((((xi * (Cn >> 5) + cb * 2 + j) * nchunks + ck) * 4) * 64) * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          bv[s_ % 3][q] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
-              rsU, (unsigned)((((long long)xi * Cn + cb * 64 + j * 32 + l31) * Cr + ck * W_CK + 16 * h + 4 * q) * 4), 0, 0));
+          bv[s_ % 3][q] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsU, vo + q * 1024u, 0, 0));
       };
       load_b(0);
       load_b(1);
@@ -234,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
       for (int s_ = 0; s_ < 8; ++s_) {
         const int c = s_ >> 1, j = s_ & 1;
         if (s_ + 2 < 8) load_b(s_ + 2);
+        if (s_ == W_LATE) issue_next();
         if (j == 0) {
           const float* Ap = sm + ((wave * 4 + c) * W_TB + l31) * W_VLD + 16 * h;
 #pragma unroll
@@ -369,6 +384,394 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
         const int cc = c % 64;
         a = (red[cc] + red[64 + cc]) + (red[128 + cc] + red[192 + cc]);
         b = (red[256 + cc] + red[320 + cc]) + (red[384 + cc] + red[448 + cc]);
+      }
+      row[c] = a;
+      row[Cn + c] = b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wino2_kernel: the same computation as ONE instruction stream per SIMD (round 3).  In wino_kernel a workgroup's input
+// transform, products and output transform are phases separated by barriers, and the co-resident workgroup is meant to
+// fill the matrix pipe meanwhile; the phase trace shows what that costs: a transforming wave that competes with another
+// wave's back-to-back MFMAs gets about one vector instruction issued per MFMA (64 cycles), so ~100 instructions of
+// transform take 3 us beside 3.4 us of products, and the pipe idles whenever both workgroups are outside their products.
+// Inside ONE wave a vector instruction between two MFMAs costs ~5 cycles (tools/mfma_shadow).  So here:
+//   * one workgroup of 4 waves per CU (one wave per SIMD, up to 512 registers), unit = 64 tiles x 64 output channels;
+//     wave (th, nh) owns ALL 16 transform points of the 32 tiles x 32 channels block (tile half th, channel half nh):
+//     16 accumulators of 32 x 32, and the output transform is lane-local — no exchange through LDS, no barrier;
+//   * the reduction runs in chunks of 16 channels: V[16][64 tiles][16] = 64 KB per stage, two stages; while chunk k is
+//     multiplied out of one stage, every thread transforms its 4x4 patch x 4 channels of chunk k + 1 (registers, loaded
+//     during chunk k - 1) into the other stage and then issues the loads of chunk k + 2 — all of it between the MFMAs
+//     of the products, ONE barrier per chunk;
+//   * U comes straight from L2 into four rotating register slots, three transform points ahead.  Vector memory loads
+//     return in order, so a wait for U also waits for every patch load issued before it: the patch loads go out two per
+//     transform point, U first, and are not needed before the next chunk;
+//   * a unit's first MFMA per transform point takes a constant-zero C operand (no 256-instruction clear);
+//   * BatchNorm sums: the four output pixels of a tile are summed in the lane, then one pass per 16 channels through
+//     the per-wave LDS staging of wino_kernel.
+// Units are 64-tile blocks dealt as in wino_kernel; it is used where a layer has enough of them to fill the CUs.
+#ifndef AVID_W2_DBG
+#define AVID_W2_DBG 0      // development: 1 skip transform, 2 skip patch loads, 4 skip U loads, 8 skip output phase, 16 skip V reads
+#endif
+constexpr int W2_DBG = AVID_W2_DBG;
+#ifndef AVID_W2_T0
+#define AVID_W2_T0 8
+#endif
+constexpr int W2_T0 = AVID_W2_T0;
+#ifndef AVID_W2_STAGGER
+#define AVID_W2_STAGGER 1
+#endif
+constexpr int W2_TB = 64, W2_CK = 16;
+constexpr int W2_STAGE = 16 * W2_TB * W2_CK;                 // floats per stage
+constexpr int W2_TAB_OFF = 2 * W2_STAGE;                     // three tile tables of 64 x int4
+constexpr int W2_ST_OFF = W2_TAB_OFF + 3 * W2_TB * 4;        // statistics staging: 4 waves x 512 floats
+constexpr int W2_LDS_FLOATS = W2_ST_OFF + 4 * 512;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void wino2_kernel(const WinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int th = wave & 1, nh = wave >> 1;
+  const int H = p.H, W = p.W, TW = p.TW, TPF = p.TH * p.TW, Cr = p.Cr, Cn = p.Cn;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((long long)p.F * H * W * Cr * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, 16 * Cn * Cr * 4, 0x00020000);
+  const int dbytes = (int)((long long)p.F * H * W * Cn * 4);
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst, 0, dbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI & 2) ? p.addend : p.src), 0, (EPI & 2) ? dbytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI & 4) ? p.bnb_x : p.src), 0, (EPI & 4) ? dbytes : 0, 0x00020000);
+  const int nchunks = Cr / W2_CK;
+  // unit order: see wino_kernel
+  const bool xl = p.xcd_local && gridDim.x % (8 * p.ncb) == 0;
+  const int lid = xl ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int cb = lid % p.ncb, q = lid / p.ncb, Gq = (int)gridDim.x / p.ncb;
+  const int nblk = p.units / p.ncb;
+  const int fullq = xl ? nblk / Gq * Gq : nblk;
+  const int qlast = fullq + (q % (Gq / 8)) * 8 + q / (Gq / 8);
+  auto blk_after = [&](int blk) {
+    if (blk >= fullq) return nblk;
+    const int nx = blk + Gq;
+    return nx < fullq ? nx : qlast;
+  };
+  const int blk0 = q < fullq ? q : (xl ? qlast : q);
+  int4* tabs = reinterpret_cast<int4*>(sm + W2_TAB_OFF);
+  auto fill_tab = [&](int blk, int buf) {
+    if (tid < W2_TB) {
+      const long long t = (long long)blk * W2_TB + tid;
+      int4 e = {-1, 0, 0, 0};
+      if (blk < nblk && t < p.ntiles) {
+        const int f = (int)(t / TPF), rem = (int)(t - (long long)f * TPF);
+        e.x = f; e.y = rem / TW; e.z = rem - e.y * TW;
+      }
+      tabs[buf * W2_TB + tid] = e;
+    }
+  };
+  // ---- this thread's item of the input transform: tile tt, channels c4 .. c4 + 3 of the chunk
+  const int tt = tid >> 2, c4 = (tid & 3) * 4;
+  const unsigned px_b = (unsigned)Cr * 4u, row_b = (unsigned)W * px_b;
+  floatx4 raw[4][4];
+  // load cursor: the chunk whose patch is loaded next (two chunks ahead of the products)
+  unsigned ld_o11 = 0;
+  bool ld_oky[4] = {false, false, false, false}, ld_okx[4] = {false, true, false, false};
+  int ld_ck = 0, ld_buf = 0;
+  auto ld_unit = [&](int buf) {                    // the cursor enters the unit whose table sits in buffer buf
+    const int4 e = tabs[buf * W2_TB + tt];
+    const bool t_ok = e.x >= 0;
+    const int y1 = 2 * e.y, x1 = 2 * e.z;
+    // based at patch element (1, 1), which is always inside the frame (see wino_kernel)
+    ld_o11 = (unsigned)(((e.x * H + y1) * W + x1) * Cr + c4) * 4u;
+    ld_oky[0] = t_ok && e.y > 0; ld_oky[1] = t_ok; ld_oky[2] = t_ok && y1 + 1 < H; ld_oky[3] = t_ok && y1 + 2 < H;
+    ld_okx[0] = e.z > 0; ld_okx[1] = true; ld_okx[2] = x1 + 1 < W; ld_okx[3] = x1 + 2 < W;
+  };
+  auto ld_issue = [&](int a, int b) {
+    const unsigned rowoff = ld_o11 + (unsigned)(a - 1) * row_b;
+    raw[a][b] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                rsX, (ld_oky[a] && ld_okx[b]) ? (b == 0 ? rowoff - px_b : rowoff) : 0x80000000u,
+                                                ld_ck * (W2_CK * 4) + (b == 0 ? 0 : (b - 1) * (int)px_b), 0));
+  };
+  auto ld_advance = [&]() {
+    if (++ld_ck == nchunks) {
+      ld_ck = 0;
+      ld_buf = ld_buf == 2 ? 0 : ld_buf + 1;
+      ld_unit(ld_buf);
+    }
+  };
+  // transform: column pass (raw -> w_), row pass in eight slices of two transform points (w_ -> LDS)
+  floatx4 w_[4][4];
+  auto col_pass = [&]() {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      w_[0][b] = pk4_sub(raw[0][b], raw[2][b]);
+      w_[1][b] = pk4_add(raw[1][b], raw[2][b]);
+      w_[2][b] = pk4_sub(raw[2][b], raw[1][b]);
+      w_[3][b] = pk4_sub(raw[1][b], raw[3][b]);
+    }
+  };
+  // V[xi][tile][16]: the four 16-byte slots of a row are XOR-swizzled by (tile >> 2) & 3 — 16 lanes of a 16-byte
+  // access then cover all 64 banks once, for the stores (4 threads per tile) and for the fragment loads (lane = tile)
+  const int wr_off = tt * W2_CK + (((tid & 3) ^ ((tt >> 2) & 3)) << 2);
+  auto row_slice = [&](float* Wst, int i) {
+    const int a = i >> 1;
+    float* dst = Wst + (a * 4) * (W2_TB * W2_CK) + wr_off;
+    if ((i & 1) == 0) {
+      *reinterpret_cast<floatx4*>(dst + 0 * (W2_TB * W2_CK)) = pk4_sub(w_[a][0], w_[a][2]);
+      *reinterpret_cast<floatx4*>(dst + 1 * (W2_TB * W2_CK)) = pk4_add(w_[a][1], w_[a][2]);
+    } else {
+      *reinterpret_cast<floatx4*>(dst + 2 * (W2_TB * W2_CK)) = pk4_sub(w_[a][2], w_[a][1]);
+      *reinterpret_cast<floatx4*>(dst + 3 * (W2_TB * W2_CK)) = pk4_sub(w_[a][1], w_[a][3]);
+    }
+  };
+  // ---- products: operands
+  const int ptile = 32 * th + l31;
+  const int psw = (l31 >> 2) & 3;
+  const int rd_off0 = ptile * W2_CK + (((2 * h) ^ psw) << 2), rd_off1 = ptile * W2_CK + (((2 * h + 1) ^ psw) << 2);
+  // U in fragment order (wino_weight_elements, frag = 1): one contiguous KB per load instruction
+  const unsigned u_voff = (unsigned)(lane * 16), u_voff2 = u_voff + 1024u;
+  const int u_xi = Cn * Cr * 4;
+  // (nh is wave-uniform, which the compiler cannot see: without readfirstlane every U load sits in a waterfall loop)
+  const int u_base = __builtin_amdgcn_readfirstlane((cb * 2 + nh) * nchunks * 2048), u_ck = 2048;
+  floatx4 bv[4][2], av[2][2];
+  auto load_u = [&](int slot, int xi, int ck) {
+    bv[slot][0] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsU, u_voff, u_base + xi * u_xi + ck * u_ck, 0));
+    bv[slot][1] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsU, u_voff2, u_base + xi * u_xi + ck * u_ck, 0));
+  };
+  auto read_v = [&](const float* Vst, int slot, int xi) {
+    av[slot][0] = *reinterpret_cast<const floatx4*>(Vst + xi * (W2_TB * W2_CK) + rd_off0);
+    av[slot][1] = *reinterpret_cast<const floatx4*>(Vst + xi * (W2_TB * W2_CK) + rd_off1);
+  };
+  floatx16 acc[16];
+  // BatchNorm partial sums (EPI & 5): this lane owns channel 16 r + (lane & 15) of the wave's 32 (r = 0, 1) over the
+  // tiles 8 (lane >> 4) .. + 7 of every unit
+  float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};
+
+  // ---- stagger: all workgroups start together and do identical work, so the whole chip would load, multiply and
+  // store in lockstep — the 16 stores per lane of a unit's output then hit memory as one 17 MB burst while the matrix
+  // pipes wait for it (vector memory operations complete in order: the next operand load is behind the stores).
+  // Workgroups that have one unit less than the longest delay their start by up to most of a unit's time.
+#if AVID_W2_STAGGER
+  {
+    int mine = 0;
+    for (int b = blk0; b < nblk; b = blk_after(b)) ++mine;
+    const int most = (nblk + Gq - 1) / Gq;
+    if (mine < most) {
+      const int steps = ((lid * 5) & 7) * nchunks / 8 * AVID_W2_STAGGER;
+      for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
+#endif
+  // ---- prologue
+  fill_tab(blk0, 0);
+  fill_tab(blk_after(blk0), 1);
+  __syncthreads();
+  ld_unit(0);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) ld_issue(a, b);
+  ld_advance();
+  col_pass();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) row_slice(sm, i);
+  load_u(0, 0, 0);
+  load_u(1, 1, 0);
+  load_u(2, 2, 0);
+
+  // Schedule of a chunk (xi = transform point whose 8 MFMAs the step carries):
+  //   first chunk of a unit only: the 16 patch loads of the NEXT chunk at xi = 0 .. 3 (nothing is held in registers
+  //   across the output transform, which needs them: with the patch live there the allocator spilled it everywhere);
+  //   xi = 8: column pass; xi = 8 .. 15: the row pass, two transform points per step, into the other stage;
+  //   xi = 10 .. 15 (not in a unit's last chunk): the patch loads of the chunk after the next, rows as they die.
+  auto chunk = [&](auto first_tag, int ck, int stage) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int ck_n = ck + 1 < nchunks ? ck + 1 : 0;
+    const bool last = !FIRST && ck + 1 == nchunks;
+    const float* Vst = sm + stage * W2_STAGE;
+    float* Wst = sm + (stage ^ 1) * W2_STAGE;
+    read_v(Vst, 0, 0);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+      if (!(W2_DBG & 4)) { if (xi + 3 < 16) load_u((xi + 3) & 3, xi + 3, ck); else load_u((xi + 3) & 3, xi + 3 - 16, ck_n); }
+      if (!(W2_DBG & 16) && xi + 1 < 16) read_v(Vst, (xi + 1) & 1, xi + 1);
+      if (!(W2_DBG & 2) && FIRST && xi < 4) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ld_issue(xi, b);
+        if (xi == 3) ld_advance();
+      }
+      constexpr int T0 = FIRST ? 8 : W2_T0;                 // step of the column pass
+      if (!(W2_DBG & 1) && xi == T0) col_pass();
+      if (!(W2_DBG & 1) && xi >= T0 && xi < T0 + 8) row_slice(Wst, xi - T0);
+      if (!(W2_DBG & 2) && xi >= T0 + 2 && xi < T0 + 8 && !last) {
+        const int j = xi - (T0 + 2);           // 3, 3, 3, 3, 2, 2 loads
+        const int n = j < 4 ? 3 : 2, base = j < 4 ? j * 3 : 12 + (j - 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (k < n) ld_issue((base + k) >> 2, (base + k) & 3);
+        if (j == 5) ld_advance();
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (FIRST && e == 0) {
+          const floatx16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[xi & 3][0][0], av[xi & 1][0][0], z16, 0, 0, 0);
+        } else {
+          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[xi & 3][e >> 2][e & 3], av[xi & 1][e >> 2][e & 3], acc[xi], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  float* st = sm + W2_ST_OFF + wave * 512;
+  const int st_row = l31 * 16, st_sw = ((l31 >> 1) & 3) * 4;
+  const int st_ch = lane & 15, st_tg = lane >> 4;
+  auto col_sums = [&]() {
+    float s_ = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int tile = 8 * st_tg + ((m + st_tg) & 7);
+      s_ += st[tile * 16 + (st_ch ^ (((tile >> 1) & 3) * 4))];
+    }
+    return s_;
+  };
+
+  int ubuf = 0;                                  // table buffer of the current unit
+  for (int blk = blk0; blk < nblk; blk = blk_after(blk)) {
+    __syncthreads();
+    fill_tab(blk_after(blk_after(blk)), ubuf == 0 ? 2 : ubuf - 1);     // unit u + 2 -> buffer (u + 2) % 3
+    chunk(std::true_type{}, 0, 0);
+    for (int ck = 1; ck < nchunks; ++ck) {
+      if (!(W2_DBG & 256)) __syncthreads();
+      chunk(std::false_type{}, ck, ck & 1);
+    }
+    // ---- output transform, lane-local: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]; the lane holds tile ptile and, per
+    // group g of four accumulator registers, the channels 8 g + 4 h .. + 3 of the wave's 32
+    const int4 te = tabs[ubuf * W2_TB + ptile];
+    ubuf = ubuf == 2 ? 0 : ubuf + 1;
+    if (W2_DBG & 8) {                 // (timing experiment: no output transform, every accumulator stored once)
+      const unsigned o_ = (W2_DBG & 64) ? (te.x == 12345678 ? 0u : 0x80000000u) : (unsigned)((((te.x * H + 2 * te.y) * W + 2 * te.z) * Cn + cb * 64 + nh * 32 + 4 * h) * 4);
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const floatx4 v = floatx4{acc[x][4 * (x & 3)], acc[x][4 * (x & 3) + 1], acc[x][4 * (x & 3) + 2], acc[x][4 * (x & 3) + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, v), rsD, te.x >= 0 ? o_ : 0x80000000u, (x & 3) * 32, 0);
+        asm volatile("s_nop 1" : : "v"(v));
+      }
+      continue;
+    }
+    const bool tok = te.x >= 0;
+    const int y0 = 2 * te.y, x0 = 2 * te.z;
+    const bool okp[4] = {tok, tok && x0 + 1 < W, tok && y0 + 1 < H, tok && y0 + 1 < H && x0 + 1 < W};
+    const int obase = (((te.x * H + y0) * W + x0) * Cn + cb * 64 + nh * 32 + 4 * h) * 4;       // bytes
+    unsigned ooff[4];
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) ooff[pq] = okp[pq] ? (unsigned)(obase + (((pq >> 1) * W + (pq & 1)) * Cn) * 4) : 0x80000000u;
+    floatx4 s0[4], s1[4];
+    floatx4 ad[2][4], xb[2][4];
+    auto epi_loads = [&](int g) {
+#pragma unroll
+      for (int pq = 0; pq < 4; ++pq) {
+        if (EPI & 2) ad[g & 1][pq] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ooff[pq], g * 32, 0));
+        if (EPI & 4) xb[g & 1][pq] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, ooff[pq], g * 32, 0));
+      }
+    };
+    if (EPI & 6) epi_loads(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if ((EPI & 6) && g + 1 < 4) epi_loads(g + 1);
+      floatx4 T[4][2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        // (read from the accumulation registers HERE: left to the compiler, the 256 reads of a unit are hoisted into
+        // the block behind the chunk loop and ~150 values wait in vector registers — the allocator then spills the
+        // per-lane offsets the chunk loop needs and reloads them with s_waitcnt vmcnt(0) at the top of every chunk)
+        floatx4 M[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float t_;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t_) : "a"(acc[4 * a + b][4 * g + i]));
+            M[b][i] = t_;
+          }
+        T[a][0] = pk4_add(pk4_add(M[0], M[1]), M[2]);
+        T[a][1] = pk4_sub(pk4_sub(M[1], M[2]), M[3]);
+      }
+      floatx4 Y[4];
+#pragma unroll
+      for (int qo = 0; qo < 2; ++qo) {
+        Y[qo] = pk4_add(pk4_add(T[0][qo], T[1][qo]), T[2][qo]);
+        Y[2 + qo] = pk4_sub(pk4_sub(T[1][qo], T[2][qo]), T[3][qo]);
+      }
+      floatx4 bsc, bsh, bmu, bis;
+      if (EPI & 4) {
+        const int col = cb * 64 + nh * 32 + 8 * g + 4 * h;
+        bsc = *reinterpret_cast<const floatx4*>(p.bnb_scale + col); bsh = *reinterpret_cast<const floatx4*>(p.bnb_shift + col);
+        bmu = *reinterpret_cast<const floatx4*>(p.bnb_mean + col); bis = *reinterpret_cast<const floatx4*>(p.bnb_invstd + col);
+      }
+      if (EPI & 5) { s0[g] = floatx4{0.f, 0.f, 0.f, 0.f}; s1[g] = s0[g]; }
+#pragma unroll
+      for (int pq = 0; pq < 4; ++pq) {
+        floatx4 v = Y[pq];
+        if (EPI & 2) v = pk4_add(v, ad[g & 1][pq]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, v), rsD, (W2_DBG & 128) ? (te.x == 12345678 ? 0u : 0x80000000u) : ooff[pq], g * 32, 0);
+        // The store reads its four data registers over several cycles.  The compiler's hazard recogniser assumes a
+        // buffer store whose soffset is an SGPR is exempt from the ">64-bit store data, then VALU write" wait state;
+        // measured on gfx950 it is not: a v_pk_add_f32 scheduled right behind the last store of the unit overwrote the
+        // fourth dword in flight (wrong values in channel 8 g + 4 h + 3 of some tiles, run to run).  Keep v alive for
+        // two more wait states.
+        asm volatile("s_nop 1" : : "v"(v));
+        if (EPI & 5) {
+          floatx4 t0 = okp[pq] ? v : floatx4{0.f, 0.f, 0.f, 0.f};
+          if (EPI & 1) {
+            s0[g] += t0;
+            s1[g] += t0 * t0;
+          } else {
+            const floatx4 x_ = xb[g & 1][pq];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float t = (!p.bnb_relu || fmaf(x_[i], bsc[i], bsh[i]) > 0.f) ? t0[i] : 0.f;
+              s0[g][i] += t;
+              s1[g][i] += t * ((x_[i] - bmu[i]) * bis[i]);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);      // one group at a time: hoisting the accumulator reads of all four costs 150 registers
+    }
+    if (EPI & 5) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        *reinterpret_cast<floatx4*>(st + st_row + ((4 * h) ^ st_sw)) = s0[2 * r];
+        *reinterpret_cast<floatx4*>(st + st_row + ((8 + 4 * h) ^ st_sw)) = s0[2 * r + 1];
+        cs[r] += col_sums();
+        *reinterpret_cast<floatx4*>(st + st_row + ((4 * h) ^ st_sw)) = s1[2 * r];
+        *reinterpret_cast<floatx4*>(st + st_row + ((8 + 4 * h) ^ st_sw)) = s1[2 * r + 1];
+        cq[r] += col_sums();
+      }
+    }
+  }
+  if ((EPI & 5) && p.stats) {   // one partial row [2][Cn] per workgroup
+    __syncthreads();
+    float* red = sm;            // [2 terms][4 waves][32]
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float a = cs[r], b = cq[r];
+      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+      if (lane < 16) {
+        red[wave * 32 + 16 * r + lane] = a;
+        red[128 + wave * 32 + 16 * r + lane] = b;
+      }
+    }
+    __syncthreads();
+    float* row = p.stats + (long long)blockIdx.x * 2 * Cn;
+    for (int c = tid; c < Cn; c += 256) {
+      float a = 0.f, b = 0.f;
+      if (c / 64 == cb) {
+        const int cc = c % 64, w0 = (cc >> 5) * 2, c32 = cc & 31;       // waves w0 (th = 0) and w0 + 1 (th = 1)
+        a = red[w0 * 32 + c32] + red[(w0 + 1) * 32 + c32];
+        b = red[128 + w0 * 32 + c32] + red[128 + (w0 + 1) * 32 + c32];
       }
       row[c] = a;
       row[Cn + c] = b;
@@ -691,8 +1094,26 @@ size_t wino_ws_bytes(const avid_conv_desc* d, int mode) {
   return sizeof(float) * 16 * (size_t)d->Cin * d->Cout;
 }
 
+// wino2_kernel (one workgroup per CU, 64-tile units) where the layer has at least AVID_WINO2_MIN_ROUNDS/10 rounds of
+// units for the CUs; AVID_WINO2=0 keeps wino_kernel everywhere
+static int g_wino2_override = -1;      // avid_wino2_configure
+
+static bool wino_use_v2(const avid_conv_desc* d, int mode) {
+  static int on = -1, env_r10 = 0;
+  if (on < 0) { on = wino_env("AVID_WINO2", 1); env_r10 = wino_env("AVID_WINO2_MIN_ROUNDS", 15); }
+  if (!on) return false;
+  const int min_r10 = g_wino2_override >= 0 ? g_wino2_override : env_r10;
+  const int Cn = mode ? d->Cin : d->Cout, ncb = Cn / 64;
+  const long long TH = (d->Hi + 1) / 2, TW = (d->Wi + 1) / 2;
+  const long long units = ceil_div((long long)d->B * d->Ti * TH * TW, W2_TB) * ncb;
+  return units * 10 >= (long long)min_r10 * wino_cus();
+}
+
+int wino_variant(const avid_conv_desc* d, int mode) { return wino_use_v2(d, mode) ? 2 : 1; }
+
 int wino_grid(const avid_conv_desc* d, int mode) {
   const int Cn = mode ? d->Cin : d->Cout, ncb = Cn / 64;
+  if (wino_use_v2(d, mode)) return wino_cus() / ncb * ncb;
   int g = 2 * wino_cus();
   g = g / ncb * ncb;
   const long long TH = (d->Hi + 1) / 2, TW = (d->Wi + 1) / 2;
@@ -702,7 +1123,22 @@ int wino_grid(const avid_conv_desc* d, int mode) {
 }
 
 template <int EPI>
+static void wino2_launch(const WinoArgs& a, int grid, hipStream_t s) {
+  auto kern = wino2_kernel<EPI>;
+  const size_t lds = sizeof(float) * W2_LDS_FLOATS;
+  static bool set[64] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+}
+
+template <int EPI>
 static void wino_launch(const WinoArgs& a, int grid, hipStream_t s) {
+  if (a.v2) { wino2_launch<EPI>(a, grid, s); return; }
   auto kern = wino_kernel<EPI>;
   const size_t lds = sizeof(float) * W_LDS_FLOATS + sizeof(int) * W_TAB_INTS;
   static bool set[64] = {false};           // the attribute is per device
@@ -727,7 +1163,8 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
   a.Cn = mode ? d->Cin : d->Cout;
   a.ncb = a.Cn / 64;
   a.ntiles = (long long)a.F * a.TH * a.TW;
-  a.units = (int)(ceil_div(a.ntiles, W_TB) * a.ncb);
+  a.v2 = wino_use_v2(d, mode) ? 1 : 0;
+  a.units = (int)(ceil_div(a.ntiles, a.v2 ? W2_TB : W_TB) * a.ncb);
   {
     static int xl = -1;
     if (xl < 0) xl = wino_env("AVID_WINO_XCD", 1);
@@ -741,7 +1178,7 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
     a.U = U;
     const long long n = (long long)a.Cn * a.Cr;
     ScopedTimer t(s, "wino_weight_kernel", 0.0, 4.0 * n * 25);
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, w, U, a.Cn, a.Cr, d->Cin, mode);
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, w, U, a.Cn, a.Cr, d->Cin, mode, a.v2 ? 1 : 2);
     rc = check_launch("wino_weight");
     if (rc) return rc;
   }
@@ -758,9 +1195,11 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
   const double M = (double)d->B * d->Ti * d->Hi * d->Wi;
   // flops: the multiply-adds the MFMAs of this kernel really execute (16 products of [tiles x Cr] x [Cr x Cn]), not
   // the direct form's 2.25x larger count; bytes: source + destination (+ addend, + x of the BatchNorm-backward sums)
-  static const char* kNames[8] = {"wino_kernel<0>", "wino_kernel<1>", "wino_kernel<2>", "wino_kernel<3>",
-                                  "wino_kernel<4>", "wino_kernel<5>", "wino_kernel<6>", "wino_kernel<7>"};
-  ScopedTimer t(s, kNames[epi & 7], 2.0 * 16.0 * (double)a.ntiles * a.Cr * a.Cn,
+  static const char* kNames[16] = {"wino_kernel<0>", "wino_kernel<1>", "wino_kernel<2>", "wino_kernel<3>",
+                                   "wino_kernel<4>", "wino_kernel<5>", "wino_kernel<6>", "wino_kernel<7>",
+                                   "wino2_kernel<0>", "wino2_kernel<1>", "wino2_kernel<2>", "wino2_kernel<3>",
+                                   "wino2_kernel<4>", "wino2_kernel<5>", "wino2_kernel<6>", "wino2_kernel<7>"};
+  ScopedTimer t(s, kNames[(epi & 7) + 8 * a.v2], 2.0 * 16.0 * (double)a.ntiles * a.Cr * a.Cn,
                 4.0 * M * (a.Cr + a.Cn * (1 + (addend ? 1 : 0) + ((epi & 4) ? 1 : 0))));
   switch (epi) {
     case 0: wino_launch<0>(a, grid, s); break;
@@ -849,6 +1288,11 @@ int wino_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* 
 }
 
 }  // namespace avid
+
+extern "C" int avid_wino2_configure(int min_rounds_x10) {
+  avid::g_wino2_override = min_rounds_x10;
+  return AVID_OK;
+}
 
 extern "C" int avid_wino_configure(int enabled, int64_t min_pixels, int max_channels) {
   avid::g_wino_override[0] = enabled < 0 ? -1 : (enabled ? 1 : 0);

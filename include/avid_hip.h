@@ -76,16 +76,17 @@ size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d);
  * avid_conv_fwd_stats_rows(d) (0 = this layer cannot produce them), written by the conv epilogue so that
  * avid_bn_fwd_train can skip its statistics pass over y.  Needs bias == NULL and relu == 0. */
 int avid_conv_fwd_stats_rows(const avid_conv_desc* d);
-/* u (or NULL): for a layer on the Winograd path (avid_conv_uses_wino(d, 0)), its weights already transformed by
- * avid_weight_transpose_batched (a mode-1 descriptor, current for this w): the call then skips its own transform launch.
- * Ignored by every other layer. */
+/* u (or NULL): for a layer on the Winograd path (v = avid_conv_uses_wino(d, 0) != 0), its weights already transformed by
+ * avid_weight_transpose_batched (a descriptor of mode 1 if v == 1, mode 3 if v == 2; current for this w): the call then
+ * skips its own transform launch.  Ignored by every other layer. */
 int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* u, const float* addend,
                   const float* bias, int relu, float* y, float* bn_partials, void* ws, size_t ws_bytes,
                   avid_stream_t stream);
 
 /* dx = conv_transpose(dy, w) [+ addend].  ws: scratch for the transposed weights (+ split-K slabs).
  * wt: the weights already repacked by avid_weight_transpose_batched (current for this w) — as [Cin][taps][Cout], or,
- * for a layer whose input gradient runs on the Winograd path (avid_conv_uses_wino(d, 1)), its mode-2 transform — or NULL
+ * for a layer whose input gradient runs on the Winograd path (v = avid_conv_uses_wino(d, 1)), its mode-2 (v == 1) or
+ * mode-4 (v == 2) transform — or NULL
  * to repack inside the call (one extra small launch per layer). */
 size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d);
 /* bn (or NULL): dx is the COMPLETE gradient of the output of a training-mode BatchNorm(+ReLU) whose input was
@@ -121,16 +122,19 @@ typedef struct avid_wt_desc {
   const float* w;
   float* wt;
   int32_t Cout, ntaps, Cin;
-  int32_t mode; /* 0: wt[Cin][taps][Cout]; 3x3 layers on the Winograd path (ntaps = 9): 1: wt = U[16][Cout][Cin] for the
-                   forward (pass it as `u` to avid_conv_fwd), 2: wt = U[16][Cin][Cout] with flipped taps for the input
-                   gradient (pass it as `wt` to avid_conv_dgrad) */
+  int32_t mode; /* 0: wt[Cin][taps][Cout]; 3x3 layers on the Winograd path (ntaps = 9): wt = the 16 x Cout x Cin transformed
+                   weights U in the operand-fragment order of the kernel that will read them — 1 / 3: for the forward
+                   (pass it as `u` to avid_conv_fwd), 2 / 4: with flipped taps and swapped channel roles for the input
+                   gradient (pass it as `wt` to avid_conv_dgrad); 1, 2 for wino_kernel, 3, 4 for wino2_kernel
+                   (avid_conv_uses_wino says which of the two a layer runs on) */
 } avid_wt_desc;
 int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_dev, int64_t max_elems, avid_stream_t stream);
 
 /* Which kernel instantiation a descriptor dispatches to (which: 0 fwd, 1 dgrad, 2 wgrad), e.g.
  * "igemm_kernel<4,1,1,2,1>" — lets bench.py attribute HIP-event timings to rocprofv3 kernel names. */
 int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* buf, int len);
-/* 1 if this layer's forward (which 0) / input gradient (1) / weight gradient (2) runs on the Winograd kernels. */
+/* Nonzero if this layer's forward (which 0) / input gradient (1) / weight gradient (2) runs on the Winograd kernels;
+ * for which 0 / 1: 1 = wino_kernel, 2 = wino2_kernel (layers with >= 1.5 rounds of 64-tile units for the CUs). */
 int avid_conv_uses_wino(const avid_conv_desc* d, int which);
 
 /* Dispatch switches of the Winograd path (defaults: on, layers of >= 24576 output pixels, <= 128 output channels;
@@ -140,6 +144,11 @@ int avid_conv_uses_wino(const avid_conv_desc* d, int which);
  * must drop them (ops.wino_configure does).  Parity tests use it to send the reference-generated small fixtures
  * (tests/golden) through the Winograd kernels (models/network_blocks.py:35,40 at 2 clips). */
 int avid_wino_configure(int enabled, int64_t min_pixels, int max_channels);
+/* Which of the two forward / input-gradient kernels a Winograd layer takes: wino2_kernel (one workgroup per CU, 64-tile
+ * units, one instruction stream per SIMD) where the layer has at least min_rounds_x10 / 10 rounds of units for the CUs
+ * (default 15, environment AVID_WINO2_MIN_ROUNDS; AVID_WINO2=0: never), wino_kernel otherwise.  0 sends every Winograd
+ * layer through wino2_kernel (tests), negative restores the environment / default. */
+int avid_wino2_configure(int min_rounds_x10);
 
 /* dw[Cout][kt][kh][kw][Cin] = sum_m dy[m][:]^T x_col[m][:]  (deterministic split-M + tree reduce). */
 size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d);

@@ -33,16 +33,30 @@ def gpu_device():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["default", "wino_forced"])
+@pytest.fixture(params=["default", "wino_forced", "wino2_forced"])
 def wino_mode(request, gpu_device):
     """"wino_forced": every (1,3,3) stride-1 layer with Cin % 32 == 0 and 64 | Cout <= 128 goes through the
     Winograd kernels whatever its size (avid_wino_configure), so that the small reference-generated fixtures
-    traverse them; the test asserts through ``wino_launches`` that they did."""
+    traverse them; "wino2_forced": the same through ``wino2_kernel`` (avid_wino2_configure), which otherwise only
+    takes layers with many tiles.  The tests assert from the launch log that they did."""
     from avid_hip import ops
-    if request.param == "wino_forced":
+    if request.param != "default":
         ops.wino_configure(1, 1, 128)
+    if request.param == "wino2_forced":
+        ops.wino2_configure(0)
     yield request.param
     ops.wino_configure(-1, -1, -1)
+    ops.wino2_configure(-1)
+
+
+@pytest.fixture(params=["auto", "wino2"])
+def wino_variant(request, gpu_device):
+    """"wino2": layers on the Winograd path run on ``wino2_kernel`` whatever their size (the dispatch rule stays)."""
+    from avid_hip import ops
+    if request.param == "wino2":
+        ops.wino2_configure(0)
+    yield request.param
+    ops.wino2_configure(-1)
 
 
 class _KernelLog:

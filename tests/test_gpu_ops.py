@@ -67,7 +67,7 @@ WINO_CASES = {"big_128x64", "big_unbalanced", "wino_128x128", "wino_128x128_odd"
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_fwd_dgrad_wgrad(case, gpu_device, kernel_log):
+def test_conv_fwd_dgrad_wgrad(case, gpu_device, kernel_log, wino_variant):
     """fp32 MFMA implicit GEMM vs float64 F.conv3d.  Tolerance: 2e-5 of the output scale
     (fp32 products/accumulation over K <= 2304; the reference itself is fp32)."""
     from avid_hip import ops
@@ -91,16 +91,18 @@ def test_conv_fwd_dgrad_wgrad(case, gpu_device, kernel_log):
     assert relerr(ncdhw(xd.grad), xr.grad) < 2e-5
     assert relerr(wd.grad, wr.grad) < 5e-5
     assert wd.grad.stride() == wd.stride()
+    if wino_variant == "wino2":
+        assert log.launches("wino_kernel") == 0
     if name in WINO_CASES:          # forward and input gradient really took the Winograd kernel
-        assert log.launches("wino_kernel") == 2 and log.launches("wino_wgrad_kernel") == 1, log.report.keys()
+        assert log.launches("wino_kernel") + log.launches("wino2_kernel") == 2 and log.launches("wino_wgrad_kernel") == 1, log.report.keys()
     else:
-        assert log.launches("wino_kernel") == 0 and log.launches("wino_wgrad_kernel") == 0
+        assert log.launches("wino_kernel") + log.launches("wino2_kernel") == 0 and log.launches("wino_wgrad_kernel") == 0
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 9, 11), (4, 8, 48, 48), (5, 7, 45, 47), (64, 1, 4, 4)])
 @pytest.mark.parametrize("cout", [64, 128, 256])
 @pytest.mark.parametrize("cin", [64, 128])
-def test_conv_bn_partials(shape, cout, cin, gpu_device):
+def test_conv_bn_partials(shape, cout, cin, gpu_device, wino_variant):
     """BatchNorm partial sums written by the conv epilogue / the split-K reduce: their column totals must be
     the column sums and sums of squares of the conv output (fp32 partials, 1e-5 of the scale), for whole
     tiles, ragged tails and K-split layers alike; with a fused residual add the statistics are of the sum."""
@@ -136,7 +138,7 @@ def test_conv_bn_partials(shape, cout, cin, gpu_device):
     ((8, 2, 21, 19), 256, 256, (1, 3, 3), (0, 1, 1), (1, 1, 1)),      # Winograd at 256 channels (conv4x): 4 column blocks, 8 chunks
     ((3, 7, 40, 41), 64, 64, (3, 1, 1), (1, 0, 0), (1, 1, 1)),        # large temporal layer, odd frame count
 ])
-def test_bn_backward_partials_from_dgrad(shape, cmid, cout, k, pad, stride, gpu_device):
+def test_bn_backward_partials_from_dgrad(shape, cmid, cout, k, pad, stride, gpu_device, wino_variant):
     """conv1 -> BN+ReLU -> conv2 [+ tap]: with ops.BnSource the BatchNorm's backward partial sums come out of
     conv2's input-gradient kernel (epilogue / K-split reduce) instead of the BatchNorm's own pass over dy and x.
     Gradients vs the same chain without the hand-over: 2e-5 of the gradient scale (fp32 partial sums in a
