@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import struct
 
 import torch
 from torch.autograd import Function
@@ -424,7 +425,6 @@ class TransposedWeights:
     (optimizer, load_state_dict, manual edits) are always picked up."""
 
     def __init__(self, params):
-        import struct
         ws = [p for p in params
               if p.is_cuda and p.dtype == torch.float32 and p.dim() in (2, 4, 5) and weight_layout_ok(p)
               and p.shape[1] % 64 == 0 and p.shape[0] % 32 == 0]
@@ -443,34 +443,70 @@ class TransposedWeights:
             self.map[p.data_ptr()] = wt
             self.max_elems = max(self.max_elems, p.numel())
         self.table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
-        # Winograd-transformed weights U of every 3x3 layer that CAN take that path (whether it does depends on the
-        # activation's size, known at call time): one launch per step instead of one per forward / input-gradient call.
-        # OFF by default (AVID_WINO_PRE=1 turns it on): removing the 14 small transform launches from the chain made the
-        # step SLOWER (11.91 -> 12.35 ms, alternating runs on one box) although every kernel's own duration is unchanged
-        # in the single-stream timing pass — a scheduling effect between the chain and the trailing streams, not found.
-        wino = [p for p in ws if _kdims(p) == (1, 3, 3) and p.shape[0] <= 128 and p.shape[1] <= 128] \
-            if os.environ.get("AVID_WINO_PRE", "0") == "1" else []
-        self.n_wino, self.umap = len(wino) * 2, {}
-        if wino:
-            self.ubuf = torch.empty(sum(16 * p.shape[0] * p.shape[1] for p in wino) * 2, dtype=torch.float32, device=dev)
-            recs, off = [], 0
-            for p in wino:
-                for mode in (1, 2):
-                    u = self.ubuf[off:off + 16 * p.shape[0] * p.shape[1]]
-                    off += u.numel()
-                    recs.append(struct.pack("<QQiiii", p.data_ptr(), u.data_ptr(), p.shape[0], 9, p.shape[1], mode))
-                    self.umap[(p.data_ptr(), mode)] = u
-            self.utable = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).to(dev)
-            self.umax = max(p.shape[0] * p.shape[1] for p in wino)
+        # Winograd-transformed weights U (wino.hip): which 3x3 layers run on that path, in which direction and on which
+        # of the two kernels (their operand-fragment orders differ) depends on the activations' size, i.e. is known at
+        # call time: the first step's calls REGISTER what they need (`_u_for`) and transform inside the call; from the
+        # second step on one launch per direction and step keeps all of them current (`refresh_wino`, on the helper
+        # stream) and the calls pick them up.  AVID_WINO_PRE: 0 off, 1 both directions, 2 (default) input gradients
+        # only — measured on one box, alternating: 11.415-11.435 / 11.424-11.439 / 11.381-11.408 ms per step.  The
+        # forward's transforms cannot be had for free: in front of the model they delay the stem convolution, which
+        # then loses its race with the helper stream (TrainStep.forward_backward), and behind the gradient fill on the
+        # helper the first Winograd layer waits for them (forward 4.25 -> 4.37 ms, backward 7.0 -> 6.9).
+        pre = os.environ.get("AVID_WINO_PRE", "2")
+        self.wino_on = pre in ("1", "2")
+        self.wino_fwd_on = pre == "1"
+        self.umap, self.uwant, self.n_wino, self.ucount = {}, {}, 0, [0, 0]
+        self.uready, self.uevent, self.uwaited = False, None, set()
+        self.wparams = {p.data_ptr(): p for p in ws if _kdims(p) == (1, 3, 3)}
+
+    def want_wino(self, w, code):
+        """Called by a convolution that found no current transform of ``w`` (code 1 / 2: forward / input gradient in
+        wino_kernel's fragment order, 3 / 4: in wino2_kernel's): have one from the next ``refresh_wino`` on."""
+        if self.wino_on and w.data_ptr() in self.wparams:
+            self.uwant[(w.data_ptr(), code)] = True
+
+    def _build_wino(self):
+        keys = sorted(set(self.umap) | set(self.uwant))
+        self.uwant = {}
+        ps = [self.wparams[k[0]] for k in keys]
+        dev = ps[0].device
+        self.ubuf = torch.empty(sum(16 * p.shape[0] * p.shape[1] for p in ps), dtype=torch.float32, device=dev)
+        recs, off, self.umap = {0: [], 1: []}, 0, {}
+        for (ptr, code), p in zip(keys, ps):
+            u = self.ubuf[off:off + 16 * p.shape[0] * p.shape[1]]
+            off += u.numel()
+            recs[1 - (code & 1)].append(struct.pack("<QQiiii", p.data_ptr(), u.data_ptr(), p.shape[0], 9, p.shape[1], code))
+            self.umap[(ptr, code)] = u
+        # two descriptor tables: [0] the forward's transforms (codes 1, 3), [1] the input gradient's (2, 4)
+        self.utable = [torch.frombuffer(bytearray(b"".join(r)), dtype=torch.uint8).to(dev) if r else None for r in (recs[0], recs[1])]
+        self.ucount = [len(recs[0]), len(recs[1])]
+        self.umax = max(p.shape[0] * p.shape[1] for p in ps)
+        self.n_wino = len(keys)
 
     def refresh(self):
         if self.n:
             lib.call("avid_weight_transpose_batched", self.n, _p(self.table), self.max_elems, _stream())
 
-    def refresh_wino(self):
-        """The Winograd transforms of the current weights (needed from the first Winograd layer of the FORWARD on)."""
-        if self.n_wino:
-            lib.call("avid_weight_transpose_batched", self.n_wino, _p(self.utable), self.umax, _stream())
+    def refresh_wino(self, backward):
+        """The Winograd transforms of the current weights for the forward (backward = False) or the input gradients
+        (True): one launch on the current stream."""
+        if not self.wino_on:
+            return
+        if self.n_wino and self.ucount[int(backward)]:
+            lib.call("avid_weight_transpose_batched", self.ucount[int(backward)], _p(self.utable[int(backward)]), self.umax,
+                     _stream())
+        if not backward:
+            # consumers on other streams wait for this launch at their first lookup of the step (_u_for)
+            self.uready = True
+            self.uevent = torch.cuda.Event()
+            self.uevent.record()
+            self.uwaited = {torch.cuda.current_stream().cuda_stream}
+
+    def prepare_wino(self):
+        """Rebuild the table if the previous step registered new layers — before EITHER refresh of this step, or one of
+        them fills the old buffers while the calls read the new ones."""
+        if self.uwant and not torch.cuda.is_current_stream_capturing():
+            self._build_wino()
 
     def armed_wino(self):
         return _ArmWino(self)
@@ -500,7 +536,7 @@ class _ArmWino:
 
     def __enter__(self):
         global _WINO_U
-        self.prev, _WINO_U = _WINO_U, self.tw.umap if self.tw.n_wino else None
+        self.prev, _WINO_U = _WINO_U, self.tw if self.tw.wino_on else None
         return self.tw
 
     def __exit__(self, *exc):
@@ -512,12 +548,28 @@ class _ArmWino:
 _TRANSPOSED = None
 _WINO_U = None
 
-
-def _u_for(w, mode):
-    """This weight's Winograd transform (mode 1 forward, 2 input gradient) if a TrainStep keeps one current."""
-    if _WINO_U is None:
+def _u_for(w, mode, variant):
+    """This weight's Winograd transform (mode 1 forward, 2 input gradient; variant 1 wino_kernel, 2 wino2_kernel) if a
+    TrainStep keeps one current; otherwise None — the call transforms the weights itself — and, inside a TrainStep, a
+    request to have it from the next step on."""
+    tw = _WINO_U
+    if tw is None:
         return None
-    return _WINO_U.get((w.data_ptr(), mode))
+    if mode == 1 and not tw.wino_fwd_on:
+        return None
+    code = mode + 2 * (variant - 1)
+    u = tw.umap.get((w.data_ptr(), code))
+    if u is None:
+        tw.want_wino(w, code)
+        return None
+    if mode == 1:                        # forward: refreshed on the helper stream behind the stem convolution
+        if not tw.uready:
+            return None
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream not in tw.uwaited:
+            cur.wait_event(tw.uevent)
+            tw.uwaited.add(cur.cuda_stream)
+    return u
 
 
 def _wt_for(w):
@@ -572,7 +624,7 @@ class _ConvCL(Function):
         stats = None
         if want_stats and srows > 0 and bias is None and not relu:
             stats = torch.empty((srows, 2, cout), dtype=torch.float32, device=x.device)
-        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(_u_for(w, 1) if d.wino_fwd == 1 else None), _p(addend), _p(bias),
+        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(_u_for(w, 1, d.wino_fwd) if d.wino_fwd else None), _p(addend), _p(bias),
                  int(relu), _p(y), _p(stats), _p(ws),
                  ws.numel() if ws is not None else 0, _stream())
         ctx.d, ctx.relu, ctx.channel_first = d, relu, channel_first
@@ -729,7 +781,7 @@ class _ConvCL(Function):
                 s4 = src.stats4
                 fuse = lib.BnBwdFuse(_p(src.x), _p(s4[2]), _p(s4[3]), _p(s4[0]), _p(s4[1]), int(src.relu),
                                      _p(src.partials))
-            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p((_u_for(w, 2) if d.wino_dgrad == 1 else None) if d.wino_dgrad else _wt_for(w)), _p(add),
+            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_u_for(w, 2, d.wino_dgrad) if d.wino_dgrad else _wt_for(w)), _p(add),
                      add_stride, _p(dx),
                      C.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), st)
         if side is not None:

@@ -307,23 +307,40 @@ class TrainStep:
             self.sync_buffers()
         from . import ops
         helper = None
+        if self.twt is not None:
+            self.twt.prepare_wino()
+            self.twt.uready = False
         if self.twt is not None and self.flat.grad.is_cuda and ops.DEFER_WGRAD and self._defer_ok() and not lib_timing():
-            # what the backward needs but the forward does not — zeroed gradients, the transposed weight copies —
-            # runs on a helper stream next to the forward instead of in front of / behind it (the weights cannot
-            # change in between: this method owns the step)
+            # What the backward needs but the forward does not — zeroed gradients, the transposed weight copies, the
+            # Winograd transforms of the weights — runs on a helper stream next to the forward instead of in front of /
+            # behind it (the weights cannot change in between: this method owns the step).
             # (the helper is the weight-gradient stream, idle during the forward: a FIFTH stream would share one of
             # the runtime's four hardware queues with a busy one and serialise behind it — 4700 -> 3100 clips/s)
+            # How this shares the chip with the stem convolution, the forward's first 0.87 ms, decides what it costs
+            # (tools/trace_timeline.py on rocprofv3 traces, tools/host_lead.py for the phases):
+            #  * issued like this, in front of the model, the gradient fill starts together with the stem kernel, whose
+            #    persistent workgroups hold every CU: the fill starves until the stem ends (795 us instead of 22) and the
+            #    rest follows in the ~130 us behind it — the stem pays 25 us, the side work nothing else;
+            #  * anything that DELAYS the stem's start by ~25 us (a transform launch in front of it on the main stream)
+            #    lets the side work win that race: it then runs inside the stem's first 100-150 us and the stem takes
+            #    1.35-1.47 ms instead of 0.87 (the forward 4.8 instead of 4.25 ms) — round 3's unexplained "slower with
+            #    the transforms hoisted"; a 96 MB fill or copy in front of the model does the same;
+            #  * started strictly BEHIND the stem (an event behind its launch) it shares the chip with the pooling pass
+            #    and conv2x instead: +0.07 ms.
+            # So nothing goes in front of the model on the main stream, and the forward's Winograd transforms ride on
+            # the helper behind the gradient fill (the first Winograd layer waits for their event: ops._u_for).
             cur, helper = ops.wgrad_stream(self.flat.grad.device)
             helper.wait_stream(cur)
             with torch.cuda.stream(helper):
                 self.flat.zero_grad()
+                self.twt.refresh_wino(False)
                 self.twt.refresh()
+                self.twt.refresh_wino(True)
         else:
             self.flat.zero_grad()
-        if self.twt is not None and self.twt.n_wino:
-            # the Winograd transforms of the current weights, one launch (the weights cannot change before backward:
-            # this method owns the step), used by the forward and the input-gradient kernels of those layers
-            self.twt.refresh_wino()
+            if self.twt is not None:
+                self.twt.refresh_wino(False)
+        if self.twt is not None:
             with self.twt.armed_wino():
                 video_emb, audio_emb = self.model(video, audio)
         else:
@@ -334,6 +351,7 @@ class TrainStep:
                 torch.cuda.current_stream().wait_stream(helper)
             else:
                 self.twt.refresh()                   # after the forward: whatever the weights are now
+                self.twt.refresh_wino(True)
             with self.twt.armed(), self.twt.armed_wino(), self.slots.armed(), \
                     ops.deferred_wgrads(enabled=self._defer_ok()):
                 loss.backward()

@@ -280,3 +280,44 @@ def test_trailing_wgrad_streams_change_nothing(gpu_device):
     assert res[0][0] == res[1][0]
     for a, b in zip(res[0][1:], res[1][1:]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("variant", ["wino", "wino2"])
+def test_winograd_weight_tables_change_nothing(variant, gpu_device, monkeypatch):
+    """From its second step on a TrainStep keeps the Winograd transforms of the weights current with ONE launch per
+    step (ops.TransposedWeights.refresh_wino, on the helper stream) instead of a transform launch inside every forward /
+    input-gradient call.  Same kernels, same arithmetic: losses and parameters after four steps must be IDENTICAL to
+    the run that transforms inside the calls (AVID_WINO_PRE=0) — and the table must really have been used."""
+    from avid_hip import ops, lib
+    ops.wino_configure(1, 1, 128)
+    if variant == "wino2":
+        ops.wino2_configure(0)
+    try:
+        outs = []
+        for pre in ("0", "1", "2"):
+            monkeypatch.setenv("AVID_WINO_PRE", pre)
+            m, crit, ts = _make(gpu_device)
+            video, audio, ids = _data(gpu_device, steps=4)
+            losses = [float(ts.step(video, audio, ids[i])) for i in range(3)]
+            lib.timing_enable(True)
+            losses.append(float(ts.step(video, audio, ids[3])))
+            torch.cuda.synchronize()
+            rep = lib.timing_report()
+            lib.timing_enable(False)
+            n_weight = rep.get("wino_weight_kernel", {"launches": 0})["launches"]
+            n_wino = sum(v["launches"] for k, v in rep.items() if k.startswith("wino2_kernel<" if variant == "wino2" else "wino_kernel<"))
+            assert n_wino >= 18                                   # 9 layers, forward and input gradient
+            if pre == "1":
+                assert ts.twt.n_wino == n_wino and n_weight == 0, (ts.twt.n_wino, n_wino, n_weight)
+            elif pre == "2":      # the default: input gradients from the table, the forward transforms in the call
+                assert ts.twt.n_wino == n_wino // 2 and n_weight == n_wino // 2, (ts.twt.n_wino, n_wino, n_weight)
+            else:
+                assert n_weight == n_wino
+            outs.append((losses, [p.detach().clone() for p in m.parameters()]))
+        for other in outs[1:]:
+            assert outs[0][0] == other[0]
+            for a, b in zip(outs[0][1], other[1]):
+                assert torch.equal(a, b)
+    finally:
+        ops.wino_configure(-1, -1, -1)
+        ops.wino2_configure(-1)
