@@ -210,8 +210,8 @@ def forward_roofline(model, video, lib, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1]/[2]: 64)")
     ap.add_argument("--bank", type=int, default=240000)
     ap.add_argument("--negatives", type=int, default=1024)
