@@ -327,8 +327,14 @@ class TrainStep:
             #    the transforms hoisted"; a 96 MB fill or copy in front of the model does the same;
             #  * started strictly BEHIND the stem (an event behind its launch) it shares the chip with the pooling pass
             #    and conv2x instead: +0.07 ms.
-            # So nothing goes in front of the model on the main stream, and the forward's Winograd transforms ride on
-            # the helper behind the gradient fill (the first Winograd layer waits for their event: ops._u_for).
+            # The co-runner that does the damage is the weight transposer, not the fill (tools/corun.py: the stem alone
+            # 0.87-0.97 ms; with an 85 MB fill released at the same moment or 30 us earlier 0.90-0.94; with the transposes
+            # 1.38-1.44 — their tens of thousands of short 4-wave workgroups leave the stem's persistent waves unevenly
+            # spread over the SIMDs, and the slowest workgroup sets the kernel's time; released 30 us later: 0.89).
+            # So nothing goes in front of the model on the main stream, and the fill goes first on the helper: it starts
+            # with the stem, starves, and keeps everything behind it away from the stem's start.  (Making that explicit —
+            # the transposes behind an event recorded after the stem convolution — was measured too: the event's latency
+            # moves them from the pooling pass into conv2x, forward 4.25 -> 4.44 ms.)
             cur, helper = ops.wgrad_stream(self.flat.grad.device)
             helper.wait_stream(cur)
             with torch.cuda.stream(helper):
