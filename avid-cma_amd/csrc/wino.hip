@@ -1177,14 +1177,10 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
     float* U = static_cast<float*>(ws);
     a.U = U;
     const long long n = (long long)a.Cn * a.Cr;
-    static int skip_u = -1;       // AVID_WINO_SKIP_U=1: timing experiment only (U is whatever the workspace holds)
-    if (skip_u < 0) skip_u = wino_env("AVID_WINO_SKIP_U", 0);
-    if (!skip_u) {
     ScopedTimer t(s, "wino_weight_kernel", 0.0, 4.0 * n * 25);
     hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, w, U, a.Cn, a.Cr, d->Cin, mode, a.v2 ? 1 : 2);
     rc = check_launch("wino_weight");
     if (rc) return rc;
-    }
   }
   int epi = 0;
   if (mode == 0 && stats) { epi = 1; a.stats = stats; }
