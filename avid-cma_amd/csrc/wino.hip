@@ -5,14 +5,19 @@
 // (csrc/conv.hip), which is what counts once the matrix pipe's clock is the limit.
 //
 //   source   [F][H][W][Cr]   (F = B*T frames; forward: x, Cr = Cin; input gradient: dy, Cr = Cout)
-//   U        [16][Cn][Cr]    = G g G^T per (output channel n, reduction channel k); the input gradient uses the
-//                              taps flipped and the channel roles swapped (a stride-1 pad-1 3x3 correlation again)
+//   U        16 x Cn x Cr    = G g G^T per (output channel n, reduction channel k), stored in the ORDER THE KERNEL'S
+//                              LANES READ IT (common.h: wino_weight_elements — one contiguous KB per wave load
+//                              instruction; as U[xi][n][k] the texture addresser was as busy as the matrix pipe:
+//                              DESIGN.md 3.1e); the input gradient uses the taps flipped and the channel roles
+//                              swapped (a stride-1 pad-1 3x3 correlation again)
 //   dest     [F][H][W][Cn]
 //   workgroup = 4 waves: 32 tiles (2x2 outputs each) x 64 output channels; wave w owns the transform points
 //   xi = 4w .. 4w+3 (row w of the 4x4), i.e. 8 accumulator blocks of 32 x 32.
 //   LDS: V[16][32 tiles][32 + 4]: one 32-channel chunk of the transformed input at a time (73.7 KB, two workgroups
-//   per CU).  A operand: V[xi][tile = lane & 31][16 * (lane >> 5) + s]; B operand straight from U (L2-resident):
-//   U[xi][n][16 * (lane >> 5) + s] — both are 16 consecutive floats per lane, the MFMA's k index runs (s, lane >> 5).
+//   per CU).  One MFMA operand: V[xi][tile = lane & 31][16 * (lane >> 5) + s]; the other straight from U (L2-resident):
+//   element (xi, n = lane & 31, k = 16 * (lane >> 5) + s) — both are 16 consecutive k per lane, the MFMA's k index runs
+//   (s, lane >> 5).  (wino2_kernel, below: the same computation as one instruction stream per SIMD, for layers with
+//   many tiles.)
 //   Output transform: columns in registers, rows across the four waves through LDS (V is dead by then); wave w then
 //   stores output pixel (w >> 1, w & 1) of every tile: 128 contiguous bytes per 32 lanes.
 //   Epilogues: BatchNorm partial sums of the output (forward), addend and the BatchNorm-backward sums of the
@@ -53,7 +58,7 @@ struct WinoArgs {
   int v2;                               // host only: launch wino2_kernel (units are 64-tile blocks then)
 };
 
-// U[(xi * Cn + n) * Cr + k] = (G g G^T)[xi / 4][xi % 4],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// U(xi, n, k) = (G g G^T)[xi / 4][xi % 4],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], written in fragment order frag
 // flip = 0: g[a][b] = w[n][a][b][k] (forward);  flip = 1: g[a][b] = w[k][2-a][2-b][n] (input gradient)
 __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Cn,
                                                           int Cr, int Cin, int flip, int frag) {
