@@ -692,3 +692,46 @@ def test_adam_flat(gpu_device):
     np.testing.assert_allclose(pd.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
     assert int(t_dev) == 3
     np.testing.assert_allclose(pd2.cpu().numpy(), pd.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_winograd_random_shapes(gpu_device):
+    """24 random layers (64-256 channels incl. the 3-column-block case 192, 2-40 pixel extents, 1-5 x 1-4 frames,
+    addend / statistics epilogues at random) through wino_kernel or wino2_kernel, the input gradient through the same
+    kernel and the weight gradient through wino_wgrad_kernel, against float64 F.conv3d: 2e-5 of the scale
+    (tools/wino_fuzz.py is the long version: 80 shapes, worst 8e-7)."""
+    import random
+    from avid_hip import ops
+    rng = random.Random(11)
+    ops.wino_configure(1, 1, 256)
+    try:
+        for it in range(24):
+            cin, cout = rng.choice([64, 128, 192, 256]), rng.choice([64, 128, 192, 256])
+            B, T_, H, W = rng.randint(1, 5), rng.randint(1, 4), rng.randint(2, 40), rng.randint(2, 40)
+            ops.wino2_configure(0 if rng.random() < 0.6 else 100000)
+            g = torch.Generator().manual_seed(it)
+            x = torch.randn(B, T_, H, W, cin, generator=g).to(gpu_device).requires_grad_(True)
+            w = ops.make_weight(cout, cin, 1, 3, 3)
+            w.copy_(torch.randn(cout, cin, 1, 3, 3, generator=g))
+            w = w.to(gpu_device).requires_grad_(True)
+            add = torch.randn(B, T_, H, W, cout, generator=g).to(gpu_device) if rng.random() < 0.5 else None
+            stats = rng.random() < 0.5
+            out = ops.conv_cl(x, w, (1, 1, 1), (0, 1, 1), addend=add, bn_stats=stats)
+            y, part = out if stats else (out, None)
+            gy = torch.randn(y.shape, generator=g).to(gpu_device)
+            y.backward(gy)
+            xr = x.detach().double().permute(0, 4, 1, 2, 3).requires_grad_(True)
+            wr = w.detach().double().requires_grad_(True)
+            yr = F.conv3d(xr, wr, padding=(0, 1, 1)).permute(0, 2, 3, 4, 1)
+            if add is not None:
+                yr = yr + add.double()
+            (yr * gy.double()).sum().backward()
+            tag = (it, B, T_, H, W, cin, cout)
+            assert relerr(y.detach(), yr.detach()) < 2e-5, tag
+            assert relerr(x.grad, xr.grad.permute(0, 2, 3, 4, 1)) < 2e-5, tag
+            assert relerr(w.grad, wr.grad) < 5e-5, tag
+            if stats and part is not None and part.numel():
+                yd = y.detach().double().reshape(-1, cout)
+                assert relerr(part[:, 1].double().sum(0), (yd * yd).sum(0)) < 1e-5, tag
+    finally:
+        ops.wino_configure(-1, -1, -1)
+        ops.wino2_configure(-1)
