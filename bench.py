@@ -389,7 +389,7 @@ def main():
         clips = bs * world * args.steps / dt
         # every MFMA kernel of the step: implicit-GEMM forward / dgrad, weight gradients, the two LDS-patch stems
         mfma = {k: v for k, v in kern.items()
-                if v["flops"] > 0 and ("igemm" in k or "wgrad" in k or k.startswith("stem_") or k.startswith("wino_"))}
+                if v["flops"] > 0 and ("igemm" in k or "wgrad" in k or k.startswith(("stem_", "wino_", "wino2_")))}
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         d = mfma[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -424,7 +424,7 @@ def main():
                          # `...,0>` and the input-gradient `...,1>` instantiations of the 128x64 tile are within 2 % of
                          # each other, the latter also carries the fused BatchNorm-backward sums)
                          "flop_accounting": "achieved / frac of every kernel = multiply-adds the kernel EXECUTES; the "
-                                            "Winograd kernels (wino_*) execute 16/36 of the direct form's: their "
+                                            "Winograd kernels (wino_*, wino2_*) execute 16/36 of the direct form's: their "
                                             "direct_equivalent figure prices the same launches at 2*M*N*K; "
                                             "step_algorithmic and r2p1d_forward.direct_form are direct-form",
                          "mfma_kernels": {k: dict({"ms_per_step": round(v["ms"] / kern_steps, 3),
@@ -432,7 +432,11 @@ def main():
                                                    "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                                                    "flops": "executed"},
                                                   **({"direct_equivalent": round(2.25 * v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
-                                                     if k.startswith("wino_") else {}))
+                                                     if k.startswith(("wino_", "wino2_")) else {}),
+                                                  # counter HBM traffic per launch (profiles/pmc_traffic.json) next to
+                                                  # the algorithmic bytes of the same launches
+                                                  **({"traffic": pmc[k], "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"])}
+                                                     if k in pmc else {}))
                                           for k, v in sorted(mfma.items(), key=lambda kv: -kv[1]["ms"])},
                          "all_conv_kernels": {"ms_per_step": round(conv_ms, 3), "achieved": round(conv_tf, 2),
                                               "frac": round(conv_tf / PEAK_F32_MFMA_TFLOPS, 4)},
