@@ -82,17 +82,6 @@ struct ConvArgs {
   int pk_paired;   // grid = 2 workgroups per CU: number them so that v and v + G/2 share a CU
 };
 
-// 64 lanes x 16 bytes from a buffer straight into LDS at lds + 16 * lane (buffer_load_dwordx4 ... lds); out-of-range
-// lanes write zeros.  (A __device__ function: the address-space cast is not valid in the host pass, which silently drops
-// a kernel that contains it.)
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, float* lds, unsigned voffset, int soffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voffset, soffset, 0, 0);
-}
-
-#ifndef AVID_PK_DMA
-#define AVID_PK_DMA 0
-#endif
-constexpr bool PK_DMA = AVID_PK_DMA;
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;  // padded LDS row (floats): 144 B => b128 fragment reads conflict-free
 constexpr int KTAB_MAX = 512;
@@ -405,19 +394,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   constexpr int RPP = NT / 8;                   // rows staged per pass: 8 lanes x 16 B cover a 32-float row
   constexpr int PA = BM / RPP, PB = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
-  // DMA (experiment, AVID_PK_DMA): the k-tiles go from memory straight into LDS (buffer_load ... lds: no staging
-  // registers, no ds_write), three stages of unpadded 32-float rows; the 16-byte columns of a row are XOR-swizzled by
-  // (row >> 1) & 7 on the SOURCE side (the LDS image of a wave's load is lane-linear), which keeps the ds_read_b128
-  // fragment reads conflict-free for the instruction's lane groups ({0-3, 12-15, 20-27}, ...).
-  constexpr bool DMA = PK_DMA && !STRIDED && (BM + BN) <= 192;
-  constexpr int LDR = DMA ? BK : LDK;
-  constexpr int STAGE = (BM + BN) * LDR;
+  constexpr int STAGE = (BM + BN) * LDK;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int lrow = tid >> 3, lcol = (DMA ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7)) * 4;
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
   const int h = lane >> 5, l31 = lane & 31;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   PK_STAMP(0);
 
   const int ntn = p.Cd / BN;
@@ -621,7 +603,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
 #pragma unroll
     for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + RPP * i) * p.w_row + lcol) * 4;
   };
-  auto issue_loads = [&](int dma_stage = 0) {   // k-tile (loader tile; tap, channel block) -> registers (or LDS stage dma_stage): PA + PB loads
+  auto issue_loads = [&]() {   // k-tile (loader tile; tap, channel block) -> registers: PA + PB loads
     // The descriptor words and scalar offsets were prepared when they last changed (setup_tile / advance); here
     // they are only pinned to SGPRs — the compiler's divergence analysis gives up on this loop-carried state and
     // would otherwise wrap every buffer load in a readfirstlane waterfall loop.
@@ -631,20 +613,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
         reinterpret_cast<void*>(ptr), 0, __builtin_amdgcn_readfirstlane(ld_nrec), 0x00020000);
     const int soff_a = __builtin_amdgcn_readfirstlane(ld_soff_a);
     const int soff_b = __builtin_amdgcn_readfirstlane(ld_soff_b);
-    if constexpr (DMA) {
-      float* st = smem + dma_stage * STAGE + wave_u * 8 * LDR;          // this wave's 8 rows of every pass
 #pragma unroll
-      for (int i = 0; i < PA; ++i) lds_dma16(rsA, st + RPP * i * LDR, a_cur[i], soff_a);
+    for (int i = 0; i < PA; ++i)
+      va[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_cur[i], soff_a, 0));
 #pragma unroll
-      for (int i = 0; i < PB; ++i) lds_dma16(rsB, st + (BM + RPP * i) * LDR, b_off[i], soff_b);
-    } else {
-#pragma unroll
-      for (int i = 0; i < PA; ++i)
-        va[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_cur[i], soff_a, 0));
-#pragma unroll
-      for (int i = 0; i < PB; ++i)
-        vb[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], soff_b, 0));
-    }
+    for (int i = 0; i < PB; ++i)
+      vb[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], soff_b, 0));
   };
   const auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
   // weight tap index of the loader's current (class-local) tap
@@ -710,7 +684,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     if (moved) retap();
   };
   auto store_stage = [&](float* st) {
-    if constexpr (DMA) return;
 #pragma unroll
     for (int i = 0; i < PA; ++i) *reinterpret_cast<floatx4*>(&st[(lrow + RPP * i) * LDK + lcol]) = va[i];
 #pragma unroll
@@ -718,41 +691,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   };
 
   // ---- prologue: k-tile 0 -> LDS stage 0, k-tile 1 -> registers
-  // barrier of the k-loop: under DMA the next k-tile's pieces (all but the NEW most recent ones) must have landed for
-  // this wave before it lets the others read them, and the barrier must not drain the pieces still in flight
-  // (__syncthreads() would: its fence waits for vmcnt(0) while an LDS-DMA is outstanding)
-  auto kbarrier = [&](auto in_flight) {
-    if constexpr (DMA) {
-      if (decltype(in_flight)::value) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(PA + PB) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : : "memory");
-      __builtin_amdgcn_s_barrier();
-    } else {
-      __syncthreads();
-    }
-  };
   setup_seg(0);
-  bool two_issued = false;
   if (!STRIDED || ld_seg < nseg) {  // (a strided workgroup may own nothing but empty classes)
     retap();
-    issue_loads(0);
+    issue_loads();
     advance();
     store_stage(smem);
-    if (ld_seg < nseg) {            // registers hold the k-tile after the one in LDS (DMA: it is on its way to stage 1)
-      issue_loads(1);
+    if (ld_seg < nseg) {            // registers hold the k-tile after the one in LDS
+      issue_loads();
       advance();
-      two_issued = true;
     }
   }
-  if (DMA && two_issued) kbarrier(std::true_type{}); else kbarrier(std::false_type{});
+  __syncthreads();
   PK_STAMP(1);
 
-  // fragment offsets: row pitch LDR; under DMA the 16-byte column (2 g + h) of k-group g sits at slot (2 g + h) ^ f(row)
-  const int fsw = (l31 >> 1) & 7;
-  const int a_frag = (wm * TM * 32 + l31) * LDR + (DMA ? 0 : h * 4);
-  const int b_frag = (BM + wn * TN * 32 + l31) * LDR + (DMA ? 0 : h * 4);
-  int goff[BK / 8];
-#pragma unroll
-  for (int g = 0; g < BK / 8; ++g) goff[g] = DMA ? (((2 * g + h) ^ fsw) * 4) : g * 8;
+  const int a_frag = (wm * TM * 32 + l31) * LDK + h * 4;
+  const int b_frag = (BM + wn * TN * 32 + l31) * LDK + h * 4;
   int left = n_full * nk;   // k-tiles still to be multiplied, including the one in LDS
   if (STRIDED) {
     left = 0;
@@ -773,27 +727,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   // ST: the registers hold the next k-tile (write it to the other LDS stage); LD: one more exists (load it).
   auto ktile = [&](auto ST, auto LD) {
     const float* cur = smem + u * STAGE;
-    float* nxt = smem + (DMA ? 0 : (u ^ 1)) * STAGE;
+    float* nxt = smem + (u ^ 1) * STAGE;
     const float* Ab = cur + a_frag;
     const float* Bb = cur + b_frag;
     floatx4 af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDR + goff[0]);
+    for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const floatx4*>(Bb + j * 32 * LDR + goff[0]);
+    for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const floatx4*>(Bb + j * 32 * LDK);
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       if (g + 1 < BK / 8) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          af[(g + 1) & 1][i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDR + goff[g + 1]);
+          af[(g + 1) & 1][i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK + (g + 1) * 8);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          bf[(g + 1) & 1][j] = *reinterpret_cast<const floatx4*>(Bb + j * 32 * LDR + goff[g + 1]);
+          bf[(g + 1) & 1][j] = *reinterpret_cast<const floatx4*>(Bb + j * 32 * LDK + (g + 1) * 8);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (decltype(ST)::value && g == 0) store_stage(nxt);
-      if (decltype(LD)::value && g == 1) issue_loads(u >= 1 ? u - 1 : 2);      // DMA: stage (u + 2) % 3
+      if (decltype(LD)::value && g == 1) issue_loads();
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -802,7 +756,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][s], bf[g & 1][j][s], acc[i][j], 0, 0, 0);
       // issue order inside the group: one staging instruction per MFMA, never a burst
-      if (!DMA && decltype(ST)::value && g == 0) {
+      if (decltype(ST)::value && g == 0) {
 #pragma unroll
         for (int q = 0; q < PA + PB; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
@@ -837,26 +791,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     int nst = left - 2 < nkj ? left - 2 : nkj;
     if (nst < 0) nst = 0;
     PK_STAMP(2 + 3 * j);
-    auto next_u = [&]() { u = DMA ? (u == 2 ? 0 : u + 1) : (u ^ 1); };
-    for (int ks = 0; ks < nst; ++ks) {
+    for (int ks = 0; ks < nst; ++ks, u ^= 1) {
       ktile(std::true_type{}, std::true_type{});
       advance();
-      kbarrier(std::true_type{});
-      next_u();
+      __syncthreads();
     }
     left -= nst;
     if (nst < nkj) {
       if (left == 2) {
         ktile(std::true_type{}, std::false_type{});
-        kbarrier(std::false_type{});
-        next_u();
+        __syncthreads();
+        u ^= 1;
         --left;
         ++nst;
       }
       if (nst < nkj) {
         ktile(std::false_type{}, std::false_type{});
-        kbarrier(std::false_type{});
-        next_u();
+        __syncthreads();
+        u ^= 1;
         --left;
       }
     }
@@ -2184,9 +2136,7 @@ static void launch_pk_e(const ConvArgs& a, int grid, size_t lds, hipStream_t s) 
 template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
 static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr bool DMA = PK_DMA && !STRIDED && (BM + BN) <= 192;
-  const size_t lds = DMA ? sizeof(float) * 3 * (BM + BN) * BK
-                         : sizeof(float) * 2 * (BM + BN) * LDK + (STRIDED ? sizeof(int) * 2 * BM : 0);
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + (STRIDED ? sizeof(int) * 2 * BM : 0);
   static char name[64] = "";
   if (!name[0]) snprintf(name, sizeof(name), "igemm_pk_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, MODE, STRIDED ? "s2" : "");
   const double K = (double)a.kt * a.kh * a.kw * a.Cs;
