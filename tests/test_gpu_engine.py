@@ -282,8 +282,9 @@ def test_trailing_wgrad_streams_change_nothing(gpu_device):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("helper_stream", [True, False])
 @pytest.mark.parametrize("variant", ["wino", "wino2"])
-def test_winograd_weight_tables_change_nothing(variant, gpu_device, monkeypatch):
+def test_winograd_weight_tables_change_nothing(variant, helper_stream, gpu_device, monkeypatch):
     """From its second step on a TrainStep keeps the Winograd transforms of the weights current with ONE launch per
     step (ops.TransposedWeights.refresh_wino, on the helper stream) instead of a transform launch inside every forward /
     input-gradient call.  Same kernels, same arithmetic: losses and parameters after four steps must be IDENTICAL to
@@ -292,6 +293,8 @@ def test_winograd_weight_tables_change_nothing(variant, gpu_device, monkeypatch)
     ops.wino_configure(1, 1, 128)
     if variant == "wino2":
         ops.wino2_configure(0)
+    if not helper_stream:        # the arrangement of a step with a process group: no helper stream, the tables refreshed
+        monkeypatch.setattr(ops, "DEFER_WGRAD", 0)      # on the main stream in front of the model / behind the forward
     try:
         outs = []
         for pre in ("0", "1", "2"):
