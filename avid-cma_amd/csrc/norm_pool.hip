@@ -459,8 +459,22 @@ __global__ __launch_bounds__(256) void bn_fin_apply_kernel(const float* __restri
   __shared__ double sh[4][2][FA_CH];
   __shared__ float cf[2][FA_CH];
   const int tid = threadIdx.x;
-  const int ncg = C / FA_CH, cg = blockIdx.x % ncg, slice = blockIdx.x / ncg, nsl = gridDim.x / ncg;
-  if (num_batches_tracked && blockIdx.x == 0 && tid == 0) *num_batches_tracked += 1;
+  // a workgroup reads 16 channels = 64 bytes of every row: the workgroups that read the other half of the same 128-byte
+  // lines (and the rest of the row) must sit on the SAME XCD, or every L2 fetches whole lines for half of their bytes —
+  // in hardware order (id % 8 = XCD) and with C = 128 each XCD had exactly one channel group
+  const int lid = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int ncg = C / FA_CH, cg = lid % ncg, slice = lid / ncg, nsl = gridDim.x / ncg;
+  if (num_batches_tracked && lid == 0 && tid == 0) *num_batches_tracked += 1;
+  // the first batch of x is requested BEFORE the partial sums are folded: its memory latency hides under the fold
+  // (these launches are 7-19 us long, ~3 us of which is the fold every workgroup repeats for its 16 channels)
+  const long long pstep = (long long)nsl * 64, pcol = cg * 4 + (tid & 3);
+  const long long pr = (long long)slice * 64 + (tid >> 2);
+  const bool pre = pr + 3 * pstep < M;
+  floatx4 pv[4];
+  if (pre) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pv[u] = reinterpret_cast<const floatx4*>(x)[(pr + u * pstep) * (C >> 2) + pcol];
+  }
   double s, ss;
   fold16(part, nblk, C, cg, sh, s, ss);
   if (tid < FA_CH) {
@@ -501,6 +515,11 @@ __global__ __launch_bounds__(256) void bn_fin_apply_kernel(const float* __restri
     return o;
   };
   long long r = (long long)slice * 64 + (tid >> 2);
+  if (pre) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) reinterpret_cast<floatx4*>(y)[(r + u * step) * G + col] = one(pv[u]);
+    r += 4 * step;
+  }
   for (; r + 3 * step < M; r += 4 * step) {
     floatx4 v[4];
 #pragma unroll
@@ -521,7 +540,18 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(const float* __re
   __shared__ double sh[4][2][FA_CH];
   __shared__ float cf[2][FA_CH];
   const int tid = threadIdx.x;
-  const int ncg = C / FA_CH, cg = blockIdx.x % ncg, slice = blockIdx.x / ncg, nsl = gridDim.x / ncg;
+  const int lid = (int)xcd_remap(blockIdx.x, gridDim.x);      // (see bn_fin_apply_kernel)
+  const int ncg = C / FA_CH, cg = lid % ncg, slice = lid / ncg, nsl = gridDim.x / ncg;
+  // (first batch of dy / x requested before the fold: see bn_fin_apply_kernel)
+  const long long pstep = (long long)nsl * 64;
+  const long long pr = (long long)slice * 64 + (tid >> 2);
+  const bool pre = pr + pstep < M;
+  floatx4 pd0, pd1, px0, px1;
+  if (pre) {
+    const long long i0 = pr * (C >> 2) + cg * 4 + (tid & 3), i1 = (pr + pstep) * (C >> 2) + cg * 4 + (tid & 3);
+    pd0 = reinterpret_cast<const floatx4*>(dy)[i0]; pd1 = reinterpret_cast<const floatx4*>(dy)[i1];
+    px0 = reinterpret_cast<const floatx4*>(x)[i0]; px1 = reinterpret_cast<const floatx4*>(x)[i1];
+  }
   double s, sx;
   fold16(part, nblk, C, cg, sh, s, sx);
   if (tid < FA_CH) {
@@ -552,6 +582,11 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(const float* __re
   };
   const long long step = (long long)nsl * 64;
   long long r = (long long)slice * 64 + (tid >> 2);
+  if (pre) {
+    reinterpret_cast<floatx4*>(dx)[r * G + cgi] = eval(pd0, px0);
+    reinterpret_cast<floatx4*>(dx)[(r + step) * G + cgi] = eval(pd1, px1);
+    r += 2 * step;
+  }
   for (; r + step < M; r += 2 * step) {
     const long long i0 = r * G + cgi, i1 = (r + step) * G + cgi;
     const floatx4 d0 = reinterpret_cast<const floatx4*>(dy)[i0], d1 = reinterpret_cast<const floatx4*>(dy)[i1];
