@@ -15,6 +15,8 @@
 //          plane (25 k-steps) per chunk.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace avid {
 
 struct StemArgs {
@@ -29,6 +31,7 @@ struct StemArgs {
   int PW, rows_in_max, tiles_per_frame;
   int tile_px;                    // wgrad: output pixels per tile (whole rows when a row fits, <= STEM_TILE)
   int ntiles;                     // B*Ti*tiles_per_frame
+  int xcd_local;                  // XCD-contiguous tile order
 };
 
 constexpr int STEM_TILE = 256;    // output pixels per workgroup tile
@@ -170,7 +173,10 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const S
     }
   };
 
-  int tile = blockIdx.x;
+  // tiles in XCD-contiguous order (AVID_STEM_XCD, default on): consecutive tiles are neighbouring row bands of a frame and
+  // neighbouring frames, whose input patches overlap (6 of 19 rows, two of three planes) — dealt in hardware order (id %
+  // 8 = XCD) the overlap is fetched by eight different L2s
+  int tile = p.xcd_local ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   if (tile >= p.ntiles) return;
   int u = 0;                                  // LDS stage of the weight chunk about to be multiplied
   float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};   // this lane's running column sums / sums of squares of y
@@ -386,8 +392,9 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
     }
   };
 
-  if ((int)blockIdx.x < p.ntiles) prefetch(geo(blockIdx.x));
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  const int tile0 = p.xcd_local ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  if (tile0 < p.ntiles) prefetch(geo(tile0));
+  for (int tile = tile0; tile < p.ntiles; tile += gridDim.x) {
     const TileGeo g = geo(tile);
     const int p0 = g.p0, p1 = g.p1, ho_lo = g.ho_lo;
     const int plane = g.nrows_in * p.PW;
@@ -544,6 +551,9 @@ static void stem_geometry(const avid_conv_desc* d, StemArgs& a, int tile) {
   const int rows_out = tile % d->Wo == 0 ? tile / d->Wo : (tile - 1 + d->Wo - 1) / d->Wo + 1;
   a.rows_in_max = 2 * (rows_out - 1) + 7;
   a.ntiles = d->B * d->Ti * a.tiles_per_frame;
+  static int xl = -1;
+  if (xl < 0) { const char* e = getenv("AVID_STEM_XCD"); xl = e ? atoi(e) : 1; }
+  a.xcd_local = xl;
 }
 
 size_t stem_patch_floats(const avid_conv_desc* d, int tile) {
