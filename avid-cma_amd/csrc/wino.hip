@@ -964,7 +964,10 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WinoWgradArgs p) 
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int Cr = p.Cr, Cn = p.Cn;
-  const int pair = (int)(blockIdx.x % p.pairs), split = (int)(blockIdx.x / p.pairs);
+  // the (Cout block, Cin block) pairs of one tile range on ONE XCD: they read the same dy / x halves (in hardware order,
+  // id % 8 = XCD, the four pairs of a 128-channel layer sat on four different L2s: every operand fetched twice)
+  const int lid = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = lid % p.pairs, split = lid / p.pairs;
   const int cbk = pair % p.ncb, nbk = pair / p.ncb;
   const int ch0 = split * p.cps, ch1 = min(ch0 + p.cps, p.nchunks);
   const int quad = wave & 3, e = wave >> 2, nh = quad >> 1, chh = quad & 1;
