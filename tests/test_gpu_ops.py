@@ -735,3 +735,48 @@ def test_winograd_random_shapes(gpu_device):
     finally:
         ops.wino_configure(-1, -1, -1)
         ops.wino2_configure(-1)
+
+
+def test_winograd_bn_backward_sums_random_shapes(gpu_device):
+    """conv1 -> BN+ReLU -> conv2 (3x3, on wino_kernel or wino2_kernel) [+ a second consumer through the tap]: the
+    BatchNorm-backward sums from conv2's input-gradient epilogue (wino*_kernel<4> / <6>) against the chain without the
+    hand-over, for 16 random layers (64-256 channels, odd / tiny extents): 2e-5 of each gradient's scale."""
+    import random
+    from avid_hip import ops
+    rng = random.Random(23)
+    ops.wino_configure(1, 1, 256)
+    try:
+        for it in range(16):
+            cmid, cout = rng.choice([64, 128, 256]), rng.choice([64, 128, 192, 256])      # (BatchNorm: power-of-two channels)
+            B, T_, H, W = rng.randint(1, 4), rng.randint(1, 3), rng.randint(3, 30), rng.randint(3, 30)
+            ops.wino2_configure(0 if rng.random() < 0.6 else 100000)
+            tap = rng.random() < 0.5
+            g = torch.Generator().manual_seed(100 + it)
+            x = torch.randn(B, T_, H, W, 64, generator=g).to(gpu_device)
+            w1 = ops.make_weight(cmid, 64, 1, 3, 3); w1.copy_(torch.randn(cmid, 64, 1, 3, 3, generator=g) * 0.1)
+            w2 = ops.make_weight(cout, cmid, 1, 3, 3); w2.copy_(torch.randn(cout, cmid, 1, 3, 3, generator=g) * 0.1)
+            w1, w2 = w1.to(gpu_device), w2.to(gpu_device)
+            gam = (torch.rand(cmid, generator=g) + 0.5).to(gpu_device)
+            bet = (torch.rand(cmid, generator=g) - 0.5).to(gpu_device)
+            gy, res = None, []
+            for fused in (False, True):
+                xx = x.clone().requires_grad_(True)
+                g_, b_ = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+                rm, rv = torch.zeros(cmid, device=gpu_device), torch.ones(cmid, device=gpu_device)
+                y1 = ops.conv_cl(xx, w1, (1, 1, 1), (0, 1, 1))
+                src = ops.BnSource(None, None, True) if fused else None
+                hdn = ops.batch_norm_cl(y1, g_, b_, rm, rv, True, relu=True, src=src)
+                out = ops.conv_cl(hdn, w2, (1, 1, 1), (0, 1, 1), tap=tap, bn_src=src)
+                y2, alias = (out[0], out[-1]) if tap else (out, None)
+                if gy is None:
+                    gy = torch.randn(y2.shape, generator=g).to(gpu_device)
+                loss = (y2 * gy).sum()
+                if tap:
+                    loss = loss + (alias * alias).sum() * 0.25
+                loss.backward()
+                res.append((xx.grad.clone(), g_.grad.clone(), b_.grad.clone()))
+            for a, b in zip(res[0], res[1]):
+                assert relerr(b, a) < 2e-5, (it, B, T_, H, W, cmid, cout, tap)
+    finally:
+        ops.wino_configure(-1, -1, -1)
+        ops.wino2_configure(-1)
