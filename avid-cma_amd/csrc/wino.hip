@@ -431,8 +431,7 @@ constexpr int W2_T0 = AVID_W2_T0;
 constexpr int W2_TB = 64, W2_CK = 16;
 constexpr int W2_STAGE = 16 * W2_TB * W2_CK;                 // floats per stage
 constexpr int W2_TAB_OFF = 2 * W2_STAGE;                     // three tile tables of 64 x int4
-constexpr int W2_ST_OFF = W2_TAB_OFF + 3 * W2_TB * 4;        // statistics staging: 4 waves x 512 floats
-constexpr int W2_LDS_FLOATS = W2_ST_OFF + 4 * 512;
+constexpr int W2_LDS_FLOATS = W2_TAB_OFF + 3 * W2_TB * 4;
 
 template <int EPI>
 __global__ __launch_bounds__(256) void wino2_kernel(const WinoArgs p) {
@@ -547,9 +546,6 @@ __global__ __launch_bounds__(256) void wino2_kernel(const WinoArgs p) {
     av[slot][1] = *reinterpret_cast<const floatx4*>(Vst + xi * (W2_TB * W2_CK) + rd_off1);
   };
   floatx16 acc[16];
-  // BatchNorm partial sums (EPI & 5): this lane owns channel 16 r + (lane & 15) of the wave's 32 (r = 0, 1) over the
-  // tiles 8 (lane >> 4) .. + 7 of every unit
-  float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};
 
   // ---- stagger: all workgroups start together and do identical work, so the whole chip would load, multiply and
   // store in lockstep — the 16 stores per lane of a unit's output then hit memory as one 17 MB burst while the matrix
@@ -628,18 +624,30 @@ __global__ __launch_bounds__(256) void wino2_kernel(const WinoArgs p) {
     }
   };
 
-  float* st = sm + W2_ST_OFF + wave * 512;
-  const int st_row = l31 * 16, st_sw = ((l31 >> 1) & 3) * 4;
-  const int st_ch = lane & 15, st_tg = lane >> 4;
-  auto col_sums = [&]() {
-    float s_ = 0.f;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int tile = 8 * st_tg + ((m + st_tg) & 7);
-      s_ += st[tile * 16 + (st_ch ^ (((tile >> 1) & 3) * 4))];
-    }
-    return s_;
-  };
+  // ---- output phase.  The output transform is lane-local in the MFMA layout (lane = tile, a group of four accumulator
+  // registers = four channels), but in that layout every global access of the epilogue — the stores, the addend, the
+  // BatchNorm input of the backward sums — is 32 pieces of 32 bytes per instruction, which the texture addresser serves
+  // at one lane per cycle (107 ns per load beside the MFMAs against 27: tools/mfma_shadow; the loads alone cost
+  // wino2_kernel<4> 9 % and <6> 16 %).  So Y goes through LDS once — this wave's 16 KB of stage 1, which is dead between
+  // the unit's last products and the next unit's first transform (one more barrier per unit) — into a layout in which a
+  // lane holds four channels (slot = lane & 7) of the tiles 8 k + (lane >> 3), k = 0 .. 3: a wave instruction then
+  // touches 8 tiles x 128 contiguous bytes.  The epilogue runs in that layout: the BatchNorm coefficients of a lane's
+  // four channels are loaded once per kernel, the sums over tiles accumulate in eight registers per lane across all units
+  // and are reduced over lanes once, at the end (the MFMA layout needed an LDS staging pass per unit for them).
+  //   xch[pq][tile 32][32 channels]: the eight 16-byte slots of a row XOR-swizzled by tile & 7 — conflict-free for the
+  //   stores (8 consecutive lanes = 8 tiles, one slot) and for the loads' lane groups.
+  float* xch = sm + W2_STAGE + wave * 4096;
+  const int xw_row = l31 * 32, xw_sw = l31 & 7;
+  const int t8 = lane >> 3, slot = lane & 7;
+  const int xr_off = t8 * 32 + ((slot ^ t8) << 2);               // + (pq * 32 + 8 k) * 32
+  const int ccol = cb * 64 + nh * 32 + 4 * slot;                 // this lane's four channels in the coalesced layout
+  floatx4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, bis = bsc;
+  if (EPI & 4) {
+    bsc = *reinterpret_cast<const floatx4*>(p.bnb_scale + ccol); bsh = *reinterpret_cast<const floatx4*>(p.bnb_shift + ccol);
+    bmu = *reinterpret_cast<const floatx4*>(p.bnb_mean + ccol); bis = *reinterpret_cast<const floatx4*>(p.bnb_invstd + ccol);
+  }
+  floatx4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;                     // BatchNorm partial sums of this lane's tiles, all units
+  const int pix_b[4] = {0, Cn * 4, W * Cn * 4, (W + 1) * Cn * 4};   // byte offset of output pixel pq inside a tile
 
   int ubuf = 0;                                  // table buffer of the current unit
   for (int blk = blk0; blk < nblk; blk = blk_after(blk)) {
@@ -650,40 +658,42 @@ __global__ __launch_bounds__(256) void wino2_kernel(const WinoArgs p) {
       if (!(W2_DBG & 256)) __syncthreads();
       chunk(std::false_type{}, ck, ck & 1);
     }
-    // ---- output transform, lane-local: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]; the lane holds tile ptile and, per
-    // group g of four accumulator registers, the channels 8 g + 4 h .. + 3 of the wave's 32
-    const int4 te = tabs[ubuf * W2_TB + ptile];
+    // destination offsets of the coalesced layout: tile 32 th + 8 k + t8 of the unit, k = 0 .. 3
+    unsigned voff[4];
+    int okm = 0;                                 // bit 4 k + pq: output pixel pq of tile k exists
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int4 te = tabs[ubuf * W2_TB + 32 * th + 8 * k + t8];
+      const int y0 = 2 * te.y, x0 = 2 * te.z;
+      const bool tok = te.x >= 0, okx = x0 + 1 < W, oky = y0 + 1 < H;
+      voff[k] = (unsigned)((((te.x * H + y0) * W + x0) * Cn + ccol) * 4);
+      okm |= ((tok ? 1 : 0) | (tok && okx ? 2 : 0) | (tok && oky ? 4 : 0) | (tok && okx && oky ? 8 : 0)) << (4 * k);
+    }
     ubuf = ubuf == 2 ? 0 : ubuf + 1;
     if (W2_DBG & 8) {                 // (timing experiment: no output transform, every accumulator stored once)
-      const unsigned o_ = (W2_DBG & 64) ? (te.x == 12345678 ? 0u : 0x80000000u) : (unsigned)((((te.x * H + 2 * te.y) * W + 2 * te.z) * Cn + cb * 64 + nh * 32 + 4 * h) * 4);
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
         const floatx4 v = floatx4{acc[x][4 * (x & 3)], acc[x][4 * (x & 3) + 1], acc[x][4 * (x & 3) + 2], acc[x][4 * (x & 3) + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, v), rsD, te.x >= 0 ? o_ : 0x80000000u, (x & 3) * 32, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, v), rsD, (okm & 1) ? voff[0] : 0x80000000u, (x & 3) * 32, 0);
         asm volatile("s_nop 1" : : "v"(v));
       }
       continue;
     }
-    const bool tok = te.x >= 0;
-    const int y0 = 2 * te.y, x0 = 2 * te.z;
-    const bool okp[4] = {tok, tok && x0 + 1 < W, tok && y0 + 1 < H, tok && y0 + 1 < H && x0 + 1 < W};
-    const int obase = (((te.x * H + y0) * W + x0) * Cn + cb * 64 + nh * 32 + 4 * h) * 4;       // bytes
-    unsigned ooff[4];
+    // the epilogue's inputs are requested before the output transform: their latency hides under it
+    floatx4 xb[4][4], ad[4][4];
+    auto epi_off = [&](int k, int pq) { return ((okm >> (4 * k + pq)) & 1) ? voff[k] : 0x80000000u; };
+    if (EPI & 4) {
 #pragma unroll
-    for (int pq = 0; pq < 4; ++pq) ooff[pq] = okp[pq] ? (unsigned)(obase + (((pq >> 1) * W + (pq & 1)) * Cn) * 4) : 0x80000000u;
-    floatx4 s0[4], s1[4];
-    floatx4 ad[2][4], xb[2][4];
-    auto epi_loads = [&](int g) {
+      for (int pq = 0; pq < 4; ++pq)
 #pragma unroll
-      for (int pq = 0; pq < 4; ++pq) {
-        if (EPI & 2) ad[g & 1][pq] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ooff[pq], g * 32, 0));
-        if (EPI & 4) xb[g & 1][pq] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, ooff[pq], g * 32, 0));
-      }
-    };
-    if (EPI & 6) epi_loads(0);
+        for (int k = 0; k < 4; ++k)
+          xb[pq][k] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, epi_off(k, pq), pix_b[pq], 0));
+    }
+    __syncthreads();                  // every wave is done with stage 1 (the last chunk's V): it becomes the exchange buffer
+    // ---- output transform, lane-local: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]; the lane holds tile ptile and, per
+    // group g of four accumulator registers, the channels 8 g + 4 h .. + 3 of the wave's 32
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      if ((EPI & 6) && g + 1 < 4) epi_loads(g + 1);
       floatx4 T[4][2];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -702,71 +712,67 @@ __global__ __launch_bounds__(256) void wino2_kernel(const WinoArgs p) {
         T[a][0] = pk4_add(pk4_add(M[0], M[1]), M[2]);
         T[a][1] = pk4_sub(pk4_sub(M[1], M[2]), M[3]);
       }
-      floatx4 Y[4];
+      float* wp = xch + xw_row + (((2 * g + h) ^ xw_sw) << 2);
 #pragma unroll
       for (int qo = 0; qo < 2; ++qo) {
-        Y[qo] = pk4_add(pk4_add(T[0][qo], T[1][qo]), T[2][qo]);
-        Y[2 + qo] = pk4_sub(pk4_sub(T[1][qo], T[2][qo]), T[3][qo]);
+        *reinterpret_cast<floatx4*>(wp + qo * 1024) = pk4_add(pk4_add(T[0][qo], T[1][qo]), T[2][qo]);
+        *reinterpret_cast<floatx4*>(wp + (2 + qo) * 1024) = pk4_sub(pk4_sub(T[1][qo], T[2][qo]), T[3][qo]);
       }
-      floatx4 bsc, bsh, bmu, bis;
-      if (EPI & 4) {
-        const int col = cb * 64 + nh * 32 + 8 * g + 4 * h;
-        bsc = *reinterpret_cast<const floatx4*>(p.bnb_scale + col); bsh = *reinterpret_cast<const floatx4*>(p.bnb_shift + col);
-        bmu = *reinterpret_cast<const floatx4*>(p.bnb_mean + col); bis = *reinterpret_cast<const floatx4*>(p.bnb_invstd + col);
-      }
-      if (EPI & 5) { s0[g] = floatx4{0.f, 0.f, 0.f, 0.f}; s1[g] = s0[g]; }
+      __builtin_amdgcn_sched_barrier(0);      // one group at a time: hoisting the accumulator reads of all four costs 150 registers
+    }
+    if (EPI & 2) {
 #pragma unroll
-      for (int pq = 0; pq < 4; ++pq) {
-        floatx4 v = Y[pq];
-        if (EPI & 2) v = pk4_add(v, ad[g & 1][pq]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, v), rsD, (W2_DBG & 128) ? (te.x == 12345678 ? 0u : 0x80000000u) : ooff[pq], g * 32, 0);
+      for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          ad[pq][k] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, epi_off(k, pq), pix_b[pq], 0));
+    }
+    // ---- epilogue in the coalesced layout (a wave's LDS operations execute in order: no barrier between its own stores
+    // above and these loads)
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        floatx4 v = *reinterpret_cast<const floatx4*>(xch + (pq * 32 + 8 * k) * 32 + xr_off);
+        if (EPI & 2) v = pk4_add(v, ad[pq][k]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, v), rsD, (W2_DBG & 128) ? 0x80000000u : epi_off(k, pq), pix_b[pq], 0);
         // The store reads its four data registers over several cycles.  The compiler's hazard recogniser assumes a
         // buffer store whose soffset is an SGPR is exempt from the ">64-bit store data, then VALU write" wait state;
         // measured on gfx950 it is not: a v_pk_add_f32 scheduled right behind the last store of the unit overwrote the
-        // fourth dword in flight (wrong values in channel 8 g + 4 h + 3 of some tiles, run to run).  Keep v alive for
-        // two more wait states.
+        // fourth dword in flight (wrong values in one channel of some tiles, run to run).  Keep v alive for two more
+        // wait states.
         asm volatile("s_nop 1" : : "v"(v));
         if (EPI & 5) {
-          floatx4 t0 = okp[pq] ? v : floatx4{0.f, 0.f, 0.f, 0.f};
+          const bool okv = (okm >> (4 * k + pq)) & 1;
+          const floatx4 t0 = okv ? v : floatx4{0.f, 0.f, 0.f, 0.f};
           if (EPI & 1) {
-            s0[g] += t0;
-            s1[g] += t0 * t0;
+            s0 += t0;
+            s1 += t0 * t0;
           } else {
-            const floatx4 x_ = xb[g & 1][pq];
+            const floatx4 x_ = xb[pq][k];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float t = (!p.bnb_relu || fmaf(x_[i], bsc[i], bsh[i]) > 0.f) ? t0[i] : 0.f;
-              s0[g][i] += t;
-              s1[g][i] += t * ((x_[i] - bmu[i]) * bis[i]);
+              s0[i] += t;
+              s1[i] += t * ((x_[i] - bmu[i]) * bis[i]);
             }
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);      // one group at a time: hoisting the accumulator reads of all four costs 150 registers
-    }
-    if (EPI & 5) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        *reinterpret_cast<floatx4*>(st + st_row + ((4 * h) ^ st_sw)) = s0[2 * r];
-        *reinterpret_cast<floatx4*>(st + st_row + ((8 + 4 * h) ^ st_sw)) = s0[2 * r + 1];
-        cs[r] += col_sums();
-        *reinterpret_cast<floatx4*>(st + st_row + ((4 * h) ^ st_sw)) = s1[2 * r];
-        *reinterpret_cast<floatx4*>(st + st_row + ((8 + 4 * h) ^ st_sw)) = s1[2 * r + 1];
-        cq[r] += col_sums();
-      }
     }
   }
-  if ((EPI & 5) && p.stats) {   // one partial row [2][Cn] per workgroup
+  if ((EPI & 5) && p.stats) {   // one partial row [2][Cn] per workgroup: the eight tile groups of a wave, then its two tile halves
     __syncthreads();
     float* red = sm;            // [2 terms][4 waves][32]
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      float a = cs[r], b = cq[r];
+    for (int i = 0; i < 4; ++i) {
+      float a = s0[i], b = s1[i];
+      a += __shfl_xor(a, 8, 64); b += __shfl_xor(b, 8, 64);
       a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
       a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-      if (lane < 16) {
-        red[wave * 32 + 16 * r + lane] = a;
-        red[128 + wave * 32 + 16 * r + lane] = b;
+      if (lane < 8) {
+        red[wave * 32 + 4 * lane + i] = a;
+        red[128 + wave * 32 + 4 * lane + i] = b;
       }
     }
     __syncthreads();
