@@ -20,7 +20,7 @@ torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); y = ops.conv_cl(x, w, (1, 1, 1), pd); e1.record(); torch.cuda.synchronize()
 print(f"launch (+ reduce) by events: {e0.elapsed_time(e1)*1e3:.1f} us")
-dll = C.CDLL(os.path.join(REPO, "avid-cma_amd", "avid_hip", "libavid_hip.so"))
+dll = C.CDLL(lib.LIB_PATH)
 buf = np.zeros(1024 * 64, dtype=np.int64)
 assert dll.avid_debug_pk_trace(buf.ctypes.data_as(C.c_void_p)) == 0
 tr = buf.reshape(1024, 64)
