@@ -87,7 +87,7 @@ SIGNATURES = {
     "avid_conv_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "avid_conv_dgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_dgrad_bn_rows": (_i, [_dp]),
-    "avid_conv_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avid_conv_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_weight_transpose_batched": (_i, [_i, _vp, _i64, _vp]),
     "avid_conv_wgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_wgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),

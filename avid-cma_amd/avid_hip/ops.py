@@ -112,7 +112,7 @@ def _launch_wgrad_group(lst, key):
     for i, (d, x, dy, dst, _) in enumerate(lst):
         items[i].d = d
         items[i].x, items[i].dy, items[i].dw = x.data_ptr(), dy.data_ptr(), dst.data_ptr()
-    geo = tuple(id(t[0]) for t in lst)              # (descriptors are cached per layer geometry: ids are stable)
+    geo = tuple(bytes(t[0]) for t in lst)           # (the layers' geometries)
     nb = _GROUP_WS_BYTES.get(geo)
     if nb is None:
         nb = _GROUP_WS_BYTES[geo] = lib.raw("avid_conv_wgrad_group_workspace_bytes")(n, items)
@@ -131,6 +131,8 @@ def _launch_wgrad_group(lst, key):
             with torch.cuda.stream(trail):
                 ws = workspace(dev, nb)
                 lib.call("avid_conv_wgrad_group", n, items, _p(ws), ws.numel(), _stream())
+                for t in lst:                       # (inside the context: the bucket's producer is the trailing stream)
+                    _grad_done(t[4])
             if not capturing:
                 for _, x, dy, _, _ in lst:
                     x.record_stream(trail)
@@ -139,8 +141,8 @@ def _launch_wgrad_group(lst, key):
         else:
             ws = workspace(dev, nb)
             lib.call("avid_conv_wgrad_group", n, items, _p(ws), ws.numel(), _stream())
-        for t in lst:
-            _grad_done(t[4])
+            for t in lst:
+                _grad_done(t[4])
     if stream_ctx is None:
         launch()
     else:
@@ -301,7 +303,7 @@ _BN_WS_CACHE = {}
 def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
     """(ConvDesc, fwd_ws_bytes, dgrad_ws_bytes, wgrad_ws_bytes, bn_partial_rows) — once per distinct layer geometry.
     (``d.bn_bwd_rows``: rows of BatchNorm-backward partials its dgrad can write, 0 = cannot.)"""
-    key = (xs, cin, cout, k, stride, pad, channel_first)
+    key = (xs, cin, cout, k, stride, pad, channel_first, torch.cuda.current_device())   # (plans depend on the CU count)
     hit = _DESC_CACHE.get(key)
     if hit is None:
         d = _desc(xs, cin, cout, k, stride, pad, channel_first)
@@ -322,6 +324,7 @@ def wino_configure(enabled=-1, min_pixels=-1, max_channels=-1):
     drop the per-layer plans cached here, which depend on them."""
     lib.call("avid_wino_configure", int(enabled), int(min_pixels), int(max_channels))
     _DESC_CACHE.clear()
+    _GROUP_WS_BYTES.clear()
 
 
 def wino2_configure(min_rounds_x10=-1):
@@ -329,6 +332,7 @@ def wino2_configure(min_rounds_x10=-1):
     ``wino2_kernel``, negative = environment / default (layers with >= 1.5 rounds of 64-tile units)."""
     lib.call("avid_wino2_configure", int(min_rounds_x10))
     _DESC_CACHE.clear()
+    _GROUP_WS_BYTES.clear()
 
 
 def _bn_ws_bytes(M, Cc):
@@ -391,6 +395,13 @@ class _ArmSlots:
 
     def __exit__(self, *exc):
         global _SLOTS
+        # weight gradients still queued for a grouped launch belong to THIS arming (ops.deferred_wgrads flushes them
+        # itself; a caller that arms the slots alone gets them here): launch them, or drop them after an exception —
+        # never leave (x, dy) of this step to a later step's flush
+        if exc and exc[0] is not None:
+            _GROUP_PENDING.clear()
+        elif any(_GROUP_PENDING.values()):
+            flush_wgrad_group(all_streams=True)
         _SLOTS = self.prev
         return False
 
@@ -743,7 +754,7 @@ class _ConvCL(Function):
                                                 False)
                 add = torch.empty((d.B, dr.To, dr.Ho, dr.Wo, d.Cin), dtype=torch.float32, device=x.device)
                 wsc = workspace(x.device, nbc)
-                lib.call("avid_conv_dgrad", C.byref(dc), _p(d_res), _p(res_w), _p(_wt_for(res_w)), None, None, _p(add), None,
+                lib.call("avid_conv_dgrad", C.byref(dc), _p(d_res), _p(res_w), _p(_wt_for(res_w)), None, None, None, _p(add), None,
                          _p(wsc), wsc.numel(), st)
                 if any(v != 1 for v in ctx.res_stride):
                     add_stride = (C.c_int32 * 3)(*ctx.res_stride)
@@ -781,7 +792,8 @@ class _ConvCL(Function):
                 s4 = src.stats4
                 fuse = lib.BnBwdFuse(_p(src.x), _p(s4[2]), _p(s4[3]), _p(s4[0]), _p(s4[1]), int(src.relu),
                                      _p(src.partials))
-            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_u_for(w, 2, d.wino_dgrad) if d.wino_dgrad else _wt_for(w)), _p(add),
+            lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_wt_for(w)),
+                     _p(_u_for(w, 2, d.wino_dgrad) if d.wino_dgrad else None), _p(add),
                      add_stride, _p(dx),
                      C.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), st)
         if side is not None:

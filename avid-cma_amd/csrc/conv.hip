@@ -2758,7 +2758,7 @@ extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
 }
 
 extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* wt_in,
-                               const float* addend, const int32_t* addend_stride, float* dx, const avid_bn_bwd_fuse* bn,
+                               const float* u, const float* addend, const int32_t* addend_stride, float* dx, const avid_bn_bwd_fuse* bn,
                                void* ws, size_t ws_bytes, avid_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
@@ -2787,8 +2787,8 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
   AVID_REQUIRE(d->st <= 2 && d->sh <= 2 && d->sw <= 2, AVID_E_UNSUPPORTED, "conv_dgrad: stride > 2");
   AVID_REQUIRE(ws_bytes >= dgrad_wt_bytes(d), AVID_E_BADARG, "conv_dgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  if (wino_supported(d, 1) && !sparse_add && (wt_in || ws_bytes >= wino_ws_bytes(d, 1)))
-    return wino_conv(d, 1, dy, w, wt_in, dx, addend, nullptr, bn, ws, s);   // (wt_in: this layer's pre-transformed U)
+  if (wino_supported(d, 1) && !sparse_add && (u || ws_bytes >= wino_ws_bytes(d, 1)))
+    return wino_conv(d, 1, dy, w, u, dx, addend, nullptr, bn, ws, s);   // (u: this layer's pre-transformed weights)
   const int ntaps = d->kt * d->kh * d->kw;
   const float* wt = wt_in;
   if (!wt) {

@@ -67,7 +67,7 @@ typedef struct avid_conv_desc {
 /* y = conv(x, w) [+ addend] [+ bias] [relu].  addend: [B,To,Ho,Wo,Cout] or NULL (residual add of
  * models/network_blocks.py:59 fused into tmp_conv2/res_conv); bias: [Cout] or NULL.
  * ws: scratch for the split-K partial slabs of small-M layers (may be NULL: single pass, slower).
- * Large (1,3,3) stride-1 layers with <= 128 output channels run as a fused Winograd F(2x2,3x3) kernel (forward and
+ * Large (1,3,3) stride-1 layers with <= 256 output channels run as a fused Winograd F(2x2,3x3) kernel (forward and
  * input gradient; csrc/wino.hip, AVID_WINO=0 to switch it off): same contract, results within 1e-6 of the direct
  * form; its transformed weights live in ws, so BatchNorm partials / the fused BatchNorm-backward sums of such a
  * layer need the planned workspace. */
@@ -84,10 +84,12 @@ int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const
                   avid_stream_t stream);
 
 /* dx = conv_transpose(dy, w) [+ addend].  ws: scratch for the transposed weights (+ split-K slabs).
- * wt: the weights already repacked by avid_weight_transpose_batched (current for this w) — as [Cin][taps][Cout], or,
- * for a layer whose input gradient runs on the Winograd path (v = avid_conv_uses_wino(d, 1)), its mode-2 (v == 1) or
- * mode-4 (v == 2) transform — or NULL
- * to repack inside the call (one extra small launch per layer). */
+ * wt (nullable): the weights already repacked as [Cin][taps][Cout] by avid_weight_transpose_batched (mode 0, current
+ * for this w); NULL = repack inside the call (one extra small launch per layer).
+ * u (nullable, version >= 110: its own argument): for a layer whose input gradient runs on the Winograd path
+ * (v = avid_conv_uses_wino(d, 1) != 0) its mode-2 (v == 1) or mode-4 (v == 2) transform from
+ * avid_weight_transpose_batched; NULL = transform inside the call.  Each pointer is read only by the path it belongs
+ * to: a Winograd-eligible layer that falls through to the implicit GEMM (compact addend) reads wt, never u. */
 size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d);
 /* bn (or NULL): dx is the COMPLETE gradient of the output of a training-mode BatchNorm(+ReLU) whose input was
  * bn->x (shape of dx) — the usual conv <- ReLU <- BN chain of models/network_blocks.py:30-60.  The dgrad epilogue
@@ -110,7 +112,7 @@ int avid_conv_dgrad_bn_rows(const avid_conv_desc* d);
  * (models/network_blocks.py:47-51,58), shape [B][ceil(Ti/st)][ceil(Hi/sh)][ceil(Wi/sw)][Cin]: it is added at the
  * positions divisible by the strides only, instead of being scattered into a dx-shaped tensor of mostly zeros
  * first.  Strided layers on the persistent kernel only. */
-int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* wt,
+int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const float* w, const float* wt, const float* u,
                     const float* addend, const int32_t* addend_stride, float* dx, const avid_bn_bwd_fuse* bn,
                     void* ws, size_t ws_bytes, avid_stream_t stream);
 
@@ -125,7 +127,7 @@ typedef struct avid_wt_desc {
   int32_t mode; /* 0: wt[Cin][taps][Cout]; 3x3 layers on the Winograd path (ntaps = 9): wt = the 16 x Cout x Cin transformed
                    weights U in the operand-fragment order of the kernel that will read them — 1 / 3: for the forward
                    (pass it as `u` to avid_conv_fwd), 2 / 4: with flipped taps and swapped channel roles for the input
-                   gradient (pass it as `wt` to avid_conv_dgrad); 1, 2 for wino_kernel, 3, 4 for wino2_kernel
+                   gradient (pass it as `u` to avid_conv_dgrad); 1, 2 for wino_kernel, 3, 4 for wino2_kernel
                    (avid_conv_uses_wino says which of the two a layer runs on) */
 } avid_wt_desc;
 int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_dev, int64_t max_elems, avid_stream_t stream);
@@ -137,8 +139,9 @@ int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* buf, int len
  * for which 0 / 1: 1 = wino_kernel, 2 = wino2_kernel (layers with >= 1.5 rounds of 64-tile units for the CUs). */
 int avid_conv_uses_wino(const avid_conv_desc* d, int which);
 
-/* Dispatch switches of the Winograd path (defaults: on, layers of >= 24576 output pixels, <= 128 output channels;
- * environment AVID_WINO / AVID_WINO_MIN_M / AVID_WINO_MAXC).  A negative argument returns that switch to its
+/* Dispatch switches of the Winograd path (defaults: on, layers of >= 6000 output pixels, <= 256 output channels and
+ * pixels x max(Cin, Cout) >= 1e6; environment AVID_WINO / AVID_WINO_MIN_M / AVID_WINO_MAXC / AVID_WINO_MIN_WORK — an
+ * explicit min_pixels here drops the pixels x channels rule).  A negative argument returns that switch to its
  * environment / default value.  Changes what avid_conv_fwd / avid_conv_dgrad / avid_conv_wgrad dispatch to and what
  * the *_workspace_bytes / *_rows queries answer from the next call on: callers that cache those answers per layer
  * must drop them (ops.wino_configure does).  Parity tests use it to send the reference-generated small fixtures
