@@ -516,7 +516,11 @@ class TransposedWeights:
     def prepare_wino(self):
         """Rebuild the table if the previous step registered new layers — before EITHER refresh of this step, or one of
         them fills the old buffers while the calls read the new ones."""
-        if self.uwant and not torch.cuda.is_current_stream_capturing():
+        if self.uwant and getattr(self, "frozen", False):
+            # a captured graph holds the addresses of the current table (its transform launches write it, its
+            # convolutions read it): layers that register later transform their weights inside their own calls
+            self.uwant = {}
+        elif self.uwant and not torch.cuda.is_current_stream_capturing():
             self._build_wino()
 
     def armed_wino(self):

@@ -460,6 +460,8 @@ class TrainStep:
         off_host = mult.offset if mult is not None else None
         with torch.cuda.graph(self.graph):
             self._sloss = self.step(self._sv, self._sa, self._si)
+        if self.twt is not None:
+            self.twt.frozen = True                   # (the graph holds the table's addresses: ops.prepare_wino)
         self.t = t_host                              # the capture executed nothing: host counters stay where the
         if mult is not None:                         # device counters are
             mult.offset = off_host
