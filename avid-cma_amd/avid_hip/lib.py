@@ -48,6 +48,25 @@ class WgradItem(C.Structure):
     _fields_ = [("d", ConvDesc), ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p)]
 
 
+class Ref(C.Structure):
+    """Mirror of ``avid_ref``: (slot, byte offset); slot < 0 = NULL."""
+    _fields_ = [("slot", C.c_int32), ("reserved", C.c_int32), ("off", C.c_int64)]
+
+
+INSTR_REFS = 12
+
+
+class Instr(C.Structure):
+    """Mirror of ``avid_instr`` (include/avid_hip.h, "Launch programs")."""
+    _fields_ = [("op", C.c_int32), ("stream", C.c_int32), ("mark", C.c_int32), ("reserved", C.c_int32),
+                ("d", ConvDesc), ("i", C.c_int32 * 6), ("n", C.c_int64 * 2), ("f", C.c_float * 6), ("t", Ref * INSTR_REFS)]
+
+
+class StreamWs(C.Structure):
+    """Mirror of ``avid_stream_ws``."""
+    _fields_ = [("ptr", C.c_void_p), ("bytes", C.c_size_t)]
+
+
 def build_library(verbose=False):
     """Compile csrc/*.hip for gfx950 into avid_hip/libavid_hip.so (hipcc cross-compiles without a GPU)."""
     proc = subprocess.run(["make", "-C", _PKG, "-j8"], capture_output=True, text=True)
@@ -136,6 +155,9 @@ SIGNATURES = {
     "avid_cma_topk_workspace_bytes": (_sz, [_i64, _i, _i]),
     "avid_cma_topk": (_i, [_i64, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "avid_adam_flat": (_i, [_i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i64, _vp, _vp, _f, _vp]),
+    "avid_program_instr_bytes": (_sz, []),
+    "avid_program_workspace_bytes": (_i, [C.POINTER(Instr), _i, _i, _i, C.POINTER(_sz)]),
+    "avid_program_run": (_i, [C.POINTER(Instr), _i, _i, C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(StreamWs), _i]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
@@ -146,6 +168,11 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 class AvidHipError(RuntimeError):
     pass
+
+
+if _lib.avid_program_instr_bytes() != C.sizeof(Instr):
+    raise AvidHipError(f"avid_instr is {_lib.avid_program_instr_bytes()} bytes in the library, {C.sizeof(Instr)} in "
+                       "avid_hip/lib.py: the ctypes mirror is out of date")
 
 
 def last_error() -> str:

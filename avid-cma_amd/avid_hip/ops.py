@@ -303,7 +303,8 @@ _BN_WS_CACHE = {}
 def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
     """(ConvDesc, fwd_ws_bytes, dgrad_ws_bytes, wgrad_ws_bytes, bn_partial_rows) — once per distinct layer geometry.
     (``d.bn_bwd_rows``: rows of BatchNorm-backward partials its dgrad can write, 0 = cannot.)"""
-    key = (xs, cin, cout, k, stride, pad, channel_first, torch.cuda.current_device())   # (plans depend on the CU count)
+    key = (xs, cin, cout, k, stride, pad, channel_first,
+           torch.cuda.current_device() if torch.cuda.is_available() else -1)       # (plans depend on the CU count)
     hit = _DESC_CACHE.get(key)
     if hit is None:
         d = _desc(xs, cin, cout, k, stride, pad, channel_first)
@@ -319,12 +320,21 @@ def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
     return hit
 
 
+_WINO_EPOCH = [0]
+
+
+def wino_epoch():
+    """Bumped whenever the Winograd dispatch switches change: compiled launch programs (avid_hip.plan) are keyed by it."""
+    return _WINO_EPOCH[0]
+
+
 def wino_configure(enabled=-1, min_pixels=-1, max_channels=-1):
     """Dispatch switches of the Winograd kernels (``avid_wino_configure``; negative = environment / default) — and
     drop the per-layer plans cached here, which depend on them."""
     lib.call("avid_wino_configure", int(enabled), int(min_pixels), int(max_channels))
     _DESC_CACHE.clear()
     _GROUP_WS_BYTES.clear()
+    _WINO_EPOCH[0] += 1
 
 
 def wino2_configure(min_rounds_x10=-1):
@@ -333,6 +343,7 @@ def wino2_configure(min_rounds_x10=-1):
     lib.call("avid_wino2_configure", int(min_rounds_x10))
     _DESC_CACHE.clear()
     _GROUP_WS_BYTES.clear()
+    _WINO_EPOCH[0] += 1
 
 
 def _bn_ws_bytes(M, Cc):

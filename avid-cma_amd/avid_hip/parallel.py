@@ -137,14 +137,15 @@ class GradBuckets:
             for i, p in enumerate(flat.params):
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
-    def ready(self, i):
-        """Gradient of parameter i has been issued (autograd hook, or ops.GradSlots for kernels that write the
-        flat buffer directly): launch its bucket's all-reduce once the bucket is complete."""
+    def ready(self, i, stream=None):
+        """Gradient of parameter i has been issued on ``stream`` (default: the current one) — autograd hook,
+        ops.GradSlots for kernels that write the flat buffer directly, or a launch program's segment end: launch its
+        bucket's all-reduce once the bucket is complete."""
         if not self.comm:
             return
         b = self.bucket_of[i]
         if self.flat.grad.is_cuda:
-            self.producers[b].add(torch.cuda.current_stream(self.flat.grad.device))
+            self.producers[b].add(stream if stream is not None else torch.cuda.current_stream(self.flat.grad.device))
         self.pending[b] -= 1
         # (with the weight gradients on trailing streams — AVID_DEFER_DIST=1 — a bucket's collective would make RCCL's
         # stream wait for a trailing stream in the middle of the backward; whatever shares its hardware queue then
@@ -302,9 +303,39 @@ class TrainStep:
         evaluating the model or saving it on a rank other than 0."""
         self.flat_buffers.broadcast(0)
 
+    def _plan_backward(self, pl, fa, video, audio, dv, da):
+        """The backward launch program of the model (called from its autograd node): in one piece, or — with gradient
+        collectives — cut where a bucket becomes complete, so that its all-reduce starts under the rest of the pass."""
+        if not self.buckets.comm or self.buckets._capturing():
+            pl.backward(fa, video, audio, dv, da, self.flat.grad)
+            return
+        ba, begin = None, 0
+        for end, ready in pl.segments(self.buckets.bucket_of, self.buckets.counts):
+            ba = pl.backward(fa, video, audio, dv, da, self.flat.grad, begin, end, ba)
+            for i, st in ready:
+                self.buckets.ready(i, pl.stream_objs[st])
+            begin = end
+
+    def _forward_backward_plan(self, video, audio, index):
+        """The step through the compiled launch programs (avid_hip/plan.py); None if the model is outside them."""
+        from . import plan
+        if not self.flat.grad.is_cuda:
+            return None
+        with plan.engine(self):
+            out = plan.run(self.model, video, audio)
+            if out is None:
+                return None
+            loss, _ = self.criterion(out[0], out[1], index)
+            loss.backward()
+        self.buckets.finish()
+        return loss
+
     def forward_backward(self, video, audio, index):
         if self.broadcast_buffers == "step":
             self.sync_buffers()
+        loss = self._forward_backward_plan(video, audio, index)
+        if loss is not None:
+            return loss
         from . import ops
         helper = None
         if self.twt is not None:

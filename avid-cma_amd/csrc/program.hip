@@ -1,0 +1,227 @@
+// Launch programs (include/avid_hip.h, "Launch programs"): the host side of a forward / backward pass as one call.
+//
+// avid_program_run walks an array of avid_instr records and calls the library's own entry points — exactly the calls a
+// binding would make one by one (avid-cma_amd/avid_hip/ops.py), so results are bit-identical — and places the
+// cross-stream dependencies itself.  Host cost per record: reference resolution (a few adds) + the entry point's own
+// dispatch + hipLaunchKernel; no interpreter, no allocator, no autograd node.
+#include <vector>
+
+#include "common.h"
+
+namespace avid {
+
+// Events for AVID_OP_WAIT.  An event may be re-recorded while an earlier wait on it is still pending: a
+// hipStreamWaitEvent captures the record that is current when it is called.  One pool per device, round-robin.
+struct EventPool {
+  std::vector<hipEvent_t> ev;
+  size_t next = 0;
+};
+static EventPool g_wait_events[16];
+
+static hipEvent_t wait_event() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  EventPool& p = g_wait_events[dev & 15];
+  if (p.ev.empty()) {
+    p.ev.resize(64);
+    for (auto& e : p.ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  }
+  hipEvent_t e = p.ev[p.next];
+  p.next = (p.next + 1) % p.ev.size();
+  return e;
+}
+
+static inline size_t maxz(size_t a, size_t b) { return a > b ? a : b; }
+
+}  // namespace avid
+
+using namespace avid;
+
+static size_t instr_ws_bytes(const avid_instr* prog, int k, int end) {
+  const avid_instr& in = prog[k];
+  switch (in.op) {
+    case AVID_OP_CONV_FWD: return avid_conv_fwd_workspace_bytes(&in.d);
+    case AVID_OP_CONV_DGRAD: return avid_conv_dgrad_workspace_bytes(&in.d);
+    case AVID_OP_CONV_WGRAD: return avid_conv_wgrad_workspace_bytes(&in.d);
+    case AVID_OP_WGRAD_GROUP: {
+      avid_wgrad_item items[12];
+      const int n = in.i[0];
+      if (n < 1 || n > 12 || k + n >= end) return 0;
+      for (int j = 0; j < n; ++j) {
+        items[j].d = prog[k + 1 + j].d;
+        items[j].x = items[j].dy = nullptr;
+        items[j].dw = nullptr;
+      }
+      return avid_conv_wgrad_group_workspace_bytes(n, items);
+    }
+    case AVID_OP_BN_FWD:
+    case AVID_OP_BN_BWD: return avid_bn_workspace_bytes(in.n[0], in.i[0]);
+    case AVID_OP_BN_POOL_FWD:
+    case AVID_OP_BN_POOL_BWD: return avid_bn_workspace_bytes((int64_t)in.i[0] * in.i[1] * in.i[2] * in.i[3], in.i[4]);
+    default: return 0;
+  }
+}
+
+extern "C" size_t avid_program_instr_bytes(void) { return sizeof(avid_instr); }
+
+extern "C" int avid_program_workspace_bytes(const avid_instr* prog, int begin, int end, int n_streams, size_t* out_bytes) {
+  AVID_REQUIRE(prog && out_bytes && begin >= 0 && end >= begin && n_streams > 0, AVID_E_BADARG, "program_workspace_bytes: bad arguments");
+  for (int s = 0; s < n_streams; ++s) out_bytes[s] = 0;
+  for (int k = begin; k < end; ++k) {
+    const avid_instr& in = prog[k];
+    if (in.op == AVID_OP_WAIT || in.op == AVID_OP_WGRAD_ITEM || in.op == AVID_OP_NOP) continue;
+    AVID_REQUIRE(in.stream >= 0 && in.stream < n_streams, AVID_E_BADARG, "program record %d: stream %d of %d", k, in.stream, n_streams);
+    out_bytes[in.stream] = maxz(out_bytes[in.stream], instr_ws_bytes(prog, k, end));
+  }
+  return AVID_OK;
+}
+
+extern "C" int avid_program_run(const avid_instr* prog, int begin, int end, void* const* slots, int n_slots,
+                                const avid_stream_t* streams, const avid_stream_ws* ws, int n_streams) {
+  AVID_REQUIRE(prog && slots && streams && ws && begin >= 0 && end >= begin && n_streams > 0, AVID_E_BADARG,
+               "program_run: bad arguments");
+  int bad_slot = 0;
+  auto P = [&](const avid_ref& r) -> char* {
+    if (r.slot < 0) return nullptr;
+    if (r.slot >= n_slots || !slots[r.slot]) {
+      bad_slot = 1;
+      return nullptr;
+    }
+    return static_cast<char*>(slots[r.slot]) + r.off;
+  };
+#define F(r) reinterpret_cast<float*>(P(r))
+  for (int k = begin; k < end; ++k) {
+    const avid_instr& in = prog[k];
+    const avid_ref* t = in.t;
+    int rc = AVID_OK;
+    if (in.op == AVID_OP_NOP || in.op == AVID_OP_WGRAD_ITEM) continue;
+    if (in.op == AVID_OP_WAIT) {
+      const int a = in.i[0], b = in.i[1];
+      AVID_REQUIRE(a >= 0 && a < n_streams && b >= 0 && b < n_streams, AVID_E_BADARG, "program record %d: wait %d <- %d of %d streams",
+                   k, a, b, n_streams);
+      if (a == b || streams[a] == streams[b]) continue;
+      hipEvent_t e = wait_event();
+      hipError_t he = hipEventRecord(e, (hipStream_t)streams[b]);
+      if (he == hipSuccess) he = hipStreamWaitEvent((hipStream_t)streams[a], e, 0);
+      if (he != hipSuccess) {
+        set_error("program record %d (wait): %s", k, hipGetErrorString(he));
+        return AVID_E_HIP;
+      }
+      continue;
+    }
+    AVID_REQUIRE(in.stream >= 0 && in.stream < n_streams, AVID_E_BADARG, "program record %d: stream %d of %d", k, in.stream, n_streams);
+    avid_stream_t s = streams[in.stream];
+    void* w = ws[in.stream].ptr;
+    const size_t wb = ws[in.stream].bytes;
+    switch (in.op) {
+      case AVID_OP_MEMSET0: {
+        hipError_t he = hipMemsetAsync(P(t[0]), 0, (size_t)in.n[0], (hipStream_t)s);
+        if (he != hipSuccess) {
+          set_error("memset: %s", hipGetErrorString(he));
+          rc = AVID_E_HIP;
+        }
+        break;
+      }
+      case AVID_OP_CONV_FWD:
+        rc = avid_conv_fwd(&in.d, F(t[0]), F(t[1]), F(t[2]), F(t[3]), F(t[4]), in.i[0], F(t[5]), F(t[6]), w, wb, s);
+        break;
+      case AVID_OP_CONV_DGRAD: {
+        avid_bn_bwd_fuse bn;
+        if (in.i[4]) {
+          bn.x = F(t[6]); bn.scale = F(t[7]); bn.shift = F(t[8]); bn.mean = F(t[9]); bn.invstd = F(t[10]);
+          bn.relu = in.i[3];
+          bn.partials = F(t[11]);
+        }
+        const bool strided_add = in.i[0] > 0;
+        rc = avid_conv_dgrad(&in.d, F(t[0]), F(t[1]), F(t[2]), F(t[3]), F(t[4]), strided_add ? in.i : nullptr, F(t[5]),
+                             in.i[4] ? &bn : nullptr, w, wb, s);
+        break;
+      }
+      case AVID_OP_CONV_WGRAD:
+        rc = avid_conv_wgrad(&in.d, F(t[0]), F(t[1]), F(t[2]), w, wb, s);
+        break;
+      case AVID_OP_WGRAD_GROUP: {
+        const int n = in.i[0];
+        AVID_REQUIRE(n >= 1 && n <= 12 && k + n < end, AVID_E_BADARG, "program record %d: a group of %d items", k, n);
+        avid_wgrad_item items[12];
+        for (int j = 0; j < n; ++j) {
+          const avid_instr& it = prog[k + 1 + j];
+          AVID_REQUIRE(it.op == AVID_OP_WGRAD_ITEM, AVID_E_BADARG, "program record %d: item %d of the group is a record of kind %d", k, j, it.op);
+          items[j].d = it.d;
+          items[j].x = F(it.t[0]);
+          items[j].dy = F(it.t[1]);
+          items[j].dw = F(it.t[2]);
+        }
+        rc = avid_conv_wgrad_group(n, items, w, wb, s);
+        break;
+      }
+      case AVID_OP_BN_FWD: {
+        const int C = in.i[0];
+        float* s4 = F(t[6]);
+        rc = avid_bn_fwd_train(in.n[0], C, F(t[0]), F(t[1]), F(t[2]), F(t[3]), F(t[4]), in.f[0], in.f[1], in.i[1], F(t[5]), s4,
+                               s4 + C, s4 + 2 * C, s4 + 3 * C, reinterpret_cast<int64_t*>(P(t[7])), F(t[8]), in.i[2], w, wb, s);
+        break;
+      }
+      case AVID_OP_BN_BWD: {
+        const int C = in.i[0];
+        const float* s4 = F(t[3]);
+        rc = avid_bn_bwd(in.n[0], C, F(t[0]), F(t[1]), F(t[2]), s4, s4 + C, s4 + 2 * C, s4 + 3 * C, in.i[1], F(t[4]), F(t[5]),
+                         F(t[6]), F(t[7]), in.i[2], in.i[3], w, wb, s);
+        break;
+      }
+      case AVID_OP_BN_POOL_FWD: {
+        const int C = in.i[4];
+        float* s4 = F(t[7]);
+        rc = avid_bn_relu_maxpool_fwd(in.i[0], in.i[1], in.i[2], in.i[3], C, F(t[0]), F(t[1]), F(t[2]), F(t[3]), F(t[4]), in.f[0],
+                                      in.f[1], F(t[5]), reinterpret_cast<uint8_t*>(P(t[6])), s4, s4 + C, s4 + 2 * C, s4 + 3 * C,
+                                      reinterpret_cast<int64_t*>(P(t[8])), F(t[9]), in.i[5], w, wb, s);
+        break;
+      }
+      case AVID_OP_BN_POOL_BWD: {
+        const int C = in.i[4];
+        const float* s4 = F(t[4]);
+        rc = avid_bn_relu_maxpool_bwd(in.i[0], in.i[1], in.i[2], in.i[3], C, F(t[0]), F(t[1]), reinterpret_cast<uint8_t*>(P(t[2])),
+                                      F(t[3]), s4, s4 + C, s4 + 2 * C, s4 + 3 * C, F(t[5]), F(t[6]), F(t[7]), w, wb, s);
+        break;
+      }
+      case AVID_OP_GPOOL_FWD:
+        rc = avid_global_maxpool_fwd(in.i[0], in.i[1], in.i[2], F(t[0]), F(t[1]), reinterpret_cast<int32_t*>(P(t[2])), s);
+        break;
+      case AVID_OP_GPOOL_BWD:
+        rc = avid_global_maxpool_bwd(in.i[0], in.i[1], in.i[2], F(t[0]), reinterpret_cast<int32_t*>(P(t[1])), F(t[2]), s);
+        break;
+      case AVID_OP_RELU_BWD:
+        rc = avid_relu_bwd(in.n[0], F(t[0]), F(t[1]), F(t[2]), s);
+        break;
+      case AVID_OP_COLSUM:
+        rc = avid_colsum(in.n[0], in.i[0], F(t[0]), F(t[1]), s);
+        break;
+      case AVID_OP_WT_BATCH:
+        rc = avid_weight_transpose_batched(in.i[0], reinterpret_cast<const avid_wt_desc*>(P(t[0])), in.n[0], s);
+        break;
+      case AVID_OP_ADAM: {
+        uint64_t* step_dev = reinterpret_cast<uint64_t*>(P(t[4]));
+        if (step_dev) rc = avid_counter_add(step_dev, 1, s);
+        if (rc == AVID_OK)
+          rc = avid_adam_flat(in.n[0], F(t[0]), F(t[1]), F(t[2]), F(t[3]), in.f[0], in.f[1], in.f[2], in.f[3], in.f[4], in.n[1],
+                              reinterpret_cast<const int64_t*>(step_dev), F(t[5]), in.f[5], s);
+        break;
+      }
+      default:
+        set_error("program record %d: unknown kind %d", k, in.op);
+        return AVID_E_BADARG;
+    }
+    if (bad_slot) {
+      set_error("program record %d (kind %d): a tensor reference names slot outside [0, %d) or an empty slot", k, in.op, n_slots);
+      return AVID_E_BADARG;
+    }
+    if (rc != AVID_OK) {
+      char msg[400];
+      snprintf(msg, sizeof(msg), "%s", avid_last_error());
+      set_error("program record %d (kind %d): %s", k, in.op, msg);
+      return rc;
+    }
+  }
+#undef F
+  return AVID_OK;
+}

@@ -82,6 +82,14 @@ class AV_Wrapper(nn.Module):
         return audio_emb
 
     def forward(self, video, audio):
+        # A training step through the stock module tree runs as two compiled launch programs (avid_hip/plan.py: one C
+        # call per pass, one autograd node for the whole model); anything else — evaluation, hooked modules, frozen
+        # parameters, return_embs on a tower — takes the per-layer path below.
+        if video.is_cuda and self.training:
+            from avid_hip import plan
+            out = plan.run(self, video, audio)
+            if out is not None:
+                return out
         side = None
         capturing = audio.is_cuda and torch.cuda.is_current_stream_capturing()
         if self.overlap_towers and audio.is_cuda and (ops.OVERLAP_IN_CAPTURE or not capturing):

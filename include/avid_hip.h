@@ -373,6 +373,86 @@ int avid_logspec(int B, int L, const float* sig, int n_stft, int hop, int T, con
                  const float* mean, const float* std, float top_db, float* out, void* ws, size_t ws_bytes,
                  avid_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Launch programs: the host side of a whole forward / backward pass as ONE call.
+ *
+ * The reference drives its step from Python, one ATen call per layer (main-avid.py:155-180 ->
+ * models/av_wrapper.py:50-61 -> models/video.py:44-54, models/audio.py:33-44, models/network_blocks.py:23-27,
+ * 52-60, and autograd's mirror image of that for loss.backward()).  A binding that does the same with the
+ * entry points above issues ~330 launches per step through its interpreter.  A program is that launch
+ * sequence compiled once per (model, input shape): an array of avid_instr records — opcode, stream index,
+ * geometry, tensor references — that avid_program_run() walks, calling the SAME entry points above with the
+ * SAME arguments (results are bit-identical to issuing the calls one by one), plus the cross-stream
+ * dependencies (AVID_OP_WAIT) that keep the four-stream arrangement of the step (two towers, each with a
+ * trailing weight-gradient stream).
+ *
+ * A tensor reference is (slot, byte offset): slots[] is an array of base pointers the caller fills for each
+ * run (activation arenas, the parameter / gradient / BatchNorm-buffer tensors, the inputs), so the compiled
+ * program never holds an address and the caller's allocator stays in charge.  slot < 0 = NULL.
+ * The program owns nothing on the device; the only state of the executor is a pool of hipEvents for the waits.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct avid_ref {
+  int32_t slot;
+  int32_t reserved;
+  int64_t off;
+} avid_ref;
+
+enum {
+  AVID_OP_NOP = 0,
+  AVID_OP_WAIT = 1,          /* stream i[0] waits for everything issued so far on stream i[1] (event record + wait) */
+  AVID_OP_MEMSET0 = 2,       /* t0 <- zeros, n[0] bytes */
+  AVID_OP_CONV_FWD = 3,      /* d; t: x w u addend bias y bn_partials; i0 relu */
+  AVID_OP_CONV_DGRAD = 4,    /* d; t: dy w wt u addend dx bn.x bn.scale bn.shift bn.mean bn.invstd bn.partials;
+                                i0..2 addend strides (0 = dense addend), i3 bn.relu, i4 bn present */
+  AVID_OP_CONV_WGRAD = 5,    /* d; t: x dy dw */
+  AVID_OP_WGRAD_GROUP = 6,   /* i0 = n, followed by n AVID_OP_WGRAD_ITEM records (d; t: x dy dw) */
+  AVID_OP_WGRAD_ITEM = 7,
+  AVID_OP_BN_FWD = 8,        /* n0 M; i0 C, i1 relu, i2 nparts; f0 momentum, f1 eps;
+                                t: x gamma beta running_mean running_var y save4 counter partials
+                                (save4 = mean | invstd | scale | shift, C floats each) */
+  AVID_OP_BN_BWD = 9,        /* n0 M; i0 C, i1 relu, i2 nparts, i3 frozen; t: x dy gamma save4 dx dgamma dbeta partials */
+  AVID_OP_BN_POOL_FWD = 10,  /* i0..4 B T H W C, i5 nparts; f0 momentum, f1 eps;
+                                t: x gamma beta running_mean running_var y argmax save4 counter partials */
+  AVID_OP_BN_POOL_BWD = 11,  /* i0..4 B T H W C; t: x dy argmax gamma save4 dx dgamma dbeta */
+  AVID_OP_GPOOL_FWD = 12,    /* i0 B, i1 S, i2 C; t: x y argmax */
+  AVID_OP_GPOOL_BWD = 13,    /* i0 B, i1 S, i2 C; t: dy argmax dx */
+  AVID_OP_RELU_BWD = 14,     /* n0 elements; t: y dy dx */
+  AVID_OP_COLSUM = 15,       /* n0 M; i0 C; t: x out */
+  AVID_OP_WT_BATCH = 16,     /* i0 descriptors, n0 max_elems; t: table (avid_wt_desc[] in device memory) */
+  AVID_OP_ADAM = 17,         /* n0 elements; f0 lr, f1 beta1, f2 beta2, f3 eps, f4 weight_decay, f5 grad_scale; n1 step;
+                                t: p g m v step_dev lr_dev (step_dev, if given, is advanced by one first) */
+  AVID_OP_COUNT_
+};
+
+#define AVID_INSTR_REFS 12
+typedef struct avid_instr {
+  int32_t op;
+  int32_t stream; /* index into the run's stream table (ignored by AVID_OP_WAIT) */
+  int32_t mark;   /* free for the caller (segment labels) */
+  int32_t reserved;
+  avid_conv_desc d;
+  int32_t i[6];
+  int64_t n[2];
+  float f[6];
+  avid_ref t[AVID_INSTR_REFS];
+} avid_instr;
+
+/* Scratch of one stream of a run (what the *_workspace_bytes queries ask for, maximum over the stream's records). */
+typedef struct avid_stream_ws {
+  void* ptr;
+  size_t bytes;
+} avid_stream_ws;
+
+/* sizeof(avid_instr) as the library was compiled: a binding checks its mirror of the record against it. */
+size_t avid_program_instr_bytes(void);
+/* Scratch bytes records [begin, end) need on each of n_streams streams (out_bytes[n_streams]). */
+int avid_program_workspace_bytes(const avid_instr* prog, int begin, int end, int n_streams, size_t* out_bytes);
+/* Issue records [begin, end) of prog.  streams[n_streams]: hipStream_t handles, ws[n_streams]: their scratch.
+ * Asynchronous like every other entry point.  On error the message names the failing record. */
+int avid_program_run(const avid_instr* prog, int begin, int end, void* const* slots, int n_slots,
+                     const avid_stream_t* streams, const avid_stream_ws* ws, int n_streams);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,3 +83,11 @@ class _KernelLog:
 @pytest.fixture
 def kernel_log():
     return _KernelLog
+
+
+@pytest.fixture
+def per_layer_path(monkeypatch):
+    """The test exercises the per-layer autograd path of the step engine (avid_hip/ops.py: what a hooked / partly frozen
+    model falls back to), not the compiled launch programs (avid_hip/plan.py), which are the default."""
+    from avid_hip import plan
+    monkeypatch.setattr(plan, "ENABLED", False)

@@ -259,7 +259,7 @@ def test_residual_conv_compact_gradient(cin, cout, shape, gpu_device):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, float((a - b).abs().max() / b.abs().max())
 
 
-def test_trailing_wgrad_streams_change_nothing(gpu_device):
+def test_trailing_wgrad_streams_change_nothing(gpu_device, per_layer_path):
     """The weight gradients run on helper streams that trail the backward chain and are joined before Adam
     (ops.deferred_wgrads, on by default under TrainStep): same kernels, same order of summation — three steps with
     and without give identical losses, parameters and Adam moments, with the two towers on two streams as well."""
@@ -284,7 +284,7 @@ def test_trailing_wgrad_streams_change_nothing(gpu_device):
 
 @pytest.mark.parametrize("helper_stream", [True, False])
 @pytest.mark.parametrize("variant", ["wino", "wino2"])
-def test_winograd_weight_tables_change_nothing(variant, helper_stream, gpu_device, monkeypatch):
+def test_winograd_weight_tables_change_nothing(variant, helper_stream, gpu_device, monkeypatch, per_layer_path):
     """From its second step on a TrainStep keeps the Winograd transforms of the weights current with ONE launch per
     step (ops.TransposedWeights.refresh_wino, on the helper stream) instead of a transform launch inside every forward /
     input-gradient call.  Same kernels, same arithmetic: losses and parameters after four steps must be IDENTICAL to

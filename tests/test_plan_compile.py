@@ -1,0 +1,91 @@
+"""Host logic of the launch-program compiler (avid_hip/plan.py), no GPU: the forward / backward programs of the stock
+two-tower model compile, every tensor reference stays inside its arena, every parameter gets exactly one gradient
+record, and the gradient-buffer layout is the step engine's (parallel.FlatParams)."""
+import ctypes as C
+
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def compiled():
+    import models
+    from avid_hip import plan
+    m = models.av_wrapper("R2Plus1D", {"depth": 18}, "Conv2D", {"depth": 10}, proj_dim=[512, 512, 128]).train()
+    pl = plan.Plan(m, (4, 3, 8, 112, 112), (4, 1, 40, 100), torch.device("cpu"), True, True, True)
+    return m, pl
+
+
+def test_record_layout_matches_the_library():
+    from avid_hip import lib
+    assert lib.raw("avid_program_instr_bytes")() == C.sizeof(lib.Instr)
+
+
+def test_programs_compile_and_references_stay_in_bounds(compiled):
+    from avid_hip import plan
+    m, pl = compiled
+    # 2 stems + 8 blocks x (4 conv + 4 BN) + 3 residual convs + 9 audio layers x 2 + 2 pools + 6 linears + 5 plumbing records
+    assert pl.n_fwd == 100
+    size = {plan.S_FWD: pl.fa_bytes, plan.S_BWD: pl.ba_bytes, plan.S_GRAD: 4 * pl.gnumel, plan.S_AUX: pl.aux_bytes}
+    for prog, n in ((pl.fwd_prog, pl.n_fwd), (pl.bwd_prog, pl.n_bwd)):
+        for k in range(n):
+            r = prog[k]
+            assert 0 <= r.op <= 17 and 0 <= r.stream < 4
+            for j in range(plan.NREF):
+                s, off = r.t[j].slot, r.t[j].off
+                assert -1 <= s < pl.n_slots
+                if s in size:
+                    assert 0 <= off < size[s], (k, j, s, off)
+                elif s >= 0:
+                    assert off == 0
+    # a grouped launch is followed by exactly its items
+    k = 0
+    while k < pl.n_bwd:
+        r = pl.bwd_prog[k]
+        if r.op == plan.OP_WGRAD_GROUP:
+            n = r.i[0]
+            assert 1 <= n <= 12 and all(pl.bwd_prog[k + 1 + j].op == plan.OP_WGRAD_ITEM for j in range(n))
+            k += n
+        k += 1
+
+
+def test_every_parameter_gets_one_gradient(compiled):
+    m, pl = compiled
+    seen = []
+    for _, _, ps in pl.grad_ready:
+        seen += ps
+    assert sorted(seen) == list(range(len(pl.params))) == list(range(sum(1 for _ in m.parameters())))
+
+
+def test_gradient_layout_is_flatparams(compiled):
+    from avid_hip.parallel import FlatParams
+    import models
+    m2 = models.av_wrapper("R2Plus1D", {"depth": 18}, "Conv2D", {"depth": 10}, proj_dim=[512, 512, 128])
+    flat = FlatParams(m2)
+    _, pl = compiled
+    assert list(flat.offsets) == list(pl.goff) and flat.numel == pl.gnumel
+
+
+def test_segments_cover_the_program_and_follow_the_buckets(compiled):
+    m, pl = compiled
+    n = len(pl.params)
+    bucket_of = [min(i // 30, 4) for i in range(n)]
+    counts = [bucket_of.count(b) for b in range(5)]
+    segs = pl.segments(bucket_of, counts)
+    ends = [e for e, _ in segs]
+    assert ends == sorted(ends) and ends[-1] == pl.n_bwd
+    assert sorted(i for _, r in segs for i, _ in r) == list(range(n))
+    left = list(counts)
+    for e, r in segs[:-1]:
+        for i, _ in r:
+            left[bucket_of[i]] -= 1
+        assert 0 in left                                    # every cut completes a bucket
+
+
+def test_unknown_module_falls_back(compiled):
+    import models
+    from avid_hip import plan
+    m = models.av_wrapper("R2Plus1D", {"depth": 18}, "Conv2D", {"depth": 10}, proj_dim=[512, 512, 128]).train()
+    m.video_model.conv2x[0] = torch.nn.Identity()
+    with pytest.raises(plan.Unsupported):
+        plan.Plan(m, (2, 3, 8, 64, 64), (2, 1, 40, 100), torch.device("cpu"), True, True, True)
