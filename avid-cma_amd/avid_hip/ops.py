@@ -21,9 +21,7 @@ from . import lib
 from .lib import AvidHipError, ConvDesc
 
 _WS = {}
-_SIDE = {}
 OVERLAP_IN_CAPTURE = bool(int(__import__('os').environ.get('AVID_OVERLAP_IN_CAPTURE', '1')))
-OVERLAP_WGRAD = bool(int(__import__('os').environ.get('AVID_OVERLAP_WGRAD', '0')))     # run wgrad on a side stream concurrently with dgrad (fills each other's tail waves)
 # Weight gradients on a trailing stream (eager steps driven by parallel.TrainStep only): nothing in the backward
 # chain consumes dw, so wgrad(L) is issued on a helper stream that only waits for its dy and is joined once, before
 # the optimizer — it then runs next to the small kernels of the chain (BatchNorm finalize / apply, split-K reduces)
@@ -42,14 +40,12 @@ _DEFER_USED = set()
 
 
 def wgrad_stream(device):
-    """The trailing weight-gradient stream of the current compute stream (one per compute stream: the two towers'
-    backward passes run on two streams)."""
-    cur = torch.cuda.current_stream(device)
-    key = (device.index, cur.cuda_stream)
-    st = _DEFERRED.get(key)
-    if st is None:
-        st = _DEFERRED[key] = torch.cuda.Stream(device=device)    # (a high-priority helper stream measured 1 % slower)
-    return cur, st
+    """(current compute stream, the trailing weight-gradient stream of its StreamSet) — ONE trailing stream serves both
+    towers: four streams in all, one per dispatch pipe (avid_hip/streams.py)."""
+    from . import streams
+    ss = streams.current_set(device)
+    _DEFERRED[(device.index, ss.trail.cuda_stream)] = ss.trail
+    return torch.cuda.current_stream(device), ss.trail
 
 
 def join_deferred_wgrads():
@@ -173,12 +169,10 @@ class deferred_wgrads:
         return False
 
 
-def side_stream(device, slot=0):
-    """A per-device helper stream (slot 0: wgrad, slot 1: the audio tower)."""
-    key = (device.index, slot)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
-    return _SIDE[key]
+def side_stream(device, slot=1):
+    """The audio tower's stream of the current compute stream (placed on its own dispatch pipe: avid_hip/streams.py)."""
+    from . import streams
+    return streams.current_set(device).side
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # ~0.3 us; current_stream() builds a Stream object (~8 us)
@@ -722,7 +716,6 @@ class _ConvCL(Function):
                 return None
             return g
 
-        side = None
         deferred = False
         capturing = torch.cuda.is_current_stream_capturing()
         grouped = False
@@ -752,13 +745,6 @@ class _ConvCL(Function):
                 dy.record_stream(trail)
             _DEFER_USED.add(trail)
             deferred = True
-        elif need_dw and need_dx and OVERLAP_WGRAD and (OVERLAP_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()):
-            # dgrad (this stream) and wgrad (side stream) are independent: issue both, join afterwards
-            main = torch.cuda.current_stream()
-            side = side_stream(x.device, 0)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                dw = run_wgrad()
         add, add_stride, dw_res = d_tap, None, None
         if d_res is not None:
             d_res = d_res.contiguous()
@@ -811,13 +797,7 @@ class _ConvCL(Function):
                      _p(_u_for(w, 2, d.wino_dgrad) if d.wino_dgrad else None), _p(add),
                      add_stride, _p(dx),
                      C.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), st)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            if not torch.cuda.is_current_stream_capturing():
-                if dw is not None:
-                    dw.record_stream(torch.cuda.current_stream())
-                dy.record_stream(side)
-        elif need_dw and not deferred and not grouped:
+        if need_dw and not deferred and not grouped:
             dw = run_wgrad()
         if ctx.has_addend and ctx.needs_input_grad[2]:
             dadd = dy

@@ -95,10 +95,6 @@ class FlatBuffers:
         return dist.broadcast(self.flat, src, async_op=async_op)
 
 
-def _late_buckets():
-    return os.environ.get("AVID_DEFER_DIST", "0") == "1" and os.environ.get("AVID_EARLY_BUCKETS", "0") != "1"
-
-
 def lib_timing():
     from . import lib
     return lib.TIMING
@@ -126,7 +122,7 @@ class GradBuckets:
         self.launched = [False] * len(self.bounds)        # bucket b's collective has been issued this step
         self.works = []
         self.hooks = []
-        self.comm_stream = None
+        self.comm_used = None         # the collectives' stream, if a bucket went out on it this step
         self.measure = False          # bench.py: event-time the compute stream's wait for the collectives in finish()
         self.wait_events = []
         self.producers = [set() for _ in self.bounds]     # streams that issued gradients of each bucket
@@ -147,12 +143,7 @@ class GradBuckets:
         if self.flat.grad.is_cuda:
             self.producers[b].add(stream if stream is not None else torch.cuda.current_stream(self.flat.grad.device))
         self.pending[b] -= 1
-        # (with the weight gradients on trailing streams — AVID_DEFER_DIST=1 — a bucket's collective would make RCCL's
-        # stream wait for a trailing stream in the middle of the backward; whatever shares its hardware queue then
-        # stalls behind that wait: 4320 / 2840 clips/s with 4 / 8 queues on the one-rank group.  Those runs launch
-        # every bucket from finish(): 4470 / 4860, at the price of an all-reduce that no longer hides under the
-        # backward)
-        if self.pending[b] == 0 and not _late_buckets() and not self._capturing():
+        if self.pending[b] == 0 and not self._capturing():
             self._launch(b)
 
     def _capturing(self):
@@ -168,30 +159,27 @@ class GradBuckets:
         self._issue(b)
 
     def _issue(self, b):
-        """Issue bucket b's all-reduce.  The two towers' backward passes run on two streams (models/av_wrapper.py)
-        and a bucket may hold gradients from both, so the collective must wait for every stream that produced
-        them — but the compute streams themselves never wait for each other here (that serialised the audio
-        tower's backward in front of the video tower's): a bucket produced entirely on the current stream is
-        issued from it, a mixed one from a communication-launch stream that waits for its producers only
-        (an event record on a compute stream is not free on this runtime).  ``finish()`` joins the collectives."""
+        """Issue bucket b's all-reduce on the collectives' stream of the step's StreamSet (avid_hip/streams.py: a stream
+        on a dispatch pipe of its own), ordered behind every stream that produced one of the bucket's gradients — the
+        compute streams never wait here, and nothing waits for the collective before ``finish()``.  The collective is
+        issued as a stream-synchronous op under that stream: torch's NCCL process group then runs it ON that stream
+        (c10d: ``asyncOp = false`` uses the current stream) instead of its internal one, whose hardware queue we could
+        not choose — two queues on one dispatch pipe serialise, and a queue waiting for an event of its pipe-mate
+        stalls both (the 6-8 ms a one-rank group used to add)."""
         s, e = self.bounds[b]
         if not self.flat.grad.is_cuda:
             self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
             return
-        from . import ops
+        from . import lib, streams
         dev = self.flat.grad.device
-        cur = torch.cuda.current_stream(dev)
-        prod = self.producers[b] or {torch.cuda.default_stream(dev), ops.side_stream(dev, 1)}   # unknown: both towers
-        if prod == {cur}:
-            self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
-            return
-        if self.comm_stream is None:
-            self.comm_stream = torch.cuda.Stream(dev)
-        cs = self.comm_stream
-        for st in prod | {cur}:
-            cs.wait_stream(st)
+        ss = streams.current_set(dev)
+        prod = self.producers[b] or {ss.main, ss.side, ss.trail}      # unknown producers: everything
+        cs = ss.comm
+        for st in prod:
+            lib.call("avid_stream_wait", cs.cuda_stream, st.cuda_stream)
         with torch.cuda.stream(cs):
-            self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
+            dist.all_reduce(self.flat.grad[s:e])
+        self.comm_used = cs
 
     def exposed_wait_ms(self):
         """Mean time per step the compute stream spent waiting for the gradient collectives in ``finish()`` since
@@ -207,10 +195,10 @@ class GradBuckets:
         """Launch whatever did not fire (unused parameters, gradients that came through autograd) and make the
         current stream wait for all buckets."""
         if self.comm and self._capturing():
-            # Inside a hipGraph capture the bucketed collectives, issued from three streams while the backward pass is
-            # being recorded, turn into joins of those streams in the graph (round 2: 23.8 ms per replay against 14 ms
-            # eager).  A captured step reduces the whole gradient buffer with ONE collective behind the backward pass
-            # instead: the all-reduce is exposed (85 MB), the rest of the graph keeps its shape.
+            # Inside a hipGraph capture the bucketed collectives, issued while the backward pass is being recorded, turn
+            # into joins of the streams in the graph (round 2: 23.8 ms per replay against 14 ms eager).  A captured step
+            # reduces the whole gradient buffer with ONE collective behind the backward pass instead: the all-reduce is
+            # exposed (85 MB), the rest of the graph keeps its shape.
             from . import ops
             dev = self.flat.grad.device
             cur = torch.cuda.current_stream(dev)
@@ -222,14 +210,17 @@ class GradBuckets:
                 if self.launched[b]:
                     continue
                 if left > 0:
-                    self.producers[b].clear()        # not all producers are known: wait for both towers
-                self._launch(b)                      # (a COMPLETE bucket is still unlaunched in late-bucket mode)
+                    self.producers[b].clear()        # not all producers are known: wait for every stream
+                self._launch(b)
             timed = self.measure and self.flat.grad.is_cuda and not self._capturing()
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             for w in self.works:
-                w.wait()                             # the current (compute) stream waits for the collective
+                w.wait()                             # (CPU tensors: gloo)
+            if self.comm_used is not None:
+                torch.cuda.current_stream(self.flat.grad.device).wait_stream(self.comm_used)
+                self.comm_used = None
             if timed:
                 e1.record()
                 self.wait_events.append((e0, e1))
@@ -398,9 +389,9 @@ class TrainStep:
         return loss
 
     def _defer_ok(self):
-        """Trailing weight-gradient streams: single-process steps only; AVID_DEFER_DIST=1 forces
-        them on with a process group for experiments."""
-        return (not self.buckets.comm) or os.environ.get("AVID_DEFER_DIST", "0") == "1"
+        """Trailing weight-gradient stream: always (with or without gradient collectives — the collectives' stream is
+        placed on a dispatch pipe of its own, avid_hip/streams.py; a captured step decides for itself in ops)."""
+        return True
 
     def optimizer_step(self):
         from . import ops

@@ -42,8 +42,9 @@ _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 # ---- slots ---------------------------------------------------------------------------------------------------------
 S_FWD, S_BWD, S_GRAD, S_AUX, S_VIDEO, S_AUDIO, S_DV, S_DA, S_FIRST_TENSOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 NULL = (-1, 0)
-# streams of a run: compute (video tower), audio tower, and the trailing weight-gradient stream of each
-ST_MAIN, ST_AUDIO, ST_TRAIL_MAIN, ST_TRAIL_AUDIO = 0, 1, 2, 3
+# streams of a run (avid_hip/streams.py: one per dispatch pipe): compute (video tower), audio tower, the trailing
+# weight-gradient stream of both, the collectives' stream (not used by the programs themselves)
+ST_MAIN, ST_AUDIO, ST_TRAIL, ST_COMM = 0, 1, 2, 3
 
 ENABLED = os.environ.get("AVID_PLAN", "1") == "1"
 
@@ -162,7 +163,7 @@ class Builder:
             self.emit(OP_WAIT, stream=0, i=(waiter, waited))
 
     def trail(self):
-        return ST_TRAIL_MAIN if self.S == ST_MAIN else ST_TRAIL_AUDIO
+        return ST_TRAIL
 
     # ---- transposed weights / Winograd transforms for the input gradients (ops.TransposedWeights)
     def want_wt(self, w):
@@ -259,7 +260,7 @@ class Builder:
             return
         stream = S
         if self.trailing:
-            stream = ST_TRAIL_MAIN if S == ST_MAIN else ST_TRAIL_AUDIO
+            stream = ST_TRAIL
             self.wait(stream, S)                      # every dy of the group is complete on its compute stream
             self.trail_used.add(stream)
         self.emit(OP_WGRAD_GROUP, stream=stream, i=(len(lst),))
@@ -512,7 +513,7 @@ class Plan:
         # (what the backward needs but the forward does not — the transposed / Winograd-transformed weights — runs on
         #  the video tower's trailing stream beside the forward; the table is known only after the backward is
         #  compiled, so the record is patched in below)
-        helper = ST_TRAIL_MAIN if trailing else ST_MAIN
+        helper = ST_TRAIL if trailing else ST_MAIN
         if trailing:
             b.wait(helper, ST_MAIN)
         self._zero_index = len(b.fwd)
@@ -584,7 +585,6 @@ class Plan:
         self.slots = (_vp * self.n_slots)()
         self.streams = (_vp * 4)()
         self.vshape, self.ashape = tuple(vshape), tuple(ashape)
-        self._stream_cache = {}
 
     def _video_with_audio(self, b, model, video, audio, A_S):
         """The video tower with the audio tower (and its head) started behind the video stem on stream A_S."""
@@ -624,21 +624,12 @@ class Plan:
             self._table_ptrs = ptrs
 
     def _streams(self):
-        """Raw handles of the run's four streams: the current stream, the audio tower's, and each one's trailing
-        weight-gradient stream (the same torch streams the per-layer path uses)."""
-        dev = self.device
-        main = ops._raw_stream(dev.index)
-        hit = self._stream_cache.get(main)
-        if hit is None:
-            _, tr_main = ops.wgrad_stream(dev)
-            side = ops.side_stream(dev, 1)
-            with torch.cuda.stream(side):
-                _, tr_side = ops.wgrad_stream(dev)
-            objs = (torch.cuda.current_stream(dev), side, tr_main, tr_side)
-            hit = self._stream_cache[main] = (objs, tuple(o.cuda_stream for o in objs))
+        """Raw handles of the run's streams: the current stream and the helper streams placed for it."""
+        from . import streams
+        ss = streams.current_set(self.device)
         st = self.streams
-        st[0], st[1], st[2], st[3] = hit[1]
-        self.stream_objs = hit[0]
+        st[0], st[1], st[2], st[3] = ss.main.cuda_stream, ss.side.cuda_stream, ss.trail.cuda_stream, ss.comm.cuda_stream
+        self.stream_objs = (ss.main, ss.side, ss.trail, ss.comm)
 
     def forward(self, video, audio, grad_flat, zero_grad):
         """Issue the forward program; returns (v_emb, a_emb, arena)."""

@@ -62,6 +62,39 @@ static size_t instr_ws_bytes(const avid_instr* prog, int k, int end) {
   }
 }
 
+// One wave that spins for ~`us` microseconds (s_memrealtime: 100 MHz constant clock): the probe kernel of
+// avid_hip/streams.py, which looks for stream pairs that hardware queues / pipes serialise.
+__global__ void probe_spin_kernel(long long ticks, int* sink) {
+  const long long t0 = __builtin_readcyclecounter();
+  long long t = t0;
+  int acc = 0;
+  while (t - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(8);
+    t = __builtin_readcyclecounter();
+    ++acc;
+  }
+  if (sink && ticks < 0) *sink = acc;
+}
+
+extern "C" int avid_probe_spin(int us, avid_stream_t stream) {
+  AVID_REQUIRE(us > 0 && us < 100000, AVID_E_BADARG, "probe_spin: duration out of range");
+  // s_memtime counts shader-clock cycles on gfx9 (~2.1-2.4 GHz under no load): an approximate duration is all the probe needs
+  hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)us * 2100, nullptr);
+  return check_launch("probe_spin");
+}
+
+extern "C" int avid_stream_wait(avid_stream_t waiter, avid_stream_t waited) {
+  if (waiter == waited) return AVID_OK;
+  hipEvent_t e = wait_event();
+  hipError_t he = hipEventRecord(e, (hipStream_t)waited);
+  if (he == hipSuccess) he = hipStreamWaitEvent((hipStream_t)waiter, e, 0);
+  if (he != hipSuccess) {
+    set_error("stream_wait: %s", hipGetErrorString(he));
+    return AVID_E_HIP;
+  }
+  return AVID_OK;
+}
+
 extern "C" size_t avid_program_instr_bytes(void) { return sizeof(avid_instr); }
 
 extern "C" int avid_program_workspace_bytes(const avid_instr* prog, int begin, int end, int n_streams, size_t* out_bytes) {

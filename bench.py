@@ -276,52 +276,29 @@ def main():
     for i in range(args.warmup):
         engine.step(video, audio, ids[i])
     sync()
-    # ---- distributed mode, chosen on the spot (only real peers can price it):
-    #   "early"         : every gradient bucket is all-reduced as soon as it is complete, weight gradients on the compute streams
-    #   "late"          : weight gradients trail on helper streams, every bucket is launched from GradBuckets.finish()
-    #   "early_trailing": trailing weight-gradient streams AND buckets launched as they complete
-    # three steps each, max over ranks, the fastest runs the timed region (AVID_DIST_MODE=<name> pins it)
+    # ---- the distributed arrangement is ONE: weight gradients on the trailing stream, every gradient bucket all-reduced
+    # on the collectives' stream as soon as it is complete (avid_hip/parallel.py GradBuckets; the four streams placed on
+    # four dispatch pipes by avid_hip/streams.py — the three-way A/B of round 3 priced a pipe collision)
     dist_info = None
     if use_dist:
-        def timed_steps(n=3):
-            sync()
-            t = time.perf_counter()
-            for i in range(n):
-                engine.step(video, audio, ids[i % total])
-            sync()
-            tt = torch.tensor([(time.perf_counter() - t) / n * 1e3], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return float(tt.item())
-        modes = {}
-        forced = os.environ.get("AVID_DIST_MODE", "")
-        def set_mode(mode):
-            os.environ["AVID_DEFER_DIST"] = "0" if mode == "early" else "1"
-            os.environ["AVID_EARLY_BUCKETS"] = "1" if mode == "early_trailing" else "0"
-        for mode in ("early", "late", "early_trailing"):
-            if forced and forced != mode:
-                continue
-            set_mode(mode)
-            timed_steps(2)                      # settle (stream creation, RCCL channel setup for this pattern)
-            modes[mode] = timed_steps(3)
-        best = min(modes, key=modes.get)
-        set_mode(best)
-        dist_info = {"dist_mode": best, "dist_mode_ms": {k: round(v, 3) for k, v in modes.items()}}
-        # optional fourth arm (AVID_BENCH_GRAPH_AB=1; off by default: a capture that fails on one rank of the driver's
-        # only multi-GPU run would cost the whole line): the captured step, whose gradients are reduced by ONE collective
-        # behind the backward pass (parallel.GradBuckets.finish) — one-rank RCCL group: 12.03 ms vs 12.19 ms eager
+        dist_info = {"dist_mode": "trailing weight gradients + buckets reduced as they complete"}
         if args.graph < 0 and os.environ.get("AVID_BENCH_GRAPH_AB", "0") == "1":
             try:
+                def timed(fn, n=3):
+                    sync()
+                    t = time.perf_counter()
+                    for i in range(n):
+                        fn(i)
+                    sync()
+                    tt = torch.tensor([(time.perf_counter() - t) / n * 1e3], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    return float(tt.item())
+                eager_ms = timed(lambda i: engine.step(video, audio, ids[i % total]))
                 engine.capture(video, audio, ids[0])
                 engine.replay(index=ids[0])
-                sync()
-                t = time.perf_counter()
-                for i in range(3):
-                    engine.replay(index=ids[i % total])
-                sync()
-                tt = torch.tensor([(time.perf_counter() - t) / 3 * 1e3], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dist_info["dist_mode_ms"]["graph"] = round(float(tt.item()), 3)
-                if float(tt.item()) < 0.99 * modes[best]:
+                graph_ms = timed(lambda i: engine.replay(index=ids[i % total]))
+                dist_info["graph_ab_ms"] = {"eager": round(eager_ms, 3), "graph": round(graph_ms, 3)}
+                if graph_ms < 0.99 * eager_ms:
                     use_graph = True
                     dist_info["dist_mode"] = "graph"
             except Exception as e:                          # noqa: BLE001
@@ -383,6 +360,8 @@ def main():
                           "bucket_count": len(engine.buckets.bounds),
                           "gradient_bytes": int(engine.flat.numel * 4)})
     loss_val = float(loss)
+    from avid_hip import streams as _streams
+    stream_report = _streams.report(dev)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -414,6 +393,7 @@ def main():
                        "per_gpu_batch": bs, "global_batch": bs * world, "bank_rows": args.bank,
                        "negatives": args.negatives, "parallelism": f"dp{world}", "optimizer": "adam(2e-4, wd 1e-5)",
                        "hipgraph": use_graph, "host_issue_ms_per_step": round(host_issue_ms, 3),
+                       "stream_placement": stream_report,
                        "loss": round(loss_val, 5), **(dist_info or {})},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,

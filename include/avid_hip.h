@@ -444,6 +444,14 @@ typedef struct avid_stream_ws {
   size_t bytes;
 } avid_stream_ws;
 
+/* One single-wave kernel that spins for about `us` microseconds on `stream`: the probe with which a binding finds out
+ * which of its streams the hardware serialises (streams that share a hardware queue, or queues that share a dispatch
+ * pipe: 4 pipes serve GPU_MAX_HW_QUEUES queues) before it places the step's four streams — avid_hip/streams.py. */
+int avid_probe_spin(int us, avid_stream_t stream);
+/* Everything issued to `waiter` after this call runs behind everything issued to `waited` before it (one event of the
+ * executor's pool: record + wait) — what AVID_OP_WAIT does inside a program, for a binding that orders its collectives'
+ * stream behind the streams that produced a gradient bucket. */
+int avid_stream_wait(avid_stream_t waiter, avid_stream_t waited);
 /* sizeof(avid_instr) as the library was compiled: a binding checks its mirror of the record against it. */
 size_t avid_program_instr_bytes(void);
 /* Scratch bytes records [begin, end) need on each of n_streams streams (out_bytes[n_streams]). */

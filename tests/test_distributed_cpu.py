@@ -210,45 +210,6 @@ def test_sync_buffers_broadcasts_rank0_running_statistics_in_one_flat_buffer():
     assert int(a0[2]) == int(a1[2]) == 3                                  # the step counter advances identically anyway
 
 
-def _late_bucket_job(rank, world):
-    """AVID_DEFER_DIST=1 (late buckets): every bucket's collective is issued from finish(), complete ones included."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avid-cma_amd"))
-    from avid_hip.parallel import FlatParams, GradBuckets
-    out = {}
-    for mode in ("0", "1"):
-        os.environ["AVID_DEFER_DIST"] = mode
-        m = _tiny_model()
-        flat = FlatParams(m)
-        buckets = GradBuckets(flat, bucket_bytes=256)
-        torch.manual_seed(100 + rank)
-        x = torch.randn(5, 8)
-        grads = []
-        for _ in range(2):
-            flat.zero_grad()
-            m(x).pow(2).sum().backward()
-            launched_in_backward = sum(buckets.launched)
-            buckets.finish()
-            grads.append(flat.grad.clone().numpy())
-        out[mode] = (grads, launched_in_backward, len(buckets.bounds))
-    os.environ.pop("AVID_DEFER_DIST")
-    return out
-
-
-def test_late_bucket_mode_still_allreduces_every_bucket():
-    """with AVID_DEFER_DIST=1 a bucket that completed during backward was never all-reduced
-    (finish() only launched incomplete ones).  Late mode must give exactly the default mode's summed gradients, on
-    both steps, with no collective issued before finish()."""
-    res = run2(_late_bucket_job)
-    for rank in range(2):
-        (g_early, n_early, nb), (g_late, n_late, _) = res[rank]["0"], res[rank]["1"]
-        assert n_early == nb and n_late == 0                     # early: all fired from the hooks; late: none did
-        for a, b in zip(g_early, g_late):
-            assert (a == b).all()
-    assert (res[0]["1"][0][0] == res[1]["1"][0][0]).all()        # and the ranks agree
-    assert not (res[0]["1"][0][0] == 0).all()
-
-
 def test_optimizer_state_dict_indexes_all_parameters_like_torch_adam():
     """utils/main_utils.py:250-261 builds Adam over model.parameters(): state_dict indices count FROZEN parameters too
     (they have an index in param_groups but no state).  TrainStep.state_dict must use the same numbering, and a
