@@ -157,6 +157,7 @@ SIGNATURES = {
     "avid_adam_flat": (_i, [_i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _i64, _vp, _vp, _f, _vp]),
     "avid_probe_spin": (_i, [_i, _vp]),
     "avid_stream_wait": (_i, [_vp, _vp]),
+    "avid_clock_probe": (_i, [_i, _vp, _vp]),
     "avid_program_instr_bytes": (_sz, []),
     "avid_program_workspace_bytes": (_i, [C.POINTER(Instr), _i, _i, _i, C.POINTER(_sz)]),
     "avid_program_run": (_i, [C.POINTER(Instr), _i, _i, C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(StreamWs), _i]),

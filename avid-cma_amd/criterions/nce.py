@@ -21,6 +21,15 @@ class NCECriterion(nn.Module):
         self.register_buffer('avg_exp_score', torch.tensor(-1.))
         self.distributed = dist.is_available() and dist.is_initialized()
         self._z_ready = None     # unknown until checked once (a loaded checkpoint may carry Z)
+        self._register_state_dict_hook(self._reference_shape)
+
+    @staticmethod
+    def _reference_shape(module, state_dict, prefix, local_metadata):
+        """Checkpoint interchange: once Z is computed the reference's buffer has shape (1,) (nce.py:27-35 assigns the
+        gathered mean), before that (); what this module saves has the same shape at the same time."""
+        key = prefix + 'avg_exp_score'
+        if key in state_dict and module.z_ready():
+            state_dict[key] = state_dict[key].reshape(1)
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         key = prefix + 'avg_exp_score'

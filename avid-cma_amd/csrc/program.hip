@@ -83,6 +83,29 @@ extern "C" int avid_probe_spin(int us, avid_stream_t stream) {
   return check_launch("probe_spin");
 }
 
+// One wave that spins for `us` microseconds of the constant 100 MHz clock and reports how many shader-clock cycles
+// went by: out[0] = s_memtime ticks (shader clock), out[1] = s_memrealtime ticks (100 MHz).
+__global__ void clock_probe_kernel(long long real_ticks, long long* out) {
+  const long long r0 = __builtin_amdgcn_s_memrealtime();
+  const long long c0 = __builtin_readcyclecounter();
+  long long r = r0;
+  while (r - r0 < real_ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    r = __builtin_amdgcn_s_memrealtime();
+  }
+  const long long c1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = r - r0;
+  }
+}
+
+extern "C" int avid_clock_probe(int us, long long* out2, avid_stream_t stream) {
+  AVID_REQUIRE(us > 0 && us <= 2000000 && out2, AVID_E_BADARG, "clock_probe: bad arguments");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)us * 100, out2);
+  return check_launch("clock_probe");
+}
+
 extern "C" int avid_stream_wait(avid_stream_t waiter, avid_stream_t waited) {
   if (waiter == waited) return AVID_OK;
   hipEvent_t e = wait_event();

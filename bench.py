@@ -38,9 +38,25 @@ PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 6
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(steps=12, warmup=1):
+def csrc_digest():
+    """sha256 over the kernel sources (avid-cma_amd/csrc/*.hip, common.h, include/avid_hip.h): what profiles/pmc_traffic.json
+    is stamped with when tools/pmc_traffic.py writes it (there is no git on the GPU box)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(REPO, "avid-cma_amd", "csrc", "*.hip"))) + \
+        [os.path.join(REPO, "avid-cma_amd", "csrc", "common.h"), os.path.join(REPO, "include", "avid_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def cpu_baseline(budget=25.0):
     """BASELINE config 1 on the host cores with the oracle (a *port*, pinned to the reference by
-    tests/test_oracle_golden.py): bs=4, 1000-row bank, K=1024; full step incl. Adam."""
+    tests/test_oracle_golden.py): bs=4, 1000-row bank, K=1024; full step incl. Adam.  The step is timed at 8 / 16 / 32 /
+    64 / all threads inside one ~25 s budget (a batch of 4 clips does not scale to 128+ threads: the best count is the
+    reference path's best on this host) and the best is reported with its thread count."""
     from oracle import avid_oracle as O
     torch.manual_seed(1234)
     bs, N, K = 4, 1000, 1024
@@ -48,9 +64,8 @@ def cpu_baseline(steps=12, warmup=1):
     g = torch.Generator().manual_seed(1234)
     video = torch.randn(bs, 3, 8, 112, 112, generator=g)
     audio = torch.randn(bs, 1, 40, 100, generator=g)
-    times, fb_times = [], []
-    budget = 25.0                       # seconds of timed CPU work: the host cores are shared and their speed varies
-    for i in range(warmup + steps):     # several-fold between boxes, the default run has to stay within minutes
+
+    def step():
         y = torch.randperm(N, generator=g)[:bs]
         idx = torch.randint(0, N - 1, (bs, K), generator=g)
         idx = idx + (idx >= y[:, None]).long()
@@ -58,17 +73,36 @@ def cpu_baseline(steps=12, warmup=1):
         st.forward_backward(video, audio, y, idx)
         t1 = time.perf_counter()
         st.opt.step()
-        if i >= warmup:
-            times.append(time.perf_counter() - t0)
-            fb_times.append(t1 - t0)
-            if len(times) >= 3 and sum(times) > budget:
-                break
-    steps = len(times)
+        return time.perf_counter() - t0, t1 - t0
+
+    ncpu = os.cpu_count() or 1
+    all_threads = torch.get_num_threads()
+    counts = sorted({c for c in (8, 16, 32, 64, all_threads) if c <= max(all_threads, 8)})
+    t_start = time.perf_counter()
+    step()                                            # warm-up (allocations, first-touch)
+    sweep, spent = {}, 0.0
+    for c in counts:                                  # two steps per count: the second is the sample
+        torch.set_num_threads(c)
+        step()
+        sweep[c] = step()
+        if time.perf_counter() - t_start > 0.6 * budget:
+            break
+    best = min(sweep, key=lambda c: sweep[c][0])
+    torch.set_num_threads(best)
+    times, fb = [sweep[best][0]], [sweep[best][1]]
+    while time.perf_counter() - t_start < budget and len(times) < 12:
+        a, b = step()
+        times.append(a)
+        fb.append(b)
+    torch.set_num_threads(all_threads)
     med = statistics.median(times)
-    return {"value": round(bs / med, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "fwd_bwd_nce_only": round(bs / statistics.median(fb_times), 3),      # without the Adam step
-            "sample": f"config1: bs=4 3x8x112x112+1x40x100, bank 1000x128, K=1024, fwd+NCE+bwd+Adam fp32, "
-                      f"median of {steps} steps ({sum(times):.1f} s CPU work), os.cpu_count()={os.cpu_count()}"}
+    return {"value": round(bs / med, 3), "unit": "clips/s", "cores": best, "kind": "port",
+            "fwd_bwd_nce_only": round(bs / statistics.median(fb), 3),      # without the Adam step
+            "thread_sweep_clips_s": {str(c): round(bs / v[0], 3) for c, v in sweep.items()},
+            "os_cpu_count": ncpu,
+            "sample": f"config1: bs=4 3x8x112x112+1x40x100, bank 1000x128, K=1024, fwd+NCE+bwd+Adam fp32, median of "
+                      f"{len(times)} steps at the best thread count ({best} of {sorted(sweep)} tried; "
+                      f"{time.perf_counter() - t_start:.1f} s CPU work)"}
 
 
 def extra_configs(engine, model, video, audio, dev, lib, steps=10, warmup=3):
@@ -210,8 +244,8 @@ def forward_roofline(model, video, lib, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1]/[2]: 64)")
     ap.add_argument("--bank", type=int, default=240000)
     ap.add_argument("--negatives", type=int, default=1024)
@@ -323,6 +357,20 @@ def main():
         engine.capture(video, audio, ids[0])
         engine.replay(index=ids[0])
     sync()
+    # the shader clock DURING the timed region: one wave on the (idle at N = 1) collectives' stream spins beside the steps and
+    # counts shader cycles against the constant 100 MHz clock (avid_clock_probe) — the 157.3 TFLOP/s peak assumes 2.4 GHz
+    import ctypes as _C
+    from avid_hip import streams as _streams
+    clock_out = torch.zeros(2, dtype=torch.int64, device=dev)
+    probe_us = None
+    if not use_dist:
+        t0 = time.perf_counter()
+        for i in range(3):
+            engine.step(video, audio, ids[args.warmup + i])
+        torch.cuda.synchronize()
+        probe_us = int(0.85 * (time.perf_counter() - t0) / 3 * args.steps * 1e6)
+        lib.call("avid_clock_probe", max(1000, min(probe_us, 1900000)), _C.c_void_p(clock_out.data_ptr()),
+                 _C.c_void_p(_streams.place(dev).comm.cuda_stream))
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):
@@ -360,6 +408,9 @@ def main():
                           "bucket_count": len(engine.buckets.bounds),
                           "gradient_bytes": int(engine.flat.numel * 4)})
     loss_val = float(loss)
+    torch.cuda.synchronize()
+    co = clock_out.tolist()
+    clock_ghz = round(co[0] / co[1] / 10.0, 3) if co[1] > 0 else None
     from avid_hip import streams as _streams
     stream_report = _streams.report(dev)
 
@@ -376,8 +427,17 @@ def main():
         # FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note, + WRITE_SIZE), bytes per launch
         tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
         pmc = json.load(open(tf)) if os.path.exists(tf) else {}
+        traffic_source = pmc.pop("_source", None)
+        now = csrc_digest()
+        if traffic_source is None or traffic_source.get("csrc_sha256") != now:
+            # the table was taken from other kernel sources than the ones running now: no stale figure in the record
+            print("bench.py: profiles/pmc_traffic.json was collected from different kernel sources "
+                  f"({(traffic_source or {}).get('csrc_sha256', 'unstamped')[:12]} vs {now[:12]} now): roofline.traffic is null; "
+                  "re-run tools/collect_profiles.sh on the GPU box and commit the regenerated table", file=sys.stderr)
+            traffic_source = dict(traffic_source or {}, stale=True, csrc_sha256_now=now)
+            pmc = {}
         traffic = pmc.get(dom)
-        if traffic is None:     # a renamed / new dominant kernel must not report a stale figure: null + a loud note
+        if traffic is None and pmc:     # a renamed / new dominant kernel must not report a stale figure: null + a loud note
             print(f"bench.py: profiles/pmc_traffic.json has no entry for the dominant kernel {dom!r}: roofline.traffic "
                   f"is null; re-run tools/collect_profiles.sh on the GPU box and commit the regenerated file",
                   file=sys.stderr)
@@ -397,6 +457,8 @@ def main():
                        "loss": round(loss_val, 5), **(dist_info or {})},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": dict({"file": "profiles/pmc_traffic.json"}, **(traffic_source or {})),
+                         "shader_clock_ghz": clock_ghz,
                          "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                          "launches_per_step": d["launches"] / kern_steps,
                          "avg_launch_ms": round(d["ms"] / d["launches"], 4),

@@ -448,6 +448,10 @@ typedef struct avid_stream_ws {
  * which of its streams the hardware serialises (streams that share a hardware queue, or queues that share a dispatch
  * pipe: 4 pipes serve GPU_MAX_HW_QUEUES queues) before it places the step's four streams — avid_hip/streams.py. */
 int avid_probe_spin(int us, avid_stream_t stream);
+/* The shader clock while other work runs: one wave on `stream` spins for `us` microseconds of the constant 100 MHz clock
+ * and writes out2[0] = shader-clock cycles elapsed (s_memtime), out2[1] = 100 MHz ticks elapsed (device int64 x 2):
+ * GHz = out2[0] / out2[1] / 10.  bench.py runs it beside the timed region (roofline.shader_clock_ghz). */
+int avid_clock_probe(int us, long long* out2, avid_stream_t stream);
 /* Everything issued to `waiter` after this call runs behind everything issued to `waited` before it (one event of the
  * executor's pool: record + wait) — what AVID_OP_WAIT does inside a program, for a binding that orders its collectives'
  * stream behind the streams that produced a gradient bucket. */

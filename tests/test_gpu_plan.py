@@ -179,3 +179,24 @@ def test_backward_twice_raises(gpu_device):
     (v.sum() + a.sum()).backward(retain_graph=True)
     with pytest.raises(RuntimeError):
         (v.sum() + a.sum()).backward()
+
+
+def test_placed_streams_run_concurrently(gpu_device):
+    """avid_hip/streams.py: the audio tower's, the trailing and the collectives' stream of the current stream overlap with
+    it and with each other (single-wave probe kernels: a serialised pair takes twice as long) — also when other streams
+    were created first, which is what moves hardware queues onto shared dispatch pipes."""
+    from avid_hip import streams
+    clutter = [torch.cuda.Stream(gpu_device) for _ in range(3)]        # (an RCCL communicator, a test, a data loader ...)
+    s = torch.cuda.Stream(gpu_device)
+    with torch.cuda.stream(s):
+        ss = streams.place(gpu_device)
+        assert streams.place(gpu_device) is ss                           # cached per compute stream
+        with torch.cuda.stream(ss.side):
+            assert streams.current_set(gpu_device) is ss                 # the audio tower's stream finds its set
+    assert ss.report["probed"] and ss.report["independent"] == 4, ss.report
+    four = [ss.main, ss.side, ss.trail, ss.comm]
+    alone = min(streams._alone_us(ss.main) for _ in range(3))
+    for a in range(4):
+        for b in range(a + 1, 4):
+            assert streams.concurrent(four[a], four[b], alone), (a, b, ss.report)
+    del clutter

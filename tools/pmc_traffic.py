@@ -37,5 +37,11 @@ for r in csv.DictReader(open(summary)):
     tot_bytes[short] += (2 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024
     tot_calls[short] += n
 res = {k: round(tot_bytes[k] / tot_calls[k]) for k in tot_bytes}
+# stamp: which kernel sources the counters were taken from (bench.py refuses the table when they differ from the ones
+# it runs; there is no git on the GPU box — tools/stamp_traffic.py adds the commit afterwards)
+import datetime, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_digest
+res["_source"] = {"csrc_sha256": csrc_digest(), "date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ")}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
