@@ -21,19 +21,18 @@ from . import lib
 from .lib import AvidHipError, ConvDesc
 
 _WS = {}
-OVERLAP_IN_CAPTURE = bool(int(__import__('os').environ.get('AVID_OVERLAP_IN_CAPTURE', '1')))
-# Weight gradients on a trailing stream (eager steps driven by parallel.TrainStep only): nothing in the backward
+OVERLAP_IN_CAPTURE = True      # the two towers stay on two streams inside a hipGraph capture (graph branches)
+# Weight gradients on a trailing stream (steps driven by parallel.TrainStep / a launch program): nothing in the backward
 # chain consumes dw, so wgrad(L) is issued on a helper stream that only waits for its dy and is joined once, before
 # the optimizer — it then runs next to the small kernels of the chain (BatchNorm finalize / apply, split-K reduces)
 # instead of in front of them.  Needs the gradient to land in the flat buffer (GradSlots): a dw handed back to
-# autograd would be accumulated on the main stream before the helper stream has written it.
-# Single-process steps only: with a process group in the loop (even a one-rank RCCL group) the two extra streams
-# next to the collectives' own made the step slower (4320 -> 4220 clips/s; 2570 with GPU_MAX_HW_QUEUES=8), so
-# TrainStep keeps the weight gradients on the compute streams whenever gradients are all-reduced.
+# autograd would be accumulated on the main stream before the helper stream has written it.  With or without a process
+# group (round 3 kept it to single-process steps: what it measured then was two hardware queues on one dispatch pipe,
+# avid_hip/streams.py).
 DEFER_WGRAD = int(__import__('os').environ.get('AVID_DEFER_WGRAD', '1'))
 # (inside a hipGraph capture the trailing streams become graph branches; the replay schedules them worse than the
 # eager streams: 4518 -> 4309 clips/s with --graph 1, so a capture keeps the weight gradients on the compute streams)
-DEFER_IN_CAPTURE = bool(int(__import__('os').environ.get('AVID_DEFER_IN_CAPTURE', '0')))
+DEFER_IN_CAPTURE = False
 _DEFER_ON = False          # set by parallel.TrainStep around loss.backward()
 _DEFERRED = {}             # compute stream handle -> its trailing wgrad stream
 _DEFER_USED = set()
@@ -70,9 +69,9 @@ def join_deferred_wgrads():
 # (GradSlots armed by parallel.TrainStep), because the launch happens later than the autograd node that produced dy
 # ------------------------------------------------------------------------------------------------
 GROUP_WGRAD = int(os.environ.get("AVID_GROUP_WGRAD", "1"))
-GROUP_MAX = min(12, max(1, int(os.environ.get("AVID_GROUP_MAX", "12"))))
+GROUP_MAX = 12           # items of one grouped launch (avid_conv_wgrad_group takes at most 12; round-3 sweep: flat within noise)
 # queued layers that are flushed when a layer with its own weight-gradient launch comes by
-GROUP_MIN_FLUSH = int(os.environ.get("AVID_GROUP_MIN_FLUSH", "4"))
+GROUP_MIN_FLUSH = 4
 _GROUP_PENDING = {}        # compute stream handle -> [(desc, x, dy, dst, slot)]
 _GROUP_WS_BYTES = {}       # tuple of layer geometries -> workspace bytes
 
@@ -462,15 +461,12 @@ class TransposedWeights:
         # Winograd-transformed weights U (wino.hip): which 3x3 layers run on that path, in which direction and on which
         # of the two kernels (their operand-fragment orders differ) depends on the activations' size, i.e. is known at
         # call time: the first step's calls REGISTER what they need (`_u_for`) and transform inside the call; from the
-        # second step on one launch per direction and step keeps all of them current (`refresh_wino`, on the helper
-        # stream) and the calls pick them up.  AVID_WINO_PRE: 0 off, 1 both directions, 2 (default) input gradients
-        # only — measured on one box, alternating: 11.415-11.435 / 11.424-11.439 / 11.381-11.408 ms per step.  The
-        # forward's transforms cannot be had for free: in front of the model they delay the stem convolution, which
-        # then loses its race with the helper stream (TrainStep.forward_backward), and behind the gradient fill on the
-        # helper the first Winograd layer waits for them (forward 4.25 -> 4.37 ms, backward 7.0 -> 6.9).
-        pre = os.environ.get("AVID_WINO_PRE", "2")
-        self.wino_on = pre in ("1", "2")
-        self.wino_fwd_on = pre == "1"
+        # second step on one launch per step keeps the INPUT GRADIENTS' transforms current (`refresh_wino`, on the helper
+        # stream) and the calls pick them up; the forward's stay inside the calls: hoisted in front of the model they delay
+        # the stem convolution, which then loses its race with the helper stream, and behind the gradient fill on the
+        # helper the first Winograd layer waits for them (round 3: forward 4.25 -> 4.37 ms, no net gain; 410f826, db70d52).
+        self.wino_on = True
+        self.wino_fwd_on = False
         self.umap, self.uwant, self.n_wino, self.ucount = {}, {}, 0, [0, 0]
         self.uready, self.uevent, self.uwaited = False, None, set()
         self.wparams = {p.data_ptr(): p for p in ws if _kdims(p) == (1, 3, 3)}

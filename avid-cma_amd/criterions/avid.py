@@ -1,6 +1,4 @@
 """AVID memory-bank criterion on gfx950 kernels (reference: criterions/avid.py:20-236)."""
-import pprint
-
 import torch
 from torch import nn
 import torch.distributed as dist
@@ -142,14 +140,53 @@ class AVIDSimilarityMemoryBank(nn.Module):
                 ops.bank_update(self.view2_mem, y_all, a_all, audio_mom)
 
     def __repr__(self):
-        repr_dict = {
-            'name': self._get_name(),
-            'num_negatives': int(self.num_negatives),
-            'momentum': [float(self.momentum[0]), float(self.momentum[1])],
-            'view1_buffer_size': self.view1_mem.shape,
-            'view2_buffer_size': self.view2_mem.shape,
-        }
-        return pprint.pformat(repr_dict, indent=2)
+        return describe_bank(self)
+
+
+def describe_bank(bank):
+    """What ``str(criterion)`` shows in the training log (utils/main_utils.py:235): sizes and hyper-parameters."""
+    rows = [("name", bank._get_name()), ("num_negatives", int(bank.num_negatives)),
+            ("momentum", [float(m) for m in bank.momentum[:2]]),
+            ("view1_buffer_size", tuple(bank.view1_mem.shape)), ("view2_buffer_size", tuple(bank.view2_mem.shape))]
+    return "{ " + ",\n  ".join(f"{k!r}: {v!r}" for k, v in rows) + "}"
+
+
+def restore_banks_and_partition(criterion, checkpoint):
+    """A criterion picks up the memory banks and the partition constant of an earlier run (criterions/avid.py:187-200,
+    criterions/avid_cma.py:308-319): both banks verbatim, and ONE Z = the mean of every ``avg_exp_score`` the file holds,
+    written into every NCE term of this criterion.  Buffers are overwritten in place (shapes must agree)."""
+    saved = torch.load(checkpoint, map_location='cpu')['train_criterion']
+    zs = [v.reshape(()) for k, v in saved.items() if 'avg_exp_score' in k]
+    with torch.no_grad():
+        for name in ('view1_mem', 'view2_mem'):
+            dst, src = getattr(criterion.nce_average, name), saved['nce_average.' + name]
+            if tuple(dst.shape) != tuple(src.shape):
+                raise RuntimeError(f"checkpoint bank {name} has shape {tuple(src.shape)}, this criterion {tuple(dst.shape)}")
+            dst.copy_(src)
+        if zs:
+            z = torch.stack(zs).mean()
+            for m in criterion.modules():
+                if isinstance(m, NCECriterion):
+                    m.avg_exp_score.copy_(z)
+                    m._z_ready = None
+
+
+def combine_losses(terms, groups, tb_log):
+    """``terms``: {score-set name: NCE loss}; ``groups``: [(names of the set pair, coefficient)].  Every group's loss is
+    the mean of its (up to two) directions, the total their coefficient-weighted sum (criterions/avid.py:216-232,
+    criterions/avid_cma.py:338-358), accumulated in the reference's order."""
+    total, per_group = None, []
+    for names, coeff in groups:
+        acc = 0.
+        for k in terms:
+            if k in names:
+                acc = acc + terms[k] / 2.
+        per_group.append(acc)
+        part = acc * coeff
+        total = part if total is None else total + part
+    for k, v in terms.items():
+        tb_log[f'Loss/{k}'] = v
+    return total, per_group
 
 
 class AVID(nn.Module):
@@ -173,17 +210,8 @@ class AVID(nn.Module):
         self.wModal_coeff = wModal_coeff / sum_coeff
         self.criterion = NCECriterion(num_data).to(_device_of(device))
 
-        # Restore memory bank and partition function if necessary (avid.py:187-200)
         if checkpoint is not None:
-            ckp = torch.load(checkpoint, map_location='cpu')['train_criterion']
-            state_dict = self.state_dict()
-            state_dict['nce_average.view1_mem'] = ckp['nce_average.view1_mem']
-            state_dict['nce_average.view2_mem'] = ckp['nce_average.view2_mem']
-            Z = torch.stack([ckp[k].reshape(()) for k in ckp if 'avg_exp_score' in k]).mean()
-            for k in state_dict:
-                if 'avg_exp_score' in k:
-                    state_dict[k] = Z
-            self.load_state_dict(state_dict)
+            restore_banks_and_partition(self, checkpoint)
 
     def forward(self, emb1, emb2, target):
         tb_log = {}
@@ -196,19 +224,10 @@ class AVID(nn.Module):
             tb_log['Loss/wModal'] = 0
             return total_loss, tb_log
         scores = self.nce_average(emb1, emb2, target)
-
-        xModal_loss, wModal_loss = 0., 0
-        for k in scores:                       # one shared NCECriterion: Z comes from 'v2a' on the first batch
-            loss = self.criterion(*scores[k])
-            if k in {'v2a', 'a2v'}:
-                xModal_loss += loss / 2.
-            elif k in {'v2v', 'a2a'}:
-                wModal_loss += loss / 2.
-            tb_log[f'Loss/{k}'] = loss
-
-        tb_log['Loss/xModal'] = xModal_loss
-        tb_log['Loss/wModal'] = wModal_loss
-        total_loss = xModal_loss * self.xModal_coeff + wModal_loss * self.wModal_coeff
+        terms = {k: self.criterion(*pair) for k, pair in scores.items()}   # one shared NCECriterion: Z comes from 'v2a'
+        total_loss, (xm, wm) = combine_losses(terms, [(('v2a', 'a2v'), self.xModal_coeff), (('v2v', 'a2a'), self.wModal_coeff)],
+                                              tb_log)
+        tb_log['Loss/xModal'], tb_log['Loss/wModal'] = xm, (wm if torch.is_tensor(wm) else 0)
         return total_loss, tb_log
 
     def set_epoch(self, epoch):

@@ -1,6 +1,4 @@
 """AVID+CMA criterion on gfx950 kernels (reference: criterions/avid_cma.py:24-364)."""
-import pprint
-
 import torch
 from torch import nn
 import torch.distributed as dist
@@ -8,7 +6,8 @@ import torch.distributed as dist
 from avid_hip import ops
 from utils.alias_method import AliasMethod
 from criterions.nce import NCECriterion
-from criterions.avid import AVIDSimilarityMemoryBank, _device_of
+from criterions.avid import (AVIDSimilarityMemoryBank, _device_of, combine_losses, describe_bank,
+                             restore_banks_and_partition)
 
 __all__ = ['AVID_CMA']
 
@@ -134,14 +133,7 @@ class AVIDSimilarityPositiveExpansion(AVIDSimilarityMemoryBank):
             dist.barrier()
 
     def __repr__(self):
-        repr_dict = {
-            'name': self._get_name(),
-            'num_negatives': int(self.num_negatives),
-            'momentum': [float(self.momentum[0]), float(self.momentum[1])],
-            'view1_buffer_size': self.view1_mem.shape,
-            'view2_buffer_size': self.view2_mem.shape,
-        }
-        return pprint.pformat(repr_dict, indent=2)
+        return describe_bank(self)
 
 
 class AVID_CMA(nn.Module):
@@ -172,17 +164,8 @@ class AVID_CMA(nn.Module):
 
         self.criterion = NCECriterion(num_data).to(_device_of(device))
 
-        # Restore memory bank and partition function from an AVID checkpoint (avid_cma.py:308-319)
-        if checkpoint is not None:
-            ckp = torch.load(checkpoint, map_location='cpu')['train_criterion']
-            state_dict = self.state_dict()
-            state_dict['nce_average.view1_mem'] = ckp['nce_average.view1_mem']
-            state_dict['nce_average.view2_mem'] = ckp['nce_average.view2_mem']
-            Z = torch.stack([ckp[k].reshape(()) for k in ckp if 'avg_exp_score' in k]).mean()
-            for k in state_dict:
-                if 'avg_exp_score' in k:
-                    state_dict[k] = Z
-            self.load_state_dict(state_dict)
+        if checkpoint is not None:       # an AVID run's banks and Z (avid_cma.py:308-319)
+            restore_banks_and_partition(self, checkpoint)
 
         self.resample_freq = resample_freq
         self.nce_average.find_correspondences()
@@ -190,25 +173,11 @@ class AVID_CMA(nn.Module):
     def forward(self, emb1, emb2, target):
         tb_log = {}
         scores = self.nce_average(emb1, emb2, target)
-
-        xModalInst_loss, wModalInst_loss, xModalPos_loss, wModalPos_loss = 0., 0., 0., 0.
-        for k in scores:
-            loss = self.criterion(*scores[k])
-            if k in {'inst-v2a', 'inst-a2v'}:
-                xModalInst_loss += loss / 2.
-            elif k in {'inst-v2v', 'inst-a2a'}:
-                wModalInst_loss += loss / 2.
-            elif k in {'pos-v2a', 'pos-a2v'}:
-                xModalPos_loss += loss / 2.
-            elif k in {'pos-v2v', 'pos-a2a'}:
-                wModalPos_loss += loss / 2.
-            with torch.no_grad():
-                tb_log[f'Loss/{k}'] = loss
-
-        total_loss = xModalInst_loss * self.xModalInstCoeff
-        total_loss += wModalInst_loss * self.wModalInstCoeff
-        total_loss += xModalPos_loss * self.xModalPosCoeff
-        total_loss += wModalPos_loss * self.wModalPosCoeff
+        terms = {k: self.criterion(*pair) for k, pair in scores.items()}
+        total_loss, _ = combine_losses(terms, [(('inst-v2a', 'inst-a2v'), self.xModalInstCoeff),
+                                               (('inst-v2v', 'inst-a2a'), self.wModalInstCoeff),
+                                               (('pos-v2a', 'pos-a2v'), self.xModalPosCoeff),
+                                               (('pos-v2v', 'pos-a2a'), self.wModalPosCoeff)], tb_log)
         return total_loss, tb_log
 
     def set_epoch(self, epoch):

@@ -2005,32 +2005,7 @@ struct PkPlan {
   long long tail_row0;   // rows [tail_row0, M) are produced by splitk_reduce_kernel from f slabs
   size_t ws_floats;
 };
-static bool pk_enabled() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("AVID_PK");
-    on = e ? atoi(e) != 0 : 1;
-  }
-  return on != 0;
-}
-static int pk_alt() {
-  static int alt = -1;
-  if (alt < 0) {
-    const char* e = getenv("AVID_PK_ALT");
-    alt = e ? atoi(e) : 0;
-  }
-  return alt;
-}
-static double pk_red_scale(int mode) {   // tuning knob: weight of the slab pass in the planner's cost, per direction
-  static double sc[2] = {-1.0, -1.0};
-  if (sc[0] < 0) {
-    const char* e0 = getenv("AVID_PK_RED_FWD");
-    const char* e1 = getenv("AVID_PK_RED_DGRAD");
-    sc[0] = e0 ? atof(e0) : 1.0;
-    sc[1] = e1 ? atof(e1) : 1.0;
-  }
-  return sc[mode ? 1 : 0];
-}
+static bool pk_enabled() { return true; }   // (the persistent kernel had an off switch while the plain one was the reference for it)
 static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_out, int mode) {
   PkPlan k{};
   const int cus = device_cus();
@@ -2038,10 +2013,9 @@ static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_o
   k.tile = tile;
   switch (tile) {
     case 0: k.BM = 128; k.BN = 128; break;
-    case 1: k.BM = 128; k.BN = 64; break;
-    case 2: k.BM = 256; k.BN = 128; per_cu = 1; break;
-    case 4: k.BM = 128; k.BN = 64; break;           // two waves with 64 x 64 wave tiles (AVID_PK_ALT=4: VERDICT r2 #8)
-    default: k.BM = 256; k.BN = 64; per_cu = 1; break;
+    default: k.BM = 128; k.BN = 64; break;
+    // (256 x 128 / 256 x 64 tiles with one workgroup per CU and a two-wave 128 x 64 tile with 64 x 64 wave tiles were
+    //  measured and rejected in rounds 2 / 3: DESIGN.md 8c, 9.2)
   }
   const int ntn = Cd / k.BN;
   const int C = cus / ntn * ntn;                    // CUs, a whole number of M-tiles
@@ -2052,7 +2026,7 @@ static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_o
   // every CU gets the same number; the remaining tail tiles are cut into f K-ranges ("units", at most one
   // per workgroup, handed out starting with the workgroups that got one full tile less).  Cost model in
   // k-tiles per CU: a started tile or unit pays ~2 k-tiles of prologue/epilogue, a split adds the slab pass.
-  const double ovh = 2.0, red = 4.0 * 128 / k.BN * pk_red_scale(mode);
+  const double ovh = 2.0, red = 4.0 * 128 / k.BN;
   double best = 1e300;
   const int fmax = nk / 3 < 64 ? (nk / 3 < 1 ? 1 : nk / 3) : 64;
   for (long long m = T / C; m >= 0 && m >= T / C - 1; --m) {
@@ -2089,12 +2063,8 @@ static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_o
 // rows twice and runs a few % below the square tile per flop, so it only wins where whole rounds are lost.
 static PkPlan plan_pk(long long M, int Cd, int nk, int mode) {
   double c0, c1;
-  const int alt = pk_alt();
-  if (Cd % 128 != 0) return plan_pk_tile(M, Cd, nk, alt == 1 ? 3 : (alt == 4 ? 4 : 1), &c0, mode);
-  if (alt == 1) return plan_pk_tile(M, Cd, nk, 2, &c0, mode);
-  if (alt == 2) return plan_pk_tile(M, Cd, nk, 1, &c0, mode);
+  if (Cd % 128 != 0) return plan_pk_tile(M, Cd, nk, 1, &c0, mode);
   const PkPlan wide = plan_pk_tile(M, Cd, nk, 0, &c0, mode);
-  if (alt == 3) return wide;
   const PkPlan narrow = plan_pk_tile(M, Cd, nk, 1, &c1, mode);
   return c1 * 1.04 < c0 ? narrow : wide;
 }
@@ -2436,10 +2406,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     int rc;
     switch (pk.tile) {
       case 0: rc = launch_pk<2, 2, 2, 2, MODE>(k, pk.grid, s); break;
-      case 1: rc = launch_pk<4, 1, 1, 2, MODE>(k, pk.grid, s); break;
-      case 2: rc = launch_pk<4, 2, 2, 2, MODE>(k, pk.grid, s); break;
-      case 4: rc = launch_pk<2, 1, 2, 2, MODE>(k, pk.grid, s); break;
-      default: rc = launch_pk<4, 2, 2, 1, MODE>(k, pk.grid, s); break;
+      default: rc = launch_pk<4, 1, 1, 2, MODE>(k, pk.grid, s); break;
     }
     if (rc || pk.f == 1) return rc;
     const long long rows = a.M - pk.tail_row0, n4 = rows * a.Cd / 4, off = pk.tail_row0 * a.Cd;
@@ -2859,13 +2826,8 @@ static WgradPlan wgrad_plan(const avid_conv_desc* d) {
   }
   const long long tiles = (long long)pl.kt_tiles * pl.n_tiles;
   const long long chunks = ceil_div(M, 32);
-  // 4-wave workgroups, two per CU; AVID_WG_SLOTS (default 512 = the whole chip) is how many of them one launch aims to fill
-  static int slots = 0;
-  if (!slots) {
-    const char* e = getenv("AVID_WG_SLOTS");
-    slots = e ? atoi(e) : 512;
-    if (slots < 1) slots = 512;
-  }
+  // 4-wave workgroups, two per CU: one launch aims to fill 512 of them = the whole chip (fewer splits measured: no gain inside the step)
+  const int slots = 512;
   long long want = slots / tiles;
   long long max_split = chunks / 4 > 0 ? chunks / 4 : 1;  // >= 4 chunks (128 rows) per split (conv4x temporal: 56 -> 42 us vs 8)
   long long ns = want < 1 ? 1 : (want > max_split ? max_split : want);
@@ -3099,13 +3061,9 @@ extern "C" int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* 
   AVID_REQUIRE(fl == 0 || (ws && ws_bytes >= sizeof(float) * fl), AVID_E_BADARG, "conv_wgrad_group: workspace too small");
   g.n = n;
   {
-    static int run = 0;               // AVID_WG_GROUP_RUN: 8 / 16 / 32 / 64
-    if (!run) {
-      const char* e = getenv("AVID_WG_GROUP_RUN");
-      run = e ? atoi(e) : 32;         // measured (3 launches per step): 8: 494 MB per launch 1.076 ms; 16: 428 MB 1.070 ms;
-      if (run != 8 && run != 16 && run != 32 && run != 64) run = 32;   // 32: 389 MB 1.080 ms; 64: 377 MB 1.254 ms (278 MB algorithmic)
-    }
-    g.run = (unsigned)run;
+    // runs of 32 consecutive items per XCD — measured (3 launches per step): 8: 494 MB per launch 1.076 ms; 16: 428 MB
+    // 1.070 ms; 32: 389 MB 1.080 ms; 64: 377 MB 1.254 ms (278 MB algorithmic)
+    g.run = 32u;
   }
   WgradGroupReduce r;
   memset(&r, 0, sizeof(r));
@@ -3139,12 +3097,7 @@ extern "C" int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* 
     set = true;
   }
   int grid = g.item0[n];
-  static int grid_cap = 0;              // AVID_WG_GROUP_GRID: experiment knob (workgroups of a grouped launch; default 2 per CU)
-  if (!grid_cap) {
-    const char* e = getenv("AVID_WG_GROUP_GRID");
-    grid_cap = e ? atoi(e) : 2 * device_cus();
-    if (grid_cap < 64) grid_cap = 2 * device_cus();
-  }
+  const int grid_cap = 2 * device_cus();      // two workgroups per CU
   if (grid > grid_cap) grid = grid_cap;
   {
     ScopedTimer t(s, "wgrad_group_kernel", flops, bytes);

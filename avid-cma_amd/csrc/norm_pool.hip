@@ -930,22 +930,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   if (wave == 0 && c < C) out[c] = sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane];
 }
 
-// the fused finalize + apply path of small layers: element bound (env AVID_BN_FUSED_MAX, 0 = off) and grid
+// the fused finalize + apply path of small layers: element bound and grid
 static bool bn_fused_ok(int64_t M, int C) {
-  static long long cap = -1;
-  if (cap < 0) {
-    const char* e = getenv("AVID_BN_FUSED_MAX");
-    cap = e ? atoll(e) : (1ll << 23);   // conv3x-sized layers (6.4 M elements) still gain a launch; conv2x-sized ones lose
-  }
+  const long long cap = 1ll << 23;      // conv3x-sized layers (6.4 M elements) still gain a launch; conv2x-sized ones lose
   return C % FA_CH == 0 && (long long)M * C <= cap;
 }
 static unsigned bn_fused_grid(int64_t M, int C) {
   const int ncg = C / FA_CH;
-  static int cap = 0;
-  if (!cap) {
-    const char* e = getenv("AVID_BN_FUSED_BLOCKS");
-    cap = e ? atoi(e) : 256;      // more blocks repeat the fold more often: 512 / 1024 / 2048 measured slower
-  }
+  const int cap = 256;            // more blocks repeat the fold more often: 512 / 1024 / 2048 measured slower
   // each block folds its 16 channels' partial rows itself (a fixed ~3 us): at least 4 x 64 rows of apply work per
   // block, at most `cap` blocks
   const long long chunks = (M + 63) / 64;
@@ -956,12 +948,7 @@ static unsigned bn_fused_grid(int64_t M, int C) {
 }
 
 static unsigned ew_grid(long long n) {
-  static int cap = 0;
-  if (!cap) {
-    const char* e = getenv("AVID_EW_CAP");   // tuning knob: blocks (of 256 threads) per launch at most
-    cap = e ? atoi(e) : 256 * 32;      // 8192 blocks: conv2x-sized apply 35.2 -> 32.8 us, backward apply 53.7 -> 49.9 us
-    if (cap < 1) cap = 256 * 32;
-  }
+  const int cap = 256 * 32;            // 8192 blocks of 256 threads at most: conv2x-sized apply 35.2 -> 32.8 us, backward apply 53.7 -> 49.9 us
   long long g = ceil_div(n, 256);
   if (g > cap) g = cap;
   if (g < 1) g = 1;

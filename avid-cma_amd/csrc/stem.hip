@@ -173,7 +173,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const S
     }
   };
 
-  // tiles in XCD-contiguous order (AVID_STEM_XCD, default on): consecutive tiles are neighbouring row bands of a frame and
+  // tiles in XCD-contiguous order (round 3: time unchanged, weight-gradient traffic -1 %): consecutive tiles are neighbouring row bands of a frame and
   // neighbouring frames, whose input patches overlap (6 of 19 rows, two of three planes) — dealt in hardware order (id %
   // 8 = XCD) the overlap is fetched by eight different L2s
   int tile = p.xcd_local ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
@@ -551,9 +551,7 @@ static void stem_geometry(const avid_conv_desc* d, StemArgs& a, int tile) {
   const int rows_out = tile % d->Wo == 0 ? tile / d->Wo : (tile - 1 + d->Wo - 1) / d->Wo + 1;
   a.rows_in_max = 2 * (rows_out - 1) + 7;
   a.ntiles = d->B * d->Ti * a.tiles_per_frame;
-  static int xl = -1;
-  if (xl < 0) { const char* e = getenv("AVID_STEM_XCD"); xl = e ? atoi(e) : 1; }
-  a.xcd_local = xl;
+  a.xcd_local = 1;
 }
 
 size_t stem_patch_floats(const avid_conv_desc* d, int tile) {

@@ -54,7 +54,7 @@ struct WinoArgs {
   int F, H, W, TH, TW, Cr, Cn, ncb;
   long long ntiles;
   int units;                            // tile blocks x column blocks, column block fastest
-  int xcd_local;                        // XCD-contiguous unit order (AVID_WINO_XCD, default 1)
+  int xcd_local;                        // XCD-contiguous unit order
   int v2;                               // host only: launch wino2_kernel (units are 64-tile blocks then)
 };
 
@@ -1074,16 +1074,16 @@ static const WinoCfg& wino_cfg() {
     // forward and 91 -> 70 us input gradient, audio block 1 (64 channels, 16000 pixels) 28 -> 26 and 34 -> 27 us; it
     // loses on audio block 2 (128 channels, 4160 pixels: 31 -> 39 us), block 3 (256, 1344: 36 -> 66) and conv5x (512 channels,
     // 1024 pixels: 59 -> 120).  Rule: >= min_m pixels, <= max_c output channels, pixels x max(channels) >= min_work.
-    c.min_m = g_wino_override[1] >= 0 ? g_wino_override[1] : wino_env("AVID_WINO_MIN_M", 6000);
-    c.max_c = g_wino_override[2] >= 0 ? g_wino_override[2] : wino_env("AVID_WINO_MAXC", 256);
-    c.min_work = g_wino_override[1] >= 0 ? 0 : wino_env("AVID_WINO_MIN_WORK", 1000000);
+    c.min_m = g_wino_override[1] >= 0 ? g_wino_override[1] : 6000;
+    c.max_c = g_wino_override[2] >= 0 ? g_wino_override[2] : 256;
+    c.min_work = g_wino_override[1] >= 0 ? 0 : 1000000;
     // the weight-gradient kernel follows the same switches unless its own are set
     c.wg_on = c.on && wino_env("AVID_WINO_WGRAD", 1);
     // (weight gradient, same rule: conv4x 89 -> 67 us, audio block 1 35 -> 29 us per layer; the smaller layers ride in
     // the grouped launch at the same ~100 TFLOP/s the Winograd kernel would give them)
-    c.wg_min_m = g_wino_override[1] >= 0 ? g_wino_override[1] : wino_env("AVID_WINO_WGRAD_MIN_M", 6000);
-    c.wg_max_c = g_wino_override[2] >= 0 ? g_wino_override[2] : wino_env("AVID_WINO_WGRAD_MAXC", 256);
-    c.wg_min_work = g_wino_override[1] >= 0 ? 0 : wino_env("AVID_WINO_WGRAD_MIN_WORK", 1000000);
+    c.wg_min_m = g_wino_override[1] >= 0 ? g_wino_override[1] : 6000;
+    c.wg_max_c = g_wino_override[2] >= 0 ? g_wino_override[2] : 256;
+    c.wg_min_work = g_wino_override[1] >= 0 ? 0 : 1000000;
     c.loaded = true;
   }
   return c;
@@ -1108,15 +1108,12 @@ size_t wino_ws_bytes(const avid_conv_desc* d, int mode) {
   return sizeof(float) * 16 * (size_t)d->Cin * d->Cout;
 }
 
-// wino2_kernel (one workgroup per CU, 64-tile units) where the layer has at least AVID_WINO2_MIN_ROUNDS/10 rounds of
-// units for the CUs; AVID_WINO2=0 keeps wino_kernel everywhere
+// wino2_kernel (one workgroup per CU, 64-tile units) where the layer has at least 1.5 rounds of units for the CUs
+// (avid_wino2_configure changes the bound)
 static int g_wino2_override = -1;      // avid_wino2_configure
 
 static bool wino_use_v2(const avid_conv_desc* d, int mode) {
-  static int on = -1, env_r10 = 0;
-  if (on < 0) { on = wino_env("AVID_WINO2", 1); env_r10 = wino_env("AVID_WINO2_MIN_ROUNDS", 15); }
-  if (!on) return false;
-  const int min_r10 = g_wino2_override >= 0 ? g_wino2_override : env_r10;
+  const int min_r10 = g_wino2_override >= 0 ? g_wino2_override : 15;
   const int Cn = mode ? d->Cin : d->Cout, ncb = Cn / 64;
   const long long TH = (d->Hi + 1) / 2, TW = (d->Wi + 1) / 2;
   const long long units = ceil_div((long long)d->B * d->Ti * TH * TW, W2_TB) * ncb;
@@ -1180,9 +1177,7 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
   a.v2 = wino_use_v2(d, mode) ? 1 : 0;
   a.units = (int)(ceil_div(a.ntiles, a.v2 ? W2_TB : W_TB) * a.ncb);
   {
-    static int xl = -1;
-    if (xl < 0) xl = wino_env("AVID_WINO_XCD", 1);
-    a.xcd_local = xl;
+    a.xcd_local = 1;
   }
   int rc = AVID_OK;
   if (u_pre) {            // transformed once per step by avid_weight_transpose_batched (mode 1 / 2 descriptors)

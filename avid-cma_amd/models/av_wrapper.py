@@ -130,7 +130,7 @@ class AV_Wrapper(nn.Module):
         return video_emb, audio_emb
 
 
-AUDIO_AFTER = int(__import__('os').environ.get('AVID_AUDIO_AFTER', '1'))   # after the stem: +0.4 % (0: 4833, 1: 4854, 2: 4830, 3: 4850, 4: 4854 clips/s)
+AUDIO_AFTER = 1   # the audio tower starts behind the video stem: +0.4 % (stage 0: 4833, 1: 4854, 2: 4830, 3: 4850, 4: 4854 clips/s)
 
 
 def av_wrapper(video_backbone, video_backbone_args, audio_backbone, audio_backbone_args, proj_dim=128,

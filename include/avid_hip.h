@@ -375,6 +375,17 @@ int avid_logspec(int B, int L, const float* sig, int n_stft, int hop, int T, con
 
 
 /* ------------------------------------------------------------------------------------------------
+ * Collectives: NOT part of this library.  SURVEY.md 8(b) sketched avid_comm_init / avid_allreduce_f32 /
+ * avid_allgather_bytes / avid_broadcast; they were deliberately not built.  The reference itself speaks to
+ * torch.distributed (utils/distributed_utils.py:12-19, utils/main_utils.py:105-117: DistributedDataParallel;
+ * criterions/avid.py:99-111, criterions/nce.py:27-33), whose "nccl" backend IS RCCL on ROCm — a second communicator
+ * behind this ABI would duplicate rendezvous, error handling and the process group the driver already owns.
+ * What the step needs from the collectives' side lives in the binding: avid-cma_amd/avid_hip/parallel.py (bucketed
+ * all-reduce over one flat gradient buffer issued on a placed stream, one fused bank all-gather, one flat buffer
+ * broadcast), with avid_stream_wait / avid_probe_spin below as the only native pieces (stream ordering and placement).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ------------------------------------------------------------------------------------------------
  * Launch programs: the host side of a whole forward / backward pass as ONE call.
  *
  * The reference drives its step from Python, one ATen call per layer (main-avid.py:155-180 ->

@@ -285,21 +285,22 @@ def test_trailing_wgrad_streams_change_nothing(gpu_device, per_layer_path):
 @pytest.mark.parametrize("helper_stream", [True, False])
 @pytest.mark.parametrize("variant", ["wino", "wino2"])
 def test_winograd_weight_tables_change_nothing(variant, helper_stream, gpu_device, monkeypatch, per_layer_path):
-    """From its second step on a TrainStep keeps the Winograd transforms of the weights current with ONE launch per
-    step (ops.TransposedWeights.refresh_wino, on the helper stream) instead of a transform launch inside every forward /
-    input-gradient call.  Same kernels, same arithmetic: losses and parameters after four steps must be IDENTICAL to
-    the run that transforms inside the calls (AVID_WINO_PRE=0) — and the table must really have been used."""
+    """From its second step on the per-layer step engine keeps the Winograd transforms of the weights for the INPUT
+    GRADIENTS current with ONE launch per step (ops.TransposedWeights.refresh_wino, on the helper stream) instead of a
+    transform launch inside every input-gradient call; the forward's transforms stay inside the calls.  Same kernels,
+    same arithmetic: losses and parameters after four steps must be IDENTICAL to the run that transforms inside every
+    call (table off) — and the table must really have been used."""
     from avid_hip import ops, lib
     ops.wino_configure(1, 1, 128)
     if variant == "wino2":
         ops.wino2_configure(0)
-    if not helper_stream:        # the arrangement of a step with a process group: no helper stream, the tables refreshed
-        monkeypatch.setattr(ops, "DEFER_WGRAD", 0)      # on the main stream in front of the model / behind the forward
+    if not helper_stream:        # no helper stream: the tables refreshed on the main stream behind the forward
+        monkeypatch.setattr(ops, "DEFER_WGRAD", 0)
     try:
         outs = []
-        for pre in ("0", "1", "2"):
-            monkeypatch.setenv("AVID_WINO_PRE", pre)
+        for table in (False, True):
             m, crit, ts = _make(gpu_device)
+            ts.twt.wino_on = table
             video, audio, ids = _data(gpu_device, steps=4)
             losses = [float(ts.step(video, audio, ids[i])) for i in range(3)]
             lib.timing_enable(True)
@@ -310,9 +311,7 @@ def test_winograd_weight_tables_change_nothing(variant, helper_stream, gpu_devic
             n_weight = rep.get("wino_weight_kernel", {"launches": 0})["launches"]
             n_wino = sum(v["launches"] for k, v in rep.items() if k.startswith("wino2_kernel<" if variant == "wino2" else "wino_kernel<"))
             assert n_wino >= 18                                   # 9 layers, forward and input gradient
-            if pre == "1":
-                assert ts.twt.n_wino == n_wino and n_weight == 0, (ts.twt.n_wino, n_wino, n_weight)
-            elif pre == "2":      # the default: input gradients from the table, the forward transforms in the call
+            if table:             # input gradients from the table, the forward transforms in the call
                 assert ts.twt.n_wino == n_wino // 2 and n_weight == n_wino // 2, (ts.twt.n_wino, n_wino, n_weight)
             else:
                 assert n_weight == n_wino
