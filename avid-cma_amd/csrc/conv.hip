@@ -3134,7 +3134,7 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
     const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
     if (!vec) {
       if (stem_fwd_supported(d))
-        snprintf(buf, len, "stem_fwd_kernel<%d,%d>", d->Cin, d->kt);
+        snprintf(buf, len, stem_fwd_is_split(d) ? "stem_fwd3_kernel<%d,%d>" : "stem_fwd_kernel<%d,%d>", d->Cin, d->kt);
       else
         snprintf(buf, len, "igemm_gather_kernel<%s>", ((M + 127) / 128) * (d->Cout / 64) >= 256 ? "4,1,1,2" : "2,2,1,1");
     } else if (wino_supported(d, 0)) {

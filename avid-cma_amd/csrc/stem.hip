@@ -281,6 +281,265 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void stem_fwd_kernel(const S
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the video stem's forward on the bf16 matrix instruction with fp32 accuracy ("bf16x3").
+// Every fp32 operand is split into three bf16 terms (round-to-nearest each: together the fp32 value to its last bit) and
+// a product is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid;
+// the dropped terms are <= 2^-24 of the product; measured error against fp64 BELOW the fp32 instruction's, whose
+// accumulator rounds once per term instead of once per sixteen) — 6/16 of the issue time of v_mfma_f32_32x32x2_f32.
+// The stem is the layer where that pays at once: K = 441 per output from a patch that sits in LDS, so there is no
+// operand traffic to speak of per matrix instruction (tools/bf16x3_lab.hip: on the K = 192 layers the loads, not the
+// products, set the time).
+//
+// Same tile geometry, patch loader (fp32 patch in LDS), tile order and epilogue as stem_fwd_kernel; different inner loop:
+//   k' rows r = (c*KT + dt)*7 + dh, r < R = CIN*KT*7; one k-step of 16 = rows (2s, 2s + 1) x 8 tap slots (dw = 7 -> zero
+//   weight); the half-wave g = lane >> 5 takes the taps of ITS parity, dw = g + 2j: consecutive pixels read patch columns
+//   two apart and the halves read neighbouring columns — every LDS bank once, as in the fp32 kernel;
+//   lane (pixel i, g): 8 patch floats (4 of row 2s, 4 of row 2s + 1) -> split in registers (44 VALU) -> 3 fragments;
+//   weights: split ONCE per call into fragment order Wf[step][column tile][hi | mid | lo][lane][8 bf16] and streamed
+//   through a double-buffered LDS stage four steps (24 KB) at a time.
+// 8 waves, 256-pixel tiles, one workgroup per CU (two waves per SIMD: the split of one hides in the other's products).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned uintx4_t __attribute__((ext_vector_type(4)));
+constexpr int S3_STEP_BYTES = 2 * 3 * 1024;     // weight fragments of one k-step: 2 column tiles x (hi | mid | lo) x 1 KB
+
+__device__ __forceinline__ unsigned s3_cvt_pk(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void s3_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = s3_cvt_pk(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = s3_cvt_pk(r0, r1);
+  const float t0 = r0 - __uint_as_float(m << 16), t1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = s3_cvt_pk(t0, t1);
+}
+
+// Wf[s][tile][plane][lane][e]: element e of lane (j = lane & 31, g = lane >> 5) = w[n = 32 tile + j][row 2s + (e >> 2)][dw = g + 2 (e & 3)]
+template <int CIN, int KT>
+__global__ void stem_split_weights_kernel(const float* __restrict__ w, uintx4_t* __restrict__ Wf) {
+  constexpr int R = CIN * KT * 7;
+  const int frag = blockIdx.x, lane = threadIdx.x;
+  const int s = frag >> 1, tile = frag & 1, n = 32 * tile + (lane & 31), g = lane >> 5;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int r = 2 * s + (e >> 2), dw = g + 2 * (e & 3);
+    const int pl = r / 7, dh = r - pl * 7, dt = pl % KT, c = pl / KT;
+    v[e] = (r < R && dw < 7) ? w[(((n * KT + dt) * 7 + dh) * 7 + dw) * CIN + c] : 0.f;
+  }
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s3_split2(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+  uintx4_t* dst = Wf + ((size_t)frag * 3) * 64 + lane;
+  dst[0] = uintx4_t{h[0], h[1], h[2], h[3]};
+  dst[64] = uintx4_t{m[0], m[1], m[2], m[3]};
+  dst[128] = uintx4_t{l[0], l[1], l[2], l[3]};
+}
+
+// (Splitting the patch ONCE at commit time into three 16-bit planes and assembling fragments from 16-bit LDS loads was
+// measured too: 24 ds_read_u16 + 12 v_perm per k-step instead of 4 ds_read2_b32 + 44 VALU — 735 us against 661: the LDS
+// instruction rate binds sooner than the vector ALU.)
+// Measured around this kernel (64 clips of 8 x 112 x 112: 661-700 us whatever the instruction mix — three ways of getting
+// the split terms into registers, two workgroup shapes, six-deep or three-deep accumulation chains): (a) the patch split
+// ONCE at commit time into three 16-bit planes, fragments from 24 ds_read_u16 + 12 v_perm per k-step: 735 us; (b) a dword
+// plane (hi << 16 | mid) + a 16-bit plane of lo, 4 ds_read2_b32 + 8 ds_read_u16 + 12 v_perm: 667; (c) this form, fp32 patch,
+// 4 ds_read2_b32 + 44 VALU per k-step: 661-680; (d) all chunks unrolled (compile-time patch offsets): 689; (e) 4 waves x
+// 128-pixel tiles x two workgroups per CU: 701.  One product instead of six: 318 us, three: 470 — 242 us of tile
+// overhead + 71 us per product where the pipe needs 51 at the 1.99 GHz the chip holds under this kernel (2.29 under the
+// fp32 one).  What does not move is the LDS traffic of the weight fragments: every wave reads all 64 columns' three planes,
+// 6 KB per k-step and wave = 16 bytes per cycle and wave at the pipe's full rate — eight waves ask for the LDS's whole
+// 128 bytes per cycle.  A 64 x 64 wave tile would halve that and needs a 512-pixel patch (117 KB) beside the weight stages.
+template <int CIN, int KT>
+__global__ __launch_bounds__(512, 1) void stem_fwd3_kernel(const StemArgs p) {
+  constexpr int WAVES = 8, NT = WAVES * 64, TILE = WAVES * 32;
+  constexpr int S3_Q = 4;                     // k-steps per weight chunk (24 KB: 3 b128 items per thread)
+  constexpr int S3_CHUNK = S3_Q * S3_STEP_BYTES;
+  constexpr int R = CIN * KT * 7, NS = (R + 1) / 2, NCH = (NS + S3_Q - 1) / S3_Q;
+  constexpr int PIT = 16;                     // float4 patch items per thread
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* Wl = reinterpret_cast<char*>(smem);                 // [2][S3_CHUNK]
+  float* P = smem + 2 * S3_CHUNK / 4;                       // patch (fp32)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 5, l31 = lane & 31;
+  const int npix = p.Ho * p.Wo;
+  const int q4 = p.PW >> 2;
+  const long long item_floats = (long long)CIN * p.Ti * p.Hi * p.Wi;
+
+  struct TileGeo { int frame, to, b, p0, p1, ho_lo, nrows_in; };
+  auto geo = [&](int tile) {
+    TileGeo t;
+    const int tf = tile % p.tiles_per_frame;
+    t.frame = tile / p.tiles_per_frame;
+    t.to = t.frame % p.Ti;
+    t.b = t.frame / p.Ti;
+    t.p0 = tf * TILE;
+    t.p1 = min(t.p0 + TILE, npix);
+    t.ho_lo = t.p0 / p.Wo;
+    t.nrows_in = 2 * ((t.p1 - 1) / p.Wo - t.ho_lo) + 7;
+    return t;
+  };
+  floatx4 pre_p[PIT];
+  const unsigned mgq = 0xffffffffu / (unsigned)q4 + 1u;
+  auto prefetch = [&](const TileGeo& t) {
+    const int total = CIN * KT * t.nrows_in * q4;
+    const unsigned mgn = 0xffffffffu / (unsigned)t.nrows_in + 1u;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (long long)t.b * item_floats), 0, (int)(item_floats * 4), 0x00020000);
+    int t0 = tid;
+    asm volatile("" : "+v"(t0));
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int e = t0 + it * NT;
+      const int r = (int)__umulhi((unsigned)e, mgq), cq = e - r * q4;
+      const int pl = (int)__umulhi((unsigned)r, mgn), row = r - pl * t.nrows_in;
+      const int dt = pl % KT, c = pl / KT;
+      const int ti = t.to + dt - KT / 2, hi = 2 * t.ho_lo - 3 + row, wi = cq * 4 - 4;
+      const bool ok = (e < total) & ((unsigned)ti < (unsigned)p.Ti) & ((unsigned)hi < (unsigned)p.Hi) &
+                      ((unsigned)wi < (unsigned)p.Wi);
+      const unsigned off = (unsigned)(((c * p.Ti + ti) * p.Hi + hi) * p.Wi + wi) * 4u;
+      pre_p[it] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? off : 0xfffffff0u, 0, 0));
+    }
+  };
+  auto commit = [&](const TileGeo& t) {
+    const int total = CIN * KT * t.nrows_in * q4;
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int e = tid + it * NT;
+      if (e < total) *reinterpret_cast<floatx4*>(P + 4 * e) = pre_p[it];
+    }
+  };
+  // weight chunk: S3_CHUNK / 16 = 1536 b128 items -> 3 per thread
+  uintx4_t wv[3];
+  const uintx4_t* Wf = reinterpret_cast<const uintx4_t*>(p.wt);
+  auto load_w = [&](int ch) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wv[i] = Wf[(size_t)ch * (S3_CHUNK / 16) + tid + NT * i];
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<uintx4_t*>(Wl + buf * S3_CHUNK + (tid + NT * i) * 16) = wv[i];
+  };
+
+  int tile = (int)xcd_remap(blockIdx.x, gridDim.x);
+  if (tile >= p.ntiles) return;
+  int u = 0;
+  float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};
+  load_w(0);
+  prefetch(geo(tile));
+  store_w(0);
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const TileGeo t = geo(tile);
+    const int p0 = t.p0, p1 = t.p1, ho_lo = t.ho_lo;
+    __syncthreads();
+    commit(t);
+    __syncthreads();
+    if (tile + (int)gridDim.x < p.ntiles) prefetch(geo(tile + gridDim.x));
+
+    const int pi = p0 + wave * 32 + l31;
+    const bool pok = pi < p1;
+    const int ho = (pok ? pi : p0) / p.Wo, wo = (pok ? pi : p0) - ho * p.Wo;
+    const int pb = (2 * (ho - ho_lo)) * p.PW + 2 * wo + 1 + g;             // tap dw = g + 2 j of row offset 0
+    const float* Pb = P + pb;
+    const int plane = t.nrows_in * p.PW;
+
+    floatx16 acc[2], cor[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; cor[j][r] = 0.f; }
+
+    // (unrolling all NCH chunks — compile-time (plane, row) per k-step instead of 3.5 scalar instructions per matrix
+    //  instruction — was measured slower: 689 us against 661)
+    for (int ch = 0; ch < NCH; ++ch, u ^= 1) {
+      load_w(ch + 1 < NCH ? ch + 1 : 0);
+      const char* Wb = Wl + u * S3_CHUNK + lane * 16;
+#pragma unroll
+      for (int q = 0; q < S3_Q; ++q) {
+        const int s = ch * S3_Q + q;
+        if (s < NS) {
+          // rows 2s, 2s + 1 (the pad row past R reads row R - 1: its weights are zero, its data finite)
+          const int r0 = 2 * s, r1 = (2 * s + 1 < R) ? 2 * s + 1 : R - 1;
+          const int pl0 = r0 / 7, pl1 = r1 / 7;
+          const int o0 = pl0 * plane + (r0 - pl0 * 7) * p.PW, o1 = pl1 * plane + (r1 - pl1 * 7) * p.PW;
+          unsigned h[4], m[4], l[4];
+          const float* A0 = Pb + o0;
+          const float* A1 = Pb + o1;
+          s3_split2(A0[0], A0[2], h[0], m[0], l[0]);
+          s3_split2(A0[4], A0[6], h[1], m[1], l[1]);
+          s3_split2(A1[0], A1[2], h[2], m[2], l[2]);
+          s3_split2(A1[4], A1[6], h[3], m[3], l[3]);
+          const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, uintx4_t{h[0], h[1], h[2], h[3]});
+          const bf16x8_t am = __builtin_bit_cast(bf16x8_t, uintx4_t{m[0], m[1], m[2], m[3]});
+          const bf16x8_t al = __builtin_bit_cast(bf16x8_t, uintx4_t{l[0], l[1], l[2], l[3]});
+          // six products per column tile; the five correction products go to their own accumulators: four independent
+          // accumulation chains per wave (a chain of six back-to-back dependent instructions ran at 2/3 of the pipe's
+          // rate), and the small terms are summed among themselves before they meet the large one
+          bf16x8_t bh[2], bm[2], bl[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const char* bp = Wb + ((q * 2 + j) * 3) * 1024;
+            bh[j] = *reinterpret_cast<const bf16x8_t*>(bp);
+            bm[j] = *reinterpret_cast<const bf16x8_t*>(bp + 1024);
+            bl[j] = *reinterpret_cast<const bf16x8_t*>(bp + 2048);
+          }
+          cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[0], cor[0], 0, 0, 0);
+          cor[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[1], cor[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[0], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[1], acc[1], 0, 0, 0);
+          cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[0], cor[0], 0, 0, 0);
+          cor[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[1], cor[1], 0, 0, 0);
+          cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[0], cor[0], 0, 0, 0);
+          cor[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[1], cor[1], 0, 0, 0);
+          cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[0], cor[0], 0, 0, 0);
+          cor[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[1], cor[1], 0, 0, 0);
+          cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[0], cor[0], 0, 0, 0);
+          cor[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[1], cor[1], 0, 0, 0);
+        }
+      }
+      store_w(u ^ 1);
+      __syncthreads();
+    }
+
+    const long long m_base = (long long)t.frame * npix + p0 + wave * 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (p0 + wave * 32 + rr < p1) {
+          const float v = acc[j][r] + cor[j][r];
+          p.y[(m_base + rr) * 64 + j * 32 + l31] = v;
+          cs[j] += v;
+          cq[j] = fmaf(v, v, cq[j]);
+        }
+      }
+  }
+  if (p.stats) {
+    float* red = smem;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a = cs[j] + __shfl_xor(cs[j], 32, 64), b = cq[j] + __shfl_xor(cq[j], 32, 64);
+      if (g == 0) {
+        red[wave * 64 + j * 32 + l31] = a;
+        red[WAVES * 64 + wave * 64 + j * 32 + l31] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid & 63, q = tid >> 6;
+      float tt = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) tt += red[q * WAVES * 64 + w * 64 + c];
+      p.stats[(long long)blockIdx.x * 128 + q * 64 + c] = tt;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Stem wgrad: dW[n][k'] = sum_pixels dy[pixel][n] * patch(pixel, k').  Persistent workgroups (one per
 // CU) walk tiles of up to 256 pixels (whole output rows), keep the 64 x (R*8) accumulator in registers (each of the 8 waves owns
@@ -570,6 +829,18 @@ static int stem_fwd_tile(const avid_conv_desc* d) {
   if (stem_fwd_lds(d, 256) <= 160 * 1024 && stem_patch_floats(d, 256) <= 16 * 512 * 4) return 256;
   return 0;
 }
+// the bf16x3 forward (stem_fwd3_kernel): the video stem, 256-pixel tiles, patch + two 24 KB weight stages in 160 KB
+// k-steps of the split weights, padded to whole chunks of either kernel shape (4 steps)
+static int stem_fwd3_steps(const avid_conv_desc* d) { return ((d->Cin * d->kt * 7 + 1) / 2 + 3) / 4 * 4; }
+static size_t stem_fwd3_lds(const avid_conv_desc* d) { return 2 * 4 * (size_t)S3_STEP_BYTES + sizeof(float) * stem_patch_floats(d, 256); }
+static bool stem_fwd3_ok(const avid_conv_desc* d) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("AVID_STEM_BF16X3");
+    on = e ? atoi(e) != 0 : 1;
+  }
+  return on && d->Cin == 3 && d->kt == 3 && stem_fwd3_lds(d) <= 160 * 1024 && stem_patch_floats(d, 256) <= 16 * 512 * 4;
+}
 static size_t stem_wgrad_lds(const avid_conv_desc* d) {
   return sizeof(float) * (STEM_TILE * WS_LD + STEM_TILE + stem_patch_floats(d, stem_wgrad_tile_px(d)));
 }
@@ -584,7 +855,11 @@ bool stem_wgrad_supported(const avid_conv_desc* d) {
          d->Wi % 4 == 0 && (long long)d->Cin * d->Ti * d->Hi * d->Wi * 4 < (1ll << 31);
 }
 
-size_t stem_fwd_ws_bytes(const avid_conv_desc* d) { return sizeof(float) * (size_t)d->Cin * d->kt * FK * 64; }
+size_t stem_fwd_ws_bytes(const avid_conv_desc* d) {
+  const size_t fp32_path = sizeof(float) * (size_t)d->Cin * d->kt * FK * 64;
+  const size_t split_path = stem_fwd3_ok(d) ? (size_t)stem_fwd3_steps(d) * S3_STEP_BYTES : 0;
+  return fp32_path > split_path ? fp32_path : split_path;
+}
 int stem_wgrad_groups() { return 256; }
 size_t stem_wgrad_ws_bytes(const avid_conv_desc* d) {
   return sizeof(float) * (size_t)stem_wgrad_groups() * 64 * d->Cin * d->kt * 7 * 8;
@@ -643,8 +918,34 @@ static int stem_wgrad_launch(const avid_conv_desc* d, const float* x, const floa
   return check_launch("stem_wgrad_reduce");
 }
 
+template <int CIN, int KT>
+static int stem_fwd3_launch(const avid_conv_desc* d, const float* x, const float* w, float* y, float* stats, void* ws,
+                            hipStream_t s) {
+  StemArgs a{};
+  stem_geometry(d, a, 256);
+  a.x = x; a.w = w; a.y = y; a.wt = static_cast<float*>(ws); a.stats = stats;
+  hipLaunchKernelGGL((stem_split_weights_kernel<CIN, KT>), dim3(stem_fwd3_steps(d) * 2), dim3(64), 0, s, w, static_cast<uintx4_t*>(ws));
+  static bool set = false;
+  if (!set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd3_kernel<CIN, KT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    set = true;
+  }
+  const double M = (double)d->B * d->To * d->Ho * d->Wo, K = (double)CIN * KT * 49;
+  ScopedTimer t(s, "stem_fwd3_kernel<3,3>", 2.0 * M * 64 * K,
+                4.0 * ((double)d->B * CIN * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
+  const int grid = a.ntiles < 256 ? a.ntiles : 256;
+  hipLaunchKernelGGL((stem_fwd3_kernel<CIN, KT>), dim3(grid), dim3(512), stem_fwd3_lds(d), s, a);
+  return check_launch("stem_fwd3");
+}
+
 // workgroups of the forward launch == rows of its BatchNorm partial sums
 int stem_fwd_grid(const avid_conv_desc* d) {
+  if (stem_fwd3_ok(d)) {
+    StemArgs a{};
+    stem_geometry(d, a, 256);
+    return a.ntiles < 256 ? a.ntiles : 256;
+  }
   const int tile = stem_fwd_tile(d);
   if (!tile) return 0;
   StemArgs a{};
@@ -653,7 +954,10 @@ int stem_fwd_grid(const avid_conv_desc* d) {
   return a.ntiles < slots ? a.ntiles : slots;
 }
 
+bool stem_fwd_is_split(const avid_conv_desc* d) { return stem_fwd_supported(d) && stem_fwd3_ok(d); }
+
 int stem_fwd(const avid_conv_desc* d, const float* x, const float* w, float* y, float* stats, void* ws, hipStream_t s) {
+  if (stem_fwd3_ok(d)) return stem_fwd3_launch<3, 3>(d, x, w, y, stats, ws, s);
   if (stem_fwd_tile(d) == 128)
     return d->Cin == 3 ? stem_fwd_launch<3, 3, 4>(d, x, w, y, stats, ws, s) : stem_fwd_launch<1, 1, 4>(d, x, w, y, stats, ws, s);
   return d->Cin == 3 ? stem_fwd_launch<3, 3, 8>(d, x, w, y, stats, ws, s) : stem_fwd_launch<1, 1, 8>(d, x, w, y, stats, ws, s);

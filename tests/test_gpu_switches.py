@@ -34,7 +34,7 @@ IDENTICAL = [{"AVID_PLAN": "0"}, {"AVID_OVERLAP_TOWERS": "0"}, {"AVID_DEFER_WGRA
              {"AVID_HIP_LIB": os.path.join(os.path.dirname(HERE), "avid-cma_amd", "avid_hip", "libavid_hip.so")}]
 CLOSE = [{"AVID_GROUP_WGRAD": "0"}, {"AVID_FUSE_BN_BWD": "0"}, {"AVID_FUSE_BN_STATS": "0"}, {"AVID_FUSE_RES": "0"},
          {"AVID_FUSE_STEM_TAIL": "0"}, {"AVID_FUSED_CRITERION": "0"}, {"AVID_WINO": "0"}, {"AVID_WINO_WGRAD": "0"},
-         {"AVID_TRIM_TAPS": "0"}]
+         {"AVID_TRIM_TAPS": "0"}, {"AVID_STEM_BF16X3": "0"}]
 
 
 @pytest.mark.parametrize("env", IDENTICAL, ids=lambda e: ",".join(f"{k}={v if len(v) < 9 else '...'}" for k, v in e.items()))
