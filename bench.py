@@ -38,6 +38,58 @@ PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 6
 PEAK_HBM_GBS = 8000.0
 
 
+class ClockSampler:
+    """Mean shader clock (GHz) over an interval, read from /sys/class/drm/card*/device/pp_dpm_sclk (the level marked '*')
+    by a host thread; None where the node does not exist or does not change."""
+
+    def __init__(self, index):
+        import glob
+        import threading
+        nodes = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = None
+        try:                    # the card whose PCI address is this device's
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for n in nodes:
+                if want in os.path.realpath(os.path.dirname(n)):
+                    self.path = n
+        except Exception:       # noqa: BLE001
+            pass
+        if self.path is None and len(nodes) == 1:
+            self.path = nodes[0]
+        self.samples, self.run, self.thread = [], False, None
+        self._threading = threading
+
+    def _read(self):
+        try:
+            for line in open(self.path):
+                if "*" in line:
+                    return float(line.split(":")[1].strip().lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:       # noqa: BLE001
+            return None
+        return None
+
+    def _loop(self):
+        while self.run:
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            time.sleep(0.002)
+
+    def start(self):
+        if self.path is None:
+            return
+        self.run = True
+        self.thread = self._threading.Thread(target=self._loop, daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        self.run = False
+        if self.thread is not None:
+            self.thread.join()
+        return round(sum(self.samples) / len(self.samples) / 1e3, 3) if self.samples else None
+
+
 def csrc_digest():
     """sha256 over the kernel sources (avid-cma_amd/csrc/*.hip, common.h, include/avid_hip.h): what profiles/pmc_traffic.json
     is stamped with when tools/pmc_traffic.py writes it (there is no git on the GPU box)."""
@@ -357,20 +409,11 @@ def main():
         engine.capture(video, audio, ids[0])
         engine.replay(index=ids[0])
     sync()
-    # the shader clock DURING the timed region: one wave on the (idle at N = 1) collectives' stream spins beside the steps and
-    # counts shader cycles against the constant 100 MHz clock (avid_clock_probe) — the 157.3 TFLOP/s peak assumes 2.4 GHz
-    import ctypes as _C
-    from avid_hip import streams as _streams
-    clock_out = torch.zeros(2, dtype=torch.int64, device=dev)
-    probe_us = None
-    if not use_dist:
-        t0 = time.perf_counter()
-        for i in range(3):
-            engine.step(video, audio, ids[args.warmup + i])
-        torch.cuda.synchronize()
-        probe_us = int(0.85 * (time.perf_counter() - t0) / 3 * args.steps * 1e6)
-        lib.call("avid_clock_probe", max(1000, min(probe_us, 1900000)), _C.c_void_p(clock_out.data_ptr()),
-                 _C.c_void_p(_streams.place(dev).comm.cuda_stream))
+    # the shader clock DURING the timed region, sampled by a host thread from the driver's sysfs node every 2 ms (a probe
+    # wave spinning beside the steps was tried first: it takes one CU's registers, and a persistent kernel that cannot place
+    # one of its workgroups pays a whole extra round — 11.3 -> 12.0 ms per step)
+    sampler = ClockSampler(local_rank)
+    sampler.start()
     t0 = time.perf_counter()
     loss = None
     for i in range(args.steps):
@@ -380,6 +423,7 @@ def main():
             loss = engine.step(video, audio, ids[args.warmup + i])
     sync()
     dt = time.perf_counter() - t0
+    clock_ghz = sampler.stop()
     # host issue time: how long the host needs to ENQUEUE a step (5 steps issued back to back, nothing waited for) —
     # the margin between it and ms_per_step is what a slower host may eat before the GPU starves
     t0 = time.perf_counter()
@@ -408,9 +452,6 @@ def main():
                           "bucket_count": len(engine.buckets.bounds),
                           "gradient_bytes": int(engine.flat.numel * 4)})
     loss_val = float(loss)
-    torch.cuda.synchronize()
-    co = clock_out.tolist()
-    clock_ghz = round(co[0] / co[1] / 10.0, 3) if co[1] > 0 else None
     from avid_hip import streams as _streams
     stream_report = _streams.report(dev)
 
