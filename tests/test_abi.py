@@ -57,3 +57,28 @@ def test_ops_refuse_cpu_tensors():
         ops.conv_cl(x, w, (1, 1, 1), (0, 1, 1))
     with pytest.raises(AvidHipError):
         ops.l2_normalize(torch.zeros(2, 128))
+
+
+def test_program_executor_rejects_malformed_programs():
+    """avid_program_run validates a program before it launches anything (no GPU needed): null arguments, an unknown record
+    kind, a stream index outside the run's table — negative return code, message naming the record."""
+    import ctypes as C
+    from avid_hip import lib
+    prog = (lib.Instr * 2)()
+    slots = (C.c_void_p * 4)()
+    streams = (C.c_void_p * 2)()
+    ws = (lib.StreamWs * 2)()
+    run = lib.raw("avid_program_run")
+    assert run(None, 0, 1, slots, 4, streams, ws, 2) < 0
+    assert run(prog, 0, 1, slots, 4, streams, ws, 0) < 0
+    prog[0].op = 99
+    assert run(prog, 0, 1, slots, 4, streams, ws, 2) < 0 and "record 0" in lib.last_error()
+    prog[0].op, prog[0].stream = 15, 7                     # a column sum on stream 7 of 2
+    assert run(prog, 0, 1, slots, 4, streams, ws, 2) < 0 and "stream 7" in lib.last_error()
+    prog[0].op = 1                                         # a wait between streams 0 and 5 of 2
+    prog[0].i[0], prog[0].i[1] = 0, 5
+    assert run(prog, 0, 1, slots, 4, streams, ws, 2) < 0 and "wait" in lib.last_error()
+    prog[0].op = 0                                         # nop records run to the end
+    assert run(prog, 0, 2, slots, 4, streams, ws, 2) == 0
+    need = (C.c_size_t * 2)()
+    assert lib.raw("avid_program_workspace_bytes")(prog, 0, 2, 2, need) == 0 and list(need) == [0, 0]
