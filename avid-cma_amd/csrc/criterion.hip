@@ -372,24 +372,46 @@ struct XModalArgs {
   float inv_T, coeff;
 };
 
+// Lane layout (round 4): SIXTEEN lanes per bank row (8 consecutive floats each: two 16-byte loads per row and bank), four
+// rows per wave at a time — a row's dot product is a 4-step reduction inside its lane group instead of a 6-step one over
+// the wave, the exp / log / divide chain of four rows runs in parallel lanes, and a wave issues 64 16-byte loads instead of
+// 64 4-byte ones for the same 16 rows (29.3 -> see DESIGN 3.6).
 __global__ __launch_bounds__(256) void xmodal_fused_kernel(const XModalArgs p) {
-  constexpr int D = 128, RPW = SC_ROWS_PER_BLOCK / 4;
+  constexpr int D = 128, RPW = SC_ROWS_PER_BLOCK / 4, NU = RPW / 4;
   __shared__ float sh_g[4][2][D];
   __shared__ double sh_l[4][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 15, grp = lane >> 4;
   const int b = blockIdx.y, split = blockIdx.x, R = p.K + 1;
-  // normalised embeddings (every wave computes them: 2 floats per lane)
-  float ev[2], ea[2], nv, na;
+  auto group_sum = [](float v) {                       // over the 16 lanes of a row group
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    return v;
+  };
+  // normalised embeddings: this lane's 8 components (every lane group computes the norms)
+  float ev[8], ea[8], nv, na;
   {
-    const float v0 = p.v_emb[(long long)b * D + lane], v1 = p.v_emb[(long long)b * D + 64 + lane];
-    const float a0 = p.a_emb[(long long)b * D + lane], a1 = p.a_emb[(long long)b * D + 64 + lane];
-    nv = fmaxf(sqrtf(wave_sum(v0 * v0 + v1 * v1)), 1e-12f);
-    na = fmaxf(sqrtf(wave_sum(a0 * a0 + a1 * a1)), 1e-12f);
-    ev[0] = v0 / nv; ev[1] = v1 / nv; ea[0] = a0 / na; ea[1] = a1 / na;
-    if (split == 0 && wave == 0) {
-      p.v_hat[(long long)b * D + lane] = ev[0]; p.v_hat[(long long)b * D + 64 + lane] = ev[1];
-      p.a_hat[(long long)b * D + lane] = ea[0]; p.a_hat[(long long)b * D + 64 + lane] = ea[1];
-      if (lane == 0) { p.norms[b] = nv; p.norms[p.bs + b] = na; }
+    const floatx4 v0 = *reinterpret_cast<const floatx4*>(p.v_emb + (long long)b * D + sub * 8);
+    const floatx4 v1 = *reinterpret_cast<const floatx4*>(p.v_emb + (long long)b * D + sub * 8 + 4);
+    const floatx4 a0 = *reinterpret_cast<const floatx4*>(p.a_emb + (long long)b * D + sub * 8);
+    const floatx4 a1 = *reinterpret_cast<const floatx4*>(p.a_emb + (long long)b * D + sub * 8 + 4);
+    float sv = 0.f, sa = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ev[k] = v0[k]; ev[4 + k] = v1[k]; ea[k] = a0[k]; ea[4 + k] = a1[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sv = fmaf(ev[k], ev[k], sv); sa = fmaf(ea[k], ea[k], sa); }
+    nv = fmaxf(sqrtf(group_sum(sv)), 1e-12f);
+    na = fmaxf(sqrtf(group_sum(sa)), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ev[k] /= nv; ea[k] /= na; }
+    if (split == 0 && wave == 0 && grp == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        p.v_hat[(long long)b * D + sub * 8 + k] = ev[k];
+        p.a_hat[(long long)b * D + sub * 8 + k] = ea[k];
+      }
+      if (sub == 0) { p.norms[b] = nv; p.norms[p.bs + b] = na; }
     }
   }
   const float KZ = (float)p.K * p.Z[0];
@@ -404,38 +426,59 @@ __global__ __launch_bounds__(256) void xmodal_fused_kernel(const XModalArgs p) {
       mine = mine < 0 ? 0 : p.N - 1;
     }
   }
-  float ra[RPW][2], rv[RPW][2];          // audio-bank rows (scored against the video embedding) and video-bank rows
+  floatx4 ra[NU][2], rv[NU][2];          // audio-bank rows (scored against the video embedding) and video-bank rows
 #pragma unroll
-  for (int u = 0; u < RPW; ++u) {
-    const long long row = __shfl(mine, u, 64);
-    const float* pa = p.bank_a + row * D;
-    const float* pv = p.bank_v + row * D;
-    ra[u][0] = pa[lane]; ra[u][1] = pa[64 + lane];
-    rv[u][0] = pv[lane]; rv[u][1] = pv[64 + lane];
+  for (int u = 0; u < NU; ++u) {
+    const long long row = __shfl(mine, u * 4 + grp, 64);
+    const float* pa = p.bank_a + row * D + sub * 8;
+    const float* pv = p.bank_v + row * D + sub * 8;
+    ra[u][0] = *reinterpret_cast<const floatx4*>(pa); ra[u][1] = *reinterpret_cast<const floatx4*>(pa + 4);
+    rv[u][0] = *reinterpret_cast<const floatx4*>(pv); rv[u][1] = *reinterpret_cast<const floatx4*>(pv + 4);
   }
-  float gv[2] = {0.f, 0.f}, ga[2] = {0.f, 0.f};      // d L_v2a / d v_hat, d L_a2v / d a_hat (x T, unscaled)
+  float gv[8], ga[8];                    // d L_v2a / d v_hat, d L_a2v / d a_hat (x T, unscaled): this group's rows
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gv[k] = ga[k] = 0.f;
   double lv = 0, la = 0;
 #pragma unroll
-  for (int u = 0; u < RPW; ++u) {
-    const int j = jw + u;
-    const float s1 = wave_sum(ra[u][0] * ev[0] + ra[u][1] * ev[1]) * p.inv_T;     // v2a: video embedding . audio bank
-    const float s2 = wave_sum(rv[u][0] * ea[0] + rv[u][1] * ea[1]) * p.inv_T;     // a2v
+  for (int u = 0; u < NU; ++u) {
+    const int j = jw + u * 4 + grp;
+    float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      d1 = fmaf(ra[u][0][k], ev[k], d1); d1 = fmaf(ra[u][1][k], ev[4 + k], d1);
+      d2 = fmaf(rv[u][0][k], ea[k], d2); d2 = fmaf(rv[u][1][k], ea[4 + k], d2);
+    }
+    const float s1 = group_sum(d1) * p.inv_T;     // v2a: video embedding . audio bank
+    const float s2 = group_sum(d2) * p.inv_T;     // a2v
     if (j < j1) {
       const float e1 = expf(s1), e2 = expf(s2);
       float g1, g2;
       if (j == 0) {            // -log(e / (e + KZ));  d / ds = -KZ / (e + KZ)
-        lv += (double)(-logf(e1 / (e1 + KZ))); la += (double)(-logf(e2 / (e2 + KZ)));
+        if (sub == 0) { lv += (double)(-logf(e1 / (e1 + KZ))); la += (double)(-logf(e2 / (e2 + KZ))); }
         g1 = -(KZ / (e1 + KZ)); g2 = -(KZ / (e2 + KZ));
       } else {                 // -log(KZ / (e + KZ));  d / ds = e / (e + KZ)
-        lv += (double)(-logf(KZ / (e1 + KZ))); la += (double)(-logf(KZ / (e2 + KZ)));
+        if (sub == 0) { lv += (double)(-logf(KZ / (e1 + KZ))); la += (double)(-logf(KZ / (e2 + KZ))); }
         g1 = e1 / (e1 + KZ); g2 = e2 / (e2 + KZ);
       }
-      gv[0] = fmaf(g1, ra[u][0], gv[0]); gv[1] = fmaf(g1, ra[u][1], gv[1]);
-      ga[0] = fmaf(g2, rv[u][0], ga[0]); ga[1] = fmaf(g2, rv[u][1], ga[1]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        gv[k] = fmaf(g1, ra[u][0][k], gv[k]); gv[4 + k] = fmaf(g1, ra[u][1][k], gv[4 + k]);
+        ga[k] = fmaf(g2, rv[u][0][k], ga[k]); ga[4 + k] = fmaf(g2, rv[u][1][k], ga[4 + k]);
+      }
     }
   }
-  sh_g[wave][0][lane] = gv[0]; sh_g[wave][0][64 + lane] = gv[1];
-  sh_g[wave][1][lane] = ga[0]; sh_g[wave][1][64 + lane] = ga[1];
+  // fold the four row groups of the wave (fixed order: (g0 + g1) + (g2 + g3)), then the four waves through LDS
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    gv[k] += __shfl_xor(gv[k], 16, 64); gv[k] += __shfl_xor(gv[k], 32, 64);
+    ga[k] += __shfl_xor(ga[k], 16, 64); ga[k] += __shfl_xor(ga[k], 32, 64);
+  }
+  lv += __shfl_xor(lv, 16, 64); lv += __shfl_xor(lv, 32, 64);
+  la += __shfl_xor(la, 16, 64); la += __shfl_xor(la, 32, 64);
+  if (grp == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sh_g[wave][0][sub * 8 + k] = gv[k]; sh_g[wave][1][sub * 8 + k] = ga[k]; }
+  }
   if (lane == 0) { sh_l[wave][0] = lv; sh_l[wave][1] = la; }
   __syncthreads();
   float* pg = p.part_g + ((long long)b * p.S + split) * 2 * D;
