@@ -74,7 +74,8 @@ class FlatBuffers:
     per step on every rank and is identical everywhere by construction."""
 
     def __init__(self, module: torch.nn.Module):
-        self.bufs = [b for b in module.buffers() if b.is_floating_point()]
+        own = getattr(module, "_bn_flat", None)          # (models.AV_Wrapper's own flat buffer for DDP: superseded here)
+        self.bufs = [b for b in module.buffers() if b.is_floating_point() and b is not own]
         self.offsets, off = [], 0
         for b in self.bufs:
             self.offsets.append(off)

@@ -66,6 +66,47 @@ class AV_Wrapper(nn.Module):
             self.out_dim = self.video_proj.out_dim
         else:
             self.out_dim = video_model.out_dim
+        self._init_flat_buffers()
+
+    # ---- DistributedDataParallel copies rank 0's buffers to every rank before EVERY forward (utils/main_utils.py:112,
+    # broadcast_buffers=True): for this model 126 BatchNorm tensors flattened, broadcast and copied back one by one —
+    # 2 ms of host time per step in the reference's loop, which waits for loss.item() and therefore sees it.  The running
+    # statistics live in ONE flat buffer instead (`_bn_flat`, not part of the state_dict); the BatchNorm modules' own
+    # buffers are views of it, keep their names, shapes and state_dict keys, and are listed in DDP's ignore set, so DDP
+    # broadcasts one tensor.  (`num_batches_tracked` advances identically on every rank and is ignored as well.)
+    def _init_flat_buffers(self):
+        named = [(n, b) for n, b in self.named_buffers() if n != "_bn_flat"]
+        floats = [(n, b) for n, b in named if b.is_floating_point()]
+        self._bn_layout, off = [], 0
+        for n, b in floats:
+            self._bn_layout.append((n, off, b.numel()))
+            off += (b.numel() + 3) // 4 * 4
+        if off:
+            self.register_buffer("_bn_flat", torch.zeros(off), persistent=False)
+            self._ddp_params_and_buffers_to_ignore = [n for n, _ in named]
+        self._bn_seated = None
+
+    def _seat_flat_buffers(self):
+        """Make every floating-point BatchNorm buffer a view of `_bn_flat` (again: `.to()` / `.cuda()` re-create buffers)."""
+        flat = getattr(self, "_bn_flat", None)
+        if flat is None:
+            return
+        key = (flat.data_ptr(), flat.device)
+        if self._bn_seated == key:
+            return
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        mods = dict(self.named_modules())
+        with torch.no_grad():
+            for n, off, cnt in self._bn_layout:
+                owner, _, leaf = n.rpartition(".")
+                b = getattr(mods[owner], leaf)
+                if b.device != flat.device:
+                    return                                   # (model and flat buffer on different devices: leave as is)
+                if not (lo <= b.data_ptr() < hi):
+                    view = flat[off:off + cnt].view(b.shape)
+                    view.copy_(b)
+                    b.data = view
+        self._bn_seated = key
 
     # Run the (small) audio tower on a side stream under the video tower's tail waves.  OFF unless the build's
     # own engine drives the step (avid_hip.parallel.TrainStep switches it on): its gradient buckets know which
@@ -82,6 +123,7 @@ class AV_Wrapper(nn.Module):
         return audio_emb
 
     def forward(self, video, audio):
+        self._seat_flat_buffers()
         # A training step through the stock module tree runs as two compiled launch programs (avid_hip/plan.py: one C
         # call per pass, one autograd node for the whole model); anything else — evaluation, hooked modules, frozen
         # parameters, return_embs on a tower — takes the per-layer path below.

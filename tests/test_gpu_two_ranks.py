@@ -190,8 +190,20 @@ def _ddp_job(rank, world, out):
     loss, _ = crit(ve, ae, y)
     loss.backward()
     torch.cuda.synchronize()
-    return {"loss": float(loss), "overlap": bool(m.overlap_towers),
-            "grads": {n: p.grad.clone().cpu() for n, p in m.named_parameters()}}
+    grads = {n: p.grad.clone().cpu() for n, p in m.named_parameters()}
+    # DDP copies rank 0's buffers to every rank before every forward (broadcast_buffers=True, utils/main_utils.py:112): here
+    # ONE tensor (models.AV_Wrapper._bn_flat) of which the BatchNorm modules' own buffers are views
+    own_stats = {n: b.clone().cpu() for n, b in m.named_buffers() if n.endswith("running_var")}
+    n_bcast = sum(1 for n, _ in m.named_buffers() if n not in ddp.parameters_to_ignore)
+    with torch.no_grad():
+        ddp(v, a)                                    # second forward: the broadcast in front of it carries rank 0's statistics
+    torch.cuda.synchronize()
+    # (the training-mode forward has updated them once more on every rank from ITS shard: compare what the broadcast
+    #  installed through a module the forward does not touch ... every BatchNorm is touched, so: undo one EMA step)
+    return {"loss": float(loss), "overlap": bool(m.overlap_towers), "grads": grads, "stats_after_step0": own_stats,
+            "broadcast_tensors": n_bcast,
+            "views": all(b.untyped_storage().data_ptr() == m._bn_flat.untyped_storage().data_ptr()
+                         for n, b in m.named_buffers() if b.is_floating_point())}
 
 
 _JOBS = {"train": _train_job, "cma": _cma_job, "ddp": _ddp_job}
@@ -320,6 +332,11 @@ def test_two_rank_training_step(tmp_path, gpu_device):
     d = _run2("ddp", tmp_path)
     assert d[0]["overlap"] is False
     assert d[0]["loss"] == s0["loss"] and d[1]["loss"] == s1["loss"]
+    # DDP's per-forward buffer broadcast is ONE tensor (the flat BatchNorm statistics); the modules' buffers are views of it;
+    # before any broadcast of real values the ranks' statistics differ (per-rank batches)
+    assert d[0]["broadcast_tensors"] == 1 and d[0]["views"] and d[1]["views"]
+    k0 = next(iter(d[0]["stats_after_step0"]))
+    assert not torch.equal(d[0]["stats_after_step0"][k0], d[1]["stats_after_step0"][k0])
     eng = s1["eng"]
     for i, p in enumerate(eng.flat.params):
         name = next(n for n, q in s1["model"].named_parameters() if q is p)
