@@ -750,6 +750,197 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the video stem's weight gradient as fp32-accurate split-bf16 products (as stem_fwd3_kernel).
+// Same tiles (whole output rows), patch / dy prefetch, two-role wave layout, partial slabs and reduce as stem_wgrad_kernel;
+// the contraction runs over 16 pixels per k-step:
+//   A[i = n][k = pixel]  : lane (n, g = lane >> 5) reads dy of 8 consecutive pixels p0 + 8 g + e of its channel
+//   B[k = pixel][j = k'] : lane (k', g) reads the patch at pixbase[p0 + 8 g] + 2 e + koff(k') — a group of 8 pixels lies in
+//                          one output row (8 | Wo, whole-row tiles), so one table entry serves the group;
+// both fragments are split in registers (44 VALU each) and feed six matrix instructions per (n-tile, k'-tile).
+// dy rows are stored with their 32-column halves swapped on every second GROUP of 8 pixels (the two half-waves read groups
+// 8 pixels apart: disjoint banks).
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int KT>
+__global__ __launch_bounds__(512, 1) void stem_wgrad3_kernel(const StemArgs p) {
+  constexpr int KP = (CIN * KT * 49 + 31) / 32 * 32;   // k' columns of a slab (dense layout)
+  constexpr int NKT_ALL = KP / 32, NKT = 3;
+  static_assert(NKT_ALL == 14, "the two-role split is laid out for 14 k' tiles");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ds = smem;                               // [256][WS_LD]
+  int* pixbase = reinterpret_cast<int*>(smem + STEM_TILE * WS_LD);   // [256]
+  float* P = smem + STEM_TILE * WS_LD + STEM_TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 5, l31 = lane & 31;
+  const int npix = p.Ho * p.Wo;
+  const bool big = wave < 4;                      // role (wave-uniform): 2 n-tiles x 2 k'-tiles, or 1 n-tile x 3 k'-tiles
+  const int nb = big ? 2 : 3;
+  const int nsel = big ? 0 : ((wave - 4) & 1);
+  auto tile_of = [&](int j) { return big ? 2 * wave + j : 8 + 3 * ((wave - 4) >> 1) + j; };
+  int koff[NKT];
+  bool kok[NKT];
+#pragma unroll
+  for (int j = 0; j < NKT; ++j) {
+    const int kp = tile_of(j) * 32 + l31;
+    kok[j] = j < nb && kp < CIN * KT * 49;
+    koff[j] = 0;
+  }
+  floatx16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  constexpr int PIT = 11;
+  floatx4 pre_p[PIT], pre_d[STEM_TILE * 16 / 512];
+  struct TileGeo { int frame, to, b, p0, p1, ho_lo, nrows_in; };
+  auto geo = [&](int tile) {
+    TileGeo t;
+    const int tf = tile % p.tiles_per_frame;
+    t.frame = tile / p.tiles_per_frame;
+    t.to = t.frame % p.Ti;
+    t.b = t.frame / p.Ti;
+    t.p0 = tf * p.tile_px;
+    t.p1 = min(t.p0 + p.tile_px, npix);
+    t.ho_lo = t.p0 / p.Wo;
+    t.nrows_in = 2 * ((t.p1 - 1) / p.Wo - t.ho_lo) + 7;
+    return t;
+  };
+  const int q4 = p.PW >> 2;
+  const long long item_floats = (long long)CIN * p.Ti * p.Hi * p.Wi;
+  auto prefetch = [&](const TileGeo& t) {
+    const int total = CIN * KT * t.nrows_in * q4;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (long long)t.b * item_floats), 0, (int)(item_floats * 4), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int e = tid + it * 512;
+      const int r = e / q4, cq = e - r * q4;
+      const int pl = r / t.nrows_in, row = r - pl * t.nrows_in;
+      const int dt = pl % KT, c = pl / KT;
+      const int ti = t.to + dt - KT / 2, hi = 2 * t.ho_lo - 3 + row, wi = cq * 4 - 4;
+      const bool ok = (e < total) & ((unsigned)ti < (unsigned)p.Ti) & ((unsigned)hi < (unsigned)p.Hi) &
+                      ((unsigned)wi < (unsigned)p.Wi);
+      const unsigned off = (unsigned)(((c * p.Ti + ti) * p.Hi + hi) * p.Wi + wi) * 4u;
+      pre_p[it] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? off : 0xfffffff0u, 0, 0));
+    }
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.dy + ((long long)t.frame * npix + t.p0) * 64), 0, (t.p1 - t.p0) * 256, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < STEM_TILE * 16 / 512; ++it) {
+      const int e = tid + it * 512;
+      pre_d[it] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsD, (unsigned)e * 16u, 0, 0));
+    }
+  };
+  auto commit = [&](const TileGeo& t) {
+    const int total = CIN * KT * t.nrows_in * q4;
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int e = tid + it * 512;
+      if (e < total) *reinterpret_cast<floatx4*>(P + 4 * e) = pre_p[it];
+    }
+#pragma unroll
+    for (int it = 0; it < STEM_TILE * 16 / 512; ++it) {
+      const int e = tid + it * 512;                  // pixel e >> 4, columns 4 (e & 15) ..: halves swapped on odd pixel groups
+      *reinterpret_cast<floatx4*>(&Ds[(e >> 4) * WS_LD + (((e & 15) * 4) ^ (((e >> 7) & 1) << 5))]) = pre_d[it];
+    }
+  };
+
+  const int tile0 = (int)xcd_remap(blockIdx.x, gridDim.x);
+  if (tile0 < p.ntiles) prefetch(geo(tile0));
+  for (int tile = tile0; tile < p.ntiles; tile += gridDim.x) {
+    const TileGeo t = geo(tile);
+    const int p0 = t.p0, p1 = t.p1, ho_lo = t.ho_lo;
+    const int plane = t.nrows_in * p.PW;
+    __syncthreads();
+    commit(t);
+    if (tid < STEM_TILE) {
+      const int pi = min(p0 + tid, p1 - 1);
+      const int ho = pi / p.Wo, wo = pi - ho * p.Wo;
+      pixbase[tid] = (2 * (ho - ho_lo)) * p.PW + 2 * wo + 1;
+    }
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      const int kp = tile_of(j) * 32 + l31;
+      const int pl = kp / 49, f = kp - pl * 49, dh = f / 7, dw = f - dh * 7;
+      koff[j] = kok[j] ? pl * plane + dh * p.PW + dw : 0;
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < p.ntiles) prefetch(geo(tile + gridDim.x));
+    const int nsteps = p.tile_px / 16;             // (the host admits only tiles of whole 16-pixel steps)
+    // this lane's dy column for n-tile 0 / 1 (its own n-tile for a small wave), pixel group g of the step
+    const int colA0 = (big ? 0 : 32 * nsel) + l31, colA1 = 32 + l31;
+    auto frag3 = [&](const float (&v)[8], bf16x8_t& fh, bf16x8_t& fm, bf16x8_t& fl) {
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s3_split2(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+      fh = __builtin_bit_cast(bf16x8_t, uintx4_t{h[0], h[1], h[2], h[3]});
+      fm = __builtin_bit_cast(bf16x8_t, uintx4_t{m[0], m[1], m[2], m[3]});
+      fl = __builtin_bit_cast(bf16x8_t, uintx4_t{l[0], l[1], l[2], l[3]});
+    };
+    auto six = [&](floatx16& c, const bf16x8_t& ah, const bf16x8_t& am, const bf16x8_t& al, const bf16x8_t& bh,
+                   const bf16x8_t& bm, const bf16x8_t& bl) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    };
+    auto kloop = [&](auto BIG) {
+      constexpr bool B_ = decltype(BIG)::value;
+      constexpr int NBv = B_ ? 2 : 3;
+      for (int s = 0; s < nsteps; ++s) {
+        const int px = 16 * s + 8 * g;               // first pixel of this half-wave's group
+        const int swz = (px >> 3 & 1) << 5;          // the group's column swizzle
+        const float* dr = Ds + px * WS_LD;
+        float va[2][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          va[0][e] = dr[e * WS_LD + (colA0 ^ swz)];
+          if (B_) va[1][e] = dr[e * WS_LD + (colA1 ^ swz)];
+        }
+        const int pb = pixbase[px];
+        bf16x8_t ah[2], am[2], al[2];
+        frag3(va[0], ah[0], am[0], al[0]);
+        if (B_) frag3(va[1], ah[1], am[1], al[1]);
+#pragma unroll
+        for (int j = 0; j < NBv; ++j) {
+          float vb[8];
+          const float* pp = P + pb + koff[j];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vb[e] = pp[2 * e];
+          bf16x8_t bh, bm, bl;
+          frag3(vb, bh, bm, bl);
+          if (B_) {
+            six(acc[j], ah[0], am[0], al[0], bh, bm, bl);
+            six(acc[NBv + j], ah[1], am[1], al[1], bh, bm, bl);
+          } else {
+            six(acc[j], ah[0], am[0], al[0], bh, bm, bl);
+          }
+        }
+      }
+    };
+    if (big) kloop(std::true_type{}); else kloop(std::false_type{});
+  }
+  // partial slab [blockIdx.x][n][k']   (accumulator tile a: big wave -> n-tile a / 2, k' tile a % 2; small -> nsel, a)
+  float* o = p.part + (long long)blockIdx.x * 64 * KP;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int t = big ? a / 2 : nsel, j = big ? a % 2 : a;
+    if (!big && a >= 3) continue;
+    const int kp = tile_of(j) * 32 + l31;
+    if (kp < KP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        o[(long long)n * KP + kp] = acc[a][r];
+      }
+    }
+  }
+}
+
 // dw[n][dt][dh][dw][c] = sum_g part[g][n][k'(c,dt,dh,dw)] — block = 32 elements x 8 slices of the G partials,
 // 4 independent streams per thread (a single chain of G = 256 loads per thread took 111 us); fixed order.
 template <int CIN, int KT, bool DENSE>
@@ -889,6 +1080,17 @@ static int stem_fwd_launch(const avid_conv_desc* d, const float* x, const float*
   return check_launch("stem_fwd");
 }
 
+// the bf16x3 weight gradient (stem_wgrad3_kernel): the video stem, tiles of whole 16-pixel steps in whole output rows
+static bool stem_wgrad3_ok(const avid_conv_desc* d) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("AVID_STEM_BF16X3");
+    on = e ? atoi(e) != 0 : 1;
+  }
+  const int tile = stem_wgrad_tile_px(d);
+  return on && d->Cin == 3 && d->kt == 3 && d->Wo % 8 == 0 && tile % d->Wo == 0 && tile % 16 == 0 && (d->Ho * d->Wo) % tile == 0;
+}
+
 template <int CIN, int KT>
 static int stem_wgrad_launch(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,
                              hipStream_t s) {
@@ -898,6 +1100,26 @@ static int stem_wgrad_launch(const avid_conv_desc* d, const float* x, const floa
   int G = stem_wgrad_groups();
   if (G > a.ntiles) G = a.ntiles;
   const size_t lds = stem_wgrad_lds(d);
+  if (CIN == 3 && stem_wgrad3_ok(d)) {
+    static bool set3 = false;
+    if (!set3) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad3_kernel<3, 3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      set3 = true;
+    }
+    const double M = (double)d->B * d->To * d->Ho * d->Wo, K = 3.0 * 3 * 49;
+    {
+      ScopedTimer t(s, "stem_wgrad3_kernel<3,3>", 2.0 * M * 64 * K,
+                    4.0 * ((double)d->B * 3 * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
+      hipLaunchKernelGGL((stem_wgrad3_kernel<3, 3>), dim3(G), dim3(512), lds, s, a);
+    }
+    int rc3 = check_launch("stem_wgrad3");
+    if (rc3) return rc3;
+    const int n3 = 64 * 3 * 3 * 49;
+    hipLaunchKernelGGL((stem_wgrad_reduce_kernel<3, 3, true>), dim3((n3 + 31) / 32), dim3(256), 0, s,
+                       static_cast<const float*>(ws), dw, G);
+    return check_launch("stem_wgrad_reduce");
+  }
   static bool set = false;
   if (!set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad_kernel<CIN, KT, (CIN * KT * 49 > 64)>),

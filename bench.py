@@ -489,9 +489,10 @@ def main():
             "value": round(clips, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            # fp32 end to end; the video stem's forward assembles its fp32 products from six bf16 MFMAs with fp32
-            # accumulation (operands split into three bf16 terms: error vs fp64 BELOW the fp32 instruction's)
-            "dtype": "f32 (video stem forward: bf16x3 MFMA)" if any(k.startswith("stem_fwd3") for k in kern) else "f32",
+            # fp32 end to end; the video stem (forward and weight gradient) assembles its fp32 products from six bf16 MFMAs
+            # with fp32 accumulation (operands split into three bf16 terms: error vs fp64 at or below the fp32 instruction's,
+            # DESIGN.md 8e)
+            "dtype": "f32 (video stem: bf16x3 MFMA)" if any(k.startswith(("stem_fwd3", "stem_wgrad3")) for k in kern) else "f32",
             "data": "synthetic",
             "config": {"workload": "AVID Cross-N1024 step: R(2+1)D-18 + Conv2D-10 + heads [512,512,128], "
                                    "3x8x112x112 video + 1x40x100 audio",
@@ -517,7 +518,7 @@ def main():
                          "mfma_kernels": {k: dict({"ms_per_step": round(v["ms"] / kern_steps, 3),
                                                    "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                                    "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                                   "flops": "fp32-equivalent (six bf16 MFMAs per product, bf16x3)" if k.startswith("stem_fwd3") else "executed"},
+                                                   "flops": "fp32-equivalent (six bf16 MFMAs per product, bf16x3)" if k.startswith(("stem_fwd3", "stem_wgrad3")) else "executed"},
                                                   **({"direct_equivalent": round(2.25 * v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                                      if k.startswith(("wino_", "wino2_")) else {}),
                                                   # counter HBM traffic per launch (profiles/pmc_traffic.json) next to
