@@ -1385,7 +1385,28 @@ constexpr int WG_LD = 64 + 4;
 // ------------------------------------------------------------------------------------------------
 constexpr int WG_TABC = 32;   // chunks (of 32 pixel rows) covered by one fill of the row table: 1024 rows, 8 KB
 
-template <int NB, int KC>
+// SPLIT (round 4): the products as fp32-accurate split-bf16 — a chunk of 32 pixel rows is two k-steps of 16;
+// a lane reads its column of 8 consecutive rows (the two half-waves take rows 8 apart: DW and WG_LD put them on disjoint
+// banks), splits the 8 values into three bf16 terms in registers and feeds six v_mfma_f32_32x32x16_bf16 per dw tile.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned wg_uintx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& fh, wg_bf16x8& fm, wg_bf16x8& fl) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = v[2 * i], x1 = v[2 * i + 1];
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h[i]) : "v"(x0), "v"(x1));
+    const float r0 = x0 - __uint_as_float(h[i] << 16), r1 = x1 - __uint_as_float(h[i] & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m[i]) : "v"(r0), "v"(r1));
+    const float t0 = r0 - __uint_as_float(m[i] << 16), t1 = r1 - __uint_as_float(m[i] & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l[i]) : "v"(t0), "v"(t1));
+  }
+  fh = __builtin_bit_cast(wg_bf16x8, wg_uintx4{h[0], h[1], h[2], h[3]});
+  fm = __builtin_bit_cast(wg_bf16x8, wg_uintx4{m[0], m[1], m[2], m[3]});
+  fl = __builtin_bit_cast(wg_bf16x8, wg_uintx4{l[0], l[1], l[2], l[3]});
+}
+
+template <int NB, int KC, bool SPLIT = false>
 __device__ __forceinline__ void wgrad_tab_body(const WgradArgs& p, const unsigned lid, float* smem) {
   constexpr int DW = 64 * NB + 4;                 // dy tile row (floats)
   constexpr int BUF = 32 * (DW + KC * WG_LD);     // one stage
@@ -1507,6 +1528,40 @@ __device__ __forceinline__ void wgrad_tab_body(const WgradArgs& p, const unsigne
   auto chunk_body = [&](int ch, auto ST, auto LD) {
     const float* Db = smem + u * BUF + wm * 32 * NB + l31;
     const float* Xb = smem + u * BUF + 32 * DW + wn * 32 + l31;
+    if (SPLIT) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        if (decltype(ST)::value && st == 0) store_chunk(u ^ 1);
+        if (decltype(LD)::value && st == 1) load_chunk(ch + 2);
+        const int r0 = 16 * st + 8 * h;                  // this half-wave's 8 pixel rows
+        wg_bf16x8 ah[NB], am[NB], al[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = Db[(r0 + e) * DW + t * 32];                       // A[i = n][k = m]
+          wg_split8(v, ah[t], am[t], al[t]);
+        }
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = Xb[j * 32 * WG_LD + (r0 + e) * WG_LD];            // B[k = m][j = c]
+          wg_bf16x8 bh, bm, bl;
+          wg_split8(v, bh, bm, bl);
+#pragma unroll
+          for (int t = 0; t < NB; ++t) {
+            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], bm, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bm, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], bh, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh, acc[t][j], 0, 0, 0);
+          }
+        }
+      }
+      return;
+    }
     float a[2][2][NB], b[2][2][KC];
     auto frag = [&](int kp, int buf) {
 #pragma unroll
@@ -1576,10 +1631,10 @@ __device__ __forceinline__ void wgrad_tab_body(const WgradArgs& p, const unsigne
     }
 }
 
-template <int NB, int KC>
+template <int NB, int KC, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void wgrad_tab_kernel(const WgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  wgrad_tab_body<NB, KC>(p, xcd_remap(blockIdx.x, gridDim.x), smem);   // dw tiles of one pixel range stay on one XCD
+  wgrad_tab_body<NB, KC, SPLIT>(p, xcd_remap(blockIdx.x, gridDim.x), smem);   // dw tiles of one pixel range stay on one XCD
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1599,6 +1654,7 @@ struct WgradGroupArgs {
   unsigned run;                      // consecutive items that stay on one XCD
 };
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const WgradGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int total = g.item0[g.n];
@@ -1616,7 +1672,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const WgradGroupArg
   for (int item = (int)first; item < total; item += (int)G) {
     int l = 0;
     while (l + 1 < g.n && item >= g.item0[l + 1]) ++l;
-    wgrad_tab_body<2, 2>(g.layer[l], (unsigned)(item - g.item0[l]), smem);
+    wgrad_tab_body<2, 2, SPLIT>(g.layer[l], (unsigned)(item - g.item0[l]), smem);
     __syncthreads();                 // the next item refills the row table and both stages
   }
 }
@@ -2801,6 +2857,16 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
   return dispatch_igemm<1>(a, static_cast<char*>(ws) + dgrad_wt_bytes(d), ws_bytes - dgrad_wt_bytes(d), s);
 }
 
+// weight gradients of the vector-path layers as split-bf16 products (wgrad_tab_body<.., SPLIT>); AVID_WGRAD_BF16X3=0: fp32 MFMA
+static bool wgrad_split() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("AVID_WGRAD_BF16X3");
+    on = e ? atoi(e) != 0 : 1;
+  }
+  return on != 0;
+}
+
 // ---- wgrad plan
 struct WgradPlan {
   bool vec;
@@ -2915,18 +2981,24 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
       if (!set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tab_kernel<1, 3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tab_kernel<1, 3, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         set = true;
       }
-      hipLaunchKernelGGL((wgrad_tab_kernel<1, 3>), dim3(grid.x * grid.y), dim3(256), lds, s, a);
+      if (wgrad_split()) hipLaunchKernelGGL((wgrad_tab_kernel<1, 3, true>), dim3(grid.x * grid.y), dim3(256), lds, s, a);
+      else hipLaunchKernelGGL((wgrad_tab_kernel<1, 3>), dim3(grid.x * grid.y), dim3(256), lds, s, a);
     } else {
       const size_t lds = sizeof(float) * 2 * 32 * (64 * 2 + 4 + 2 * WG_LD) + sizeof(uint2) * WG_TABC * 32;
       static bool set = false;
       if (!set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tab_kernel<2, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tab_kernel<2, 2, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         set = true;
       }
-      hipLaunchKernelGGL((wgrad_tab_kernel<2, 2>), dim3(grid.x * grid.y), dim3(256), lds, s, a);
+      if (wgrad_split()) hipLaunchKernelGGL((wgrad_tab_kernel<2, 2, true>), dim3(grid.x * grid.y), dim3(256), lds, s, a);
+      else hipLaunchKernelGGL((wgrad_tab_kernel<2, 2>), dim3(grid.x * grid.y), dim3(256), lds, s, a);
     }
   }
   rc = check_launch("wgrad");
@@ -3092,7 +3164,9 @@ extern "C" int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* 
   const size_t lds = sizeof(float) * 2 * 32 * (64 * 2 + 4 + 2 * WG_LD) + sizeof(uint2) * WG_TABC * 32;
   static bool set = false;
   if (!set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     set = true;
   }
@@ -3101,7 +3175,8 @@ extern "C" int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* 
   if (grid > grid_cap) grid = grid_cap;
   {
     ScopedTimer t(s, "wgrad_group_kernel", flops, bytes);
-    hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)grid), dim3(256), lds, s, g);
+    if (wgrad_split()) hipLaunchKernelGGL(wgrad_group_kernel<true>, dim3((unsigned)grid), dim3(256), lds, s, g);
+    else hipLaunchKernelGGL(wgrad_group_kernel<false>, dim3((unsigned)grid), dim3(256), lds, s, g);
   }
   int rc = check_launch("wgrad_group");
   if (rc || r.count == 0) return rc;
