@@ -481,7 +481,9 @@ class TrainStep:
         t_host = self.t
         mult = getattr(getattr(self.criterion, "nce_average", None), "multinomial", None)
         off_host = mult.offset if mult is not None else None
-        with torch.cuda.graph(self.graph):
+        # (thread-local capture mode: the NCCL process group's watchdog thread polls the events of earlier collectives with
+        #  hipEventQuery — under the default global mode that call is illegal while ANY thread captures and aborts the process)
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self._sloss = self.step(self._sv, self._sa, self._si)
         if self.twt is not None:
             self.twt.frozen = True                   # (the graph holds the table's addresses: ops.prepare_wino)

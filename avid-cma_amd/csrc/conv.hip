@@ -386,6 +386,33 @@ extern "C" int avid_debug_pk_trace(long long* host) {
 #else
 #define PK_STAMP(idx) do {} while (0)
 #endif
+// Split-bf16 products (round 4): every fp32 operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 per
+// product tile — fp32 accuracy (error against fp64 at or below the fp32 instruction's) at 6/16 of its issue time.  Build
+// with -DAVID_PK_FP32 for the exact-fp32 instruction (tools/build_variant.sh: A/B on one box).
+#ifdef AVID_PK_FP32
+constexpr bool PK_SPLIT = false;
+#else
+constexpr bool PK_SPLIT = true;
+#endif
+typedef __bf16 pk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pk_uintx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pk_split8(const floatx4& v0, const floatx4& v1, pk_bf16x8& fh, pk_bf16x8& fm, pk_bf16x8& fl) {
+  const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = v[2 * i], x1 = v[2 * i + 1];
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h[i]) : "v"(x0), "v"(x1));
+    const float r0 = x0 - __uint_as_float(h[i] << 16), r1 = x1 - __uint_as_float(h[i] & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m[i]) : "v"(r0), "v"(r1));
+    const float t0 = r0 - __uint_as_float(m[i] << 16), t1 = r1 - __uint_as_float(m[i] & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l[i]) : "v"(t0), "v"(t1));
+  }
+  fh = __builtin_bit_cast(pk_bf16x8, pk_uintx4{h[0], h[1], h[2], h[3]});
+  fm = __builtin_bit_cast(pk_bf16x8, pk_uintx4{m[0], m[1], m[2], m[3]});
+  fl = __builtin_bit_cast(pk_bf16x8, pk_uintx4{l[0], l[1], l[2], l[3]});
+}
+
 template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false, int EPI = EPI_ANY>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArgs p) {
   static_assert(!STRIDED || MODE == 1, "parity classes are a dgrad construct");
@@ -730,6 +757,43 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     float* nxt = smem + (u ^ 1) * STAGE;
     const float* Ab = cur + a_frag;
     const float* Bb = cur + b_frag;
+    // (64 x 64 wave tiles only: with 32 x 64 the split of three fragments feeds 12 matrix instructions instead of four
+    //  fragments 24 — measured: <4,1,1,2,0> 0.98 -> 1.06 ms per step, <2,2,2,2,0> 0.59 -> 0.52)
+    if (PK_SPLIT && TM * TN >= 4) {
+      // two k-steps of 16: lane (row l31, half h) reads its 8 consecutive k (two 16-byte reads; the 36-float row pitch puts
+      // the 16 lanes of a read phase on disjoint banks), splits them in registers, six matrix instructions per tile
+      const float* As = Ab - h * 4 + h * 8;            // (a_frag / b_frag carry the fp32 layout's h * 4)
+      const float* Bs = Bb - h * 4 + h * 8;
+#pragma unroll
+      for (int st = 0; st < BK / 16; ++st) {
+        if (decltype(ST)::value && st == 0) store_stage(nxt);
+        if (decltype(LD)::value && st == 1) issue_loads();
+        pk_bf16x8 ah[TM], am[TM], al[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const floatx4 v0 = *reinterpret_cast<const floatx4*>(As + i * 32 * LDK + st * 16);
+          const floatx4 v1 = *reinterpret_cast<const floatx4*>(As + i * 32 * LDK + st * 16 + 4);
+          pk_split8(v0, v1, ah[i], am[i], al[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const floatx4 v0 = *reinterpret_cast<const floatx4*>(Bs + j * 32 * LDK + st * 16);
+          const floatx4 v1 = *reinterpret_cast<const floatx4*>(Bs + j * 32 * LDK + st * 16 + 4);
+          pk_bf16x8 bh, bm, bl;
+          pk_split8(v0, v1, bh, bm, bl);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      return;
+    }
     floatx4 af[2][TM], bf[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK);
