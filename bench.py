@@ -90,6 +90,15 @@ class ClockSampler:
         return round(sum(self.samples) / len(self.samples) / 1e3, 3) if self.samples else None
 
 
+def split_kernel(name):
+    """Kernels whose fp32 products are assembled from six bf16 MFMAs in the default build/environment."""
+    if name.startswith(("stem_fwd3", "stem_wgrad3")):
+        return True
+    if name.startswith(("wgrad_tab_kernel", "wgrad_group_kernel")):
+        return os.environ.get("AVID_WGRAD_BF16X3", "1") != "0"
+    return name.startswith("igemm_pk_kernel<2,2,2,2")
+
+
 def csrc_digest():
     """sha256 over the kernel sources (avid-cma_amd/csrc/*.hip, common.h, include/avid_hip.h): what profiles/pmc_traffic.json
     is stamped with when tools/pmc_traffic.py writes it (there is no git on the GPU box)."""
@@ -489,10 +498,10 @@ def main():
             "value": round(clips, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            # fp32 end to end; the video stem (forward and weight gradient) assembles its fp32 products from six bf16 MFMAs
-            # with fp32 accumulation (operands split into three bf16 terms: error vs fp64 at or below the fp32 instruction's,
-            # DESIGN.md 8e)
-            "dtype": "f32 (video stem: bf16x3 MFMA)" if any(k.startswith(("stem_fwd3", "stem_wgrad3")) for k in kern) else "f32",
+            # fp32 storage, accumulation and tolerances end to end; the stem, weight-gradient and 64x64-wave-tile convolution
+            # kernels assemble each fp32 product from six bf16 MFMAs (operands split into three bf16 terms in registers:
+            # error vs fp64 at or below the fp32 MFMA instruction's)
+            "dtype": "f32 (bf16x3 MFMA)",
             "data": "synthetic",
             "config": {"workload": "AVID Cross-N1024 step: R(2+1)D-18 + Conv2D-10 + heads [512,512,128], "
                                    "3x8x112x112 video + 1x40x100 audio",
@@ -518,7 +527,7 @@ def main():
                          "mfma_kernels": {k: dict({"ms_per_step": round(v["ms"] / kern_steps, 3),
                                                    "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                                    "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                                   "flops": "fp32-equivalent (six bf16 MFMAs per product, bf16x3)" if k.startswith(("stem_fwd3", "stem_wgrad3")) else "executed"},
+                                                   "flops": "fp32-equivalent (six bf16 MFMAs per product, bf16x3)" if split_kernel(k) else "executed"},
                                                   **({"direct_equivalent": round(2.25 * v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                                      if k.startswith(("wino_", "wino2_")) else {}),
                                                   # counter HBM traffic per launch (profiles/pmc_traffic.json) next to

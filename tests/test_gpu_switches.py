@@ -32,7 +32,7 @@ def default_run(gpu_device):
 IDENTICAL = [{"AVID_PLAN": "0"}, {"AVID_OVERLAP_TOWERS": "0"}, {"AVID_DEFER_WGRAD": "0"}, {"AVID_STREAM_PROBE": "0"},
              {"AVID_FORCE_DIST": "1"}, {"AVID_FORCE_DIST": "1", "AVID_BUCKET_MB": "2"},
              {"AVID_HIP_LIB": os.path.join(os.path.dirname(HERE), "avid-cma_amd", "avid_hip", "libavid_hip.so")}]
-CLOSE = [{"AVID_GROUP_WGRAD": "0"}, {"AVID_FUSE_BN_BWD": "0"}, {"AVID_FUSE_BN_STATS": "0"}, {"AVID_FUSE_RES": "0"},
+CLOSE = [{"AVID_GROUP_WGRAD": "0"}, {"AVID_WGRAD_BF16X3": "0"}, {"AVID_FUSE_BN_BWD": "0"}, {"AVID_FUSE_BN_STATS": "0"}, {"AVID_FUSE_RES": "0"},
          {"AVID_FUSE_STEM_TAIL": "0"}, {"AVID_FUSED_CRITERION": "0"}, {"AVID_WINO": "0"}, {"AVID_WINO_WGRAD": "0"},
          {"AVID_TRIM_TAPS": "0"}, {"AVID_STEM_BF16X3": "0"}]
 
