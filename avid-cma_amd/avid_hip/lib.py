@@ -115,6 +115,8 @@ SIGNATURES = {
     "avid_conv_wgrad_group": (_i, [_i, C.POINTER(WgradItem), _vp, _sz, _vp]),
     "avid_conv_kernel_name": (_i, [_dp, _i, C.c_char_p, _i]),
     "avid_conv_uses_wino": (_i, [_dp, _i]),
+    "avid_conv_uses_split": (_i, [_dp, _i]),
+    "avid_conv_split_bytes": (_sz, [_dp]),
     "avid_wino_configure": (_i, [_i, _i64, _i]),
     "avid_wino2_configure": (_i, [_i]),
     "avid_bn_workspace_bytes": (_sz, [_i64, _i]),

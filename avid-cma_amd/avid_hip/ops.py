@@ -309,6 +309,9 @@ def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
         d.groupable = bool(lib.raw("avid_conv_wgrad_groupable")(C.byref(d)))
         d.wino_fwd = int(lib.raw("avid_conv_uses_wino")(C.byref(d), 0))        # 0, 1 (wino_kernel) or 2 (wino2_kernel)
         d.wino_dgrad = int(lib.raw("avid_conv_uses_wino")(C.byref(d), 1))
+        # the 128 x 64 implicit-GEMM tile takes its weights pre-split into bf16 terms (avid_wt_desc mode 5 / 6)
+        d.split_fwd = bool(lib.raw("avid_conv_uses_split")(C.byref(d), 0))
+        d.split_dgrad = False if channel_first else bool(lib.raw("avid_conv_uses_split")(C.byref(d), 1))
         _DESC_CACHE[key] = hit
     return hit
 
@@ -588,6 +591,40 @@ def _u_for(w, mode, variant):
     return u
 
 
+_SPLIT_CACHE = {}
+
+
+def _split_for(w, mode):
+    """``w`` pre-split into three bf16 terms in igemm_pk_kernel's fragment order (avid_wt_desc mode 5: for the forward,
+    6: the transpose, for the input gradient): made by one small launch per call on this per-layer path (the launch
+    programs of avid_hip.plan keep every layer's in their per-step table).  Same terms either way: bit-identical results."""
+    key = (w.data_ptr(), tuple(w.shape), mode)
+    hit = _SPLIT_CACHE.get(key)
+    if hit is None:
+        k = _kdims(w)
+        planes = torch.empty(6 * w.numel(), dtype=torch.uint8, device=w.device)
+        rec = struct.pack("<QQiiii", w.data_ptr(), planes.data_ptr(), w.shape[0], k[0] * k[1] * k[2], w.shape[1], mode)
+        hit = (planes, torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(w.device))
+        if len(_SPLIT_CACHE) >= 1024:
+            _SPLIT_CACHE.clear()
+        _SPLIT_CACHE[key] = hit
+    lib.call("avid_weight_transpose_batched", 1, _p(hit[1]), w.numel(), _stream())
+    return hit[0]
+
+
+def _fwd_u(w, d, plain=True):
+    """`u` of avid_conv_fwd; ``plain``: no bias / ReLU in the epilogue (those variants read the fp32 weights)."""
+    if d.wino_fwd:
+        return _u_for(w, 1, d.wino_fwd)
+    return _split_for(w, 5) if d.split_fwd and plain else None
+
+
+def _dgrad_u(w, d):
+    if d.wino_dgrad:
+        return _u_for(w, 2, d.wino_dgrad)
+    return _split_for(w, 6) if d.split_dgrad else None
+
+
 def _wt_for(w):
     if _TRANSPOSED is None:
         return None
@@ -640,7 +677,7 @@ class _ConvCL(Function):
         stats = None
         if want_stats and srows > 0 and bias is None and not relu:
             stats = torch.empty((srows, 2, cout), dtype=torch.float32, device=x.device)
-        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(_u_for(w, 1, d.wino_fwd) if d.wino_fwd else None), _p(addend), _p(bias),
+        lib.call("avid_conv_fwd", C.byref(d), _p(x), _p(w), _p(_fwd_u(w, d, bias is None and not relu)), _p(addend), _p(bias),
                  int(relu), _p(y), _p(stats), _p(ws),
                  ws.numel() if ws is not None else 0, _stream())
         ctx.d, ctx.relu, ctx.channel_first = d, relu, channel_first
@@ -658,7 +695,7 @@ class _ConvCL(Function):
             dr, nbr, _, ctx.nb_wgrad_r, _ = _desc_cached((B, Ti, Hi, Wi), cin, res_w.shape[0], (1, 1, 1), rs, (0, 0, 0), False)
             y_res = torch.empty((B, dr.To, dr.Ho, dr.Wo, res_w.shape[0]), dtype=torch.float32, device=x.device)
             wsr = workspace(x.device, nbr) if nbr else None
-            lib.call("avid_conv_fwd", C.byref(dr), _p(x), _p(res_w), None, None, None, 0, _p(y_res), None, _p(wsr),
+            lib.call("avid_conv_fwd", C.byref(dr), _p(x), _p(res_w), _p(_fwd_u(res_w, dr)), None, None, 0, _p(y_res), None, _p(wsr),
                      wsr.numel() if wsr is not None else 0, _stream())
             ctx.dr, ctx.res_stride = dr, rs
         ctx.save_for_backward(x, w, y if relu else None, res_w)
@@ -751,7 +788,7 @@ class _ConvCL(Function):
                                                 False)
                 add = torch.empty((d.B, dr.To, dr.Ho, dr.Wo, d.Cin), dtype=torch.float32, device=x.device)
                 wsc = workspace(x.device, nbc)
-                lib.call("avid_conv_dgrad", C.byref(dc), _p(d_res), _p(res_w), _p(_wt_for(res_w)), None, None, None, _p(add), None,
+                lib.call("avid_conv_dgrad", C.byref(dc), _p(d_res), _p(res_w), _p(_wt_for(res_w)), _p(_dgrad_u(res_w, dc)), None, None, _p(add), None,
                          _p(wsc), wsc.numel(), st)
                 if any(v != 1 for v in ctx.res_stride):
                     add_stride = (C.c_int32 * 3)(*ctx.res_stride)
@@ -790,7 +827,7 @@ class _ConvCL(Function):
                 fuse = lib.BnBwdFuse(_p(src.x), _p(s4[2]), _p(s4[3]), _p(s4[0]), _p(s4[1]), int(src.relu),
                                      _p(src.partials))
             lib.call("avid_conv_dgrad", C.byref(d), _p(dy), _p(w), _p(_wt_for(w)),
-                     _p(_u_for(w, 2, d.wino_dgrad) if d.wino_dgrad else None), _p(add),
+                     _p(_dgrad_u(w, d)), _p(add),
                      add_stride, _p(dx),
                      C.byref(fuse) if fuse is not None else None, _p(ws), ws.numel(), st)
         if need_dw and not deferred and not grouped:

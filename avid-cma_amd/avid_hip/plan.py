@@ -186,6 +186,29 @@ class Builder:
             self.aux_size += _align(4 * 16 * w.shape[0] * w.shape[1])
         return (S_AUX, self.wt_off[key])
 
+    def want_split(self, w, mode):
+        """The weights pre-split into bf16 terms for igemm_pk_kernel's 128 x 64 tile (mode 5: forward, 6: input gradient)."""
+        key = (id(w), mode)
+        if key not in self.wt_off:
+            k = ops._kdims(w)
+            self.wt_off[key] = self.aux_size
+            self.wt_recs.append((w, self.aux_size, w.shape[0], k[0] * k[1] * k[2], w.shape[1], mode))
+            self.aux_size += _align(6 * w.numel())
+            if mode == 5:
+                self.fwd_tables = True
+        return (S_AUX, self.wt_off[key])
+
+    def fwd_u(self, w, d):
+        return self.want_split(w, 5) if d.split_fwd else None
+
+    def dgrad_wt_u(self, w, d):
+        """(wt, u) of an input gradient: the Winograd transform, the pre-split transpose, or the plain transpose."""
+        if d.wino_dgrad:
+            return self.want_wt(w), self.want_u(w, d.wino_dgrad)
+        if d.split_dgrad:
+            return None, self.want_split(w, 6)
+        return self.want_wt(w), None
+
     # ---- forward emitters ------------------------------------------------------------------------------------------
     def desc(self, x_shape, conv_w, stride, pad, channel_first):
         if channel_first:
@@ -207,7 +230,7 @@ class Builder:
         M = d.B * d.To * d.Ho * d.Wo
         y = self.fa.alloc(4 * M * d.Cout)
         stats = self.fa.alloc(4 * srows * 2 * d.Cout) if srows > 0 else None
-        self.emit(OP_CONV_FWD, d=d, i=(0,), t=(x.ref, self.ext(w), None, addend.ref if addend is not None else None, None, y, stats))
+        self.emit(OP_CONV_FWD, d=d, i=(0,), t=(x.ref, self.ext(w), self.fwd_u(w, d), addend.ref if addend is not None else None, None, y, stats))
         L = {"conv": conv, "bn": bn, "d": d, "x": x, "y": y, "w": w, "sole": sole, "res": None, "M": M}
         if res is not None:
             rconv = res
@@ -216,7 +239,7 @@ class Builder:
                 raise Unsupported("residual convolution")
             dr = self.desc(x.shape, rw, rconv.stride3, (0, 0, 0), False)[0]
             y_res = self.fa.alloc(4 * d.B * dr.To * dr.Ho * dr.Wo * dr.Cout)
-            self.emit(OP_CONV_FWD, d=dr, i=(0,), t=(x.ref, self.ext(rw), None, None, None, y_res, None))
+            self.emit(OP_CONV_FWD, d=dr, i=(0,), t=(x.ref, self.ext(rw), self.fwd_u(rw, dr), None, None, y_res, None))
             L["res"] = {"conv": rconv, "d": dr, "w": rw, "y": Sym(y_res, (d.B, dr.To, dr.Ho, dr.Wo, dr.Cout))}
         Cc = d.Cout
         h = self.fa.alloc(4 * M * Cc)
@@ -301,7 +324,7 @@ class Builder:
                 # compact input gradient of the residual convolution: a dense 1x1x1 dgrad over the sub-sampled grid
                 dc = ops._desc_cached((d.B, dr.To, dr.Ho, dr.Wo), d.Cin, dr.Cout, (1, 1, 1), (1, 1, 1), (0, 0, 0), False)[0]
                 add = self.ba.alloc(4 * d.B * dr.To * dr.Ho * dr.Wo * d.Cin)
-                self.emit(OP_CONV_DGRAD, d=dc, i=(0, 0, 0, 0, 0), t=(g_res, self.ext(rw), self.want_wt(rw), None, None, add))
+                self.emit(OP_CONV_DGRAD, d=dc, i=(0, 0, 0, 0, 0), t=(g_res, self.ext(rw), *self.dgrad_wt_u(rw, dc), None, add))
                 rs = res["conv"].stride3
                 add_stride = tuple(rs) if any(v != 1 for v in rs) else None
             if not self.wgrad(dr, x.ref, g_res, rw, flush_check=False):
@@ -311,7 +334,7 @@ class Builder:
             dx = self.ba.alloc(4 * x.numel)
             src = x.bn
             fuse = src is not None and ops.FUSE_BN_BWD and d.bn_bwd_rows > 0
-            t = [g, self.ext(w), self.want_wt(w), self.want_u(w, d.wino_dgrad) if d.wino_dgrad else None, add, dx]
+            t = [g, self.ext(w), *self.dgrad_wt_u(w, d), add, dx]
             iv = list(add_stride) if add_stride is not None else [0, 0, 0]
             if fuse:
                 src.rows = d.bn_bwd_rows
@@ -411,6 +434,10 @@ class Builder:
                      self.ext(bn.num_batches_tracked), stats))
         stem = {"d": d, "w": w, "x": x, "y": y, "am": am, "s4": s4, "bn": bn, "dims": (B, T, H, W, Cc)}
         h = Sym(p, (B, T, Ho, Wo, Cc))
+        # the pre-split weights of the layers from here on (want_split mode 5) come from the step's weight-transform launch
+        # on the trailing stream, issued beside the stem
+        if self.trailing:
+            self.wait(ST_MAIN, ST_TRAIL)
         if after_stem is not None:
             after_stem()
         blocks = []

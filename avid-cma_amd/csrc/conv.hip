@@ -80,6 +80,10 @@ struct ConvArgs {
   int bnb_relu;
   int pk_rot;      // tail unit u runs on workgroup (u + pk_rot) mod G: the ones that got one full tile less
   int pk_paired;   // grid = 2 workgroups per CU: number them so that v and v + G/2 share a CU
+  // igemm_pk_kernel<..., BS>: the weights pre-split into three bf16 terms, in the kernel's operand-fragment order
+  // (avid_wt_desc mode 5 / 6): base of the first live tap's chunks, bytes addressable from it, bytes between two k-tiles
+  const void* wsp;
+  int wsp_nrec, wsp_kstep;
 };
 
 constexpr int BK = 32;
@@ -413,7 +417,11 @@ __device__ __forceinline__ void pk_split8(const floatx4& v0, const floatx4& v1, 
   fl = __builtin_bit_cast(pk_bf16x8, pk_uintx4{l[0], l[1], l[2], l[3]});
 }
 
-template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false, int EPI = EPI_ANY>
+// BS: the weight operand arrives pre-split (ConvArgs::wsp): one (k-tile, 64 rows) chunk is PK_BCH contiguous bytes
+// [row block j of 32][k-step st of 16][term: hi, mid, lo][lane][8 bf16] — a straight 16-byte-per-thread copy into LDS, read
+// back as whole fragments (lane * 16: conflict-free), no split instructions for this operand.
+constexpr int PK_BCH = 2 * 2 * 3 * 1024;
+template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false, int EPI = EPI_ANY, bool BS = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArgs p) {
   static_assert(!STRIDED || MODE == 1, "parity classes are a dgrad construct");
   constexpr int NT = WM * WN * 64;
@@ -421,7 +429,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   constexpr int RPP = NT / 8;                   // rows staged per pass: 8 lanes x 16 B cover a 32-float row
   constexpr int PA = BM / RPP, PB = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
-  constexpr int STAGE = (BM + BN) * LDK;
+  static_assert(!BS || (NT == 256 && BN == 64 && PK_SPLIT), "pre-split weights: the 128 x 64 tile of the split-bf16 build");
+  constexpr int PB3 = PK_BCH / (NT * 16);       // 16-byte items of a pre-split chunk per thread
+  constexpr int STAGE = BS ? BM * LDK + PK_BCH / 4 : (BM + BN) * LDK;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   const int pix_per_b = p.Ts * p.Hs * p.Ws;
   const int pix_d = p.Td * p.Hd * p.Wd;
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.wk, 0, p.w_nrec, 0x00020000);
+      BS ? const_cast<void*>(p.wsp) : (void*)p.wk, 0, BS ? p.wsp_nrec : p.w_nrec, 0x00020000);
 
   // ---- this workgroup's segments: whole tiles slot, slot+G, ... below pk_full, then at most one
   // (tile, K-range) piece of the split tail
@@ -540,6 +550,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   unsigned a_base[PA], a_mask[PA], a_cur[PA];                  // tap-(0,0,0) offset, tap validity, current voffset
   unsigned b_off[PB];
   floatx4 va[PA], vb[PB];
+  pk_uintx4 vb3[PB3];                                          // BS: this thread's items of the weight chunk
+  int ld_bnt = 0;                                              // BS: byte offset of the loader tile's column block in a k-tile's chunks
 
   auto range_mask = [](int lo, int hi, int k) -> unsigned {    // bits lo..hi clipped to [0, k)
     lo = lo < 0 ? 0 : lo;
@@ -629,6 +641,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + RPP * i) * p.w_row + lcol) * 4;
+    if (BS) ld_bnt = __builtin_amdgcn_readfirstlane(nt * PK_BCH);
   };
   auto issue_loads = [&]() {   // k-tile (loader tile; tap, channel block) -> registers: PA + PB loads
     // The descriptor words and scalar offsets were prepared when they last changed (setup_tile / advance); here
@@ -643,6 +656,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
 #pragma unroll
     for (int i = 0; i < PA; ++i)
       va[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_cur[i], soff_a, 0));
+    if (BS) {
+      const int soff_b3 = __builtin_amdgcn_readfirstlane(ld_soff_b + ld_bnt);
+#pragma unroll
+      for (int i = 0; i < PB3; ++i)
+        vb3[i] = __builtin_bit_cast(pk_uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (tid + NT * i) * 16, soff_b3, 0));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PB; ++i)
       vb[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], soff_b, 0));
@@ -658,7 +678,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       ld_tap = sgpr((ld_dt * p.kh + ld_dh) * p.kw + ld_dw);
     }
     ld_soff_a = sgpr(ld_c0 * 4);
-    ld_soff_b = sgpr((ld_tap * p.Cs + ld_c0) * 4);
+    ld_soff_b = BS ? sgpr((ld_tap * cpt + ld_c0 / BK) * p.wsp_kstep) : sgpr((ld_tap * p.Cs + ld_c0) * 4);
   };
   auto setup_seg = [&](int j) {   // loader enters segment j (STRIDED: the next segment that has any k-tiles)
     int tile, k0, k1, split;
@@ -696,7 +716,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       }
     } else if (ld_c0 != p.Cs) {      // next channel block of the same tap
       ld_soff_a = sgpr(ld_soff_a + BK * 4);
-      ld_soff_b = sgpr(ld_soff_b + BK * 4);
+      ld_soff_b = sgpr(ld_soff_b + (BS ? p.wsp_kstep : BK * 4));
     } else {                         // next tap
       ld_c0 = 0;
       int dw = ld_dw + 1, dh = ld_dh, dt = ld_dt;
@@ -713,6 +733,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   auto store_stage = [&](float* st) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) *reinterpret_cast<floatx4*>(&st[(lrow + RPP * i) * LDK + lcol]) = va[i];
+    if (BS) {
+#pragma unroll
+      for (int i = 0; i < PB3; ++i)
+        *reinterpret_cast<pk_uintx4*>(reinterpret_cast<char*>(st + BM * LDK) + (tid + NT * i) * 16) = vb3[i];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PB; ++i) *reinterpret_cast<floatx4*>(&st[(BM + lrow + RPP * i) * LDK + lcol]) = vb[i];
   };
@@ -759,6 +785,40 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     const float* Bb = cur + b_frag;
     // (64 x 64 wave tiles only: with 32 x 64 the split of three fragments feeds 12 matrix instructions instead of four
     //  fragments 24 — measured: <4,1,1,2,0> 0.98 -> 1.06 ms per step, <2,2,2,2,0> 0.59 -> 0.52)
+    if (BS) {
+      // the weight fragments come whole from LDS; only this wave's input rows are split in registers
+      const float* As = Ab - h * 4 + h * 8;
+      const char* Bc = reinterpret_cast<const char*>(cur + BM * LDK) + lane * 16;
+#pragma unroll
+      for (int st = 0; st < BK / 16; ++st) {
+        if (decltype(ST)::value && st == 0) store_stage(nxt);
+        if (decltype(LD)::value && st == 1) issue_loads();
+        pk_bf16x8 ah[TM], am[TM], al[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const floatx4 v0 = *reinterpret_cast<const floatx4*>(As + i * 32 * LDK + st * 16);
+          const floatx4 v1 = *reinterpret_cast<const floatx4*>(As + i * 32 * LDK + st * 16 + 4);
+          pk_split8(v0, v1, ah[i], am[i], al[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const char* Bj = Bc + (((wn * TN + j) * 2 + st) * 3) * 1024;
+          const pk_bf16x8 bh = *reinterpret_cast<const pk_bf16x8*>(Bj);
+          const pk_bf16x8 bm = *reinterpret_cast<const pk_bf16x8*>(Bj + 1024);
+          const pk_bf16x8 bl = *reinterpret_cast<const pk_bf16x8*>(Bj + 2048);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      return;
+    }
     if (PK_SPLIT && TM * TN >= 4) {
       // two k-steps of 16: lane (row l31, half h) reads its 8 consecutive k (two 16-byte reads; the 36-float row pitch puts
       // the 16 lanes of a read phase on disjoint banks), splits them in registers, six matrix instructions per tile
@@ -1951,6 +2011,41 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const avid_wt_desc* __restrict__ descs) {
   __shared__ float tile[32][33];
   const avid_wt_desc d = descs[blockIdx.y];
+  if (d.mode >= 5) {     // three-bf16-term split in igemm_pk_kernel<.., BS>'s fragment order: 5 of w, 6 of its transpose
+    const int N = d.mode == 5 ? d.Cout : d.Cin, C = d.mode == 5 ? d.Cin : d.Cout;   // operand rows, channels per tap
+    const int c8 = C / 8, cpt = C / 32, ntn = N / 64;
+    const long long items = (long long)N * d.ntaps * c8;     // 8 consecutive k of one row each
+    char* out = reinterpret_cast<char*>(d.wt);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+      int n, tap, k8;
+      float v[8];
+      if (d.mode == 5) {   // k fastest: two 16-byte reads of a weight row
+        k8 = (int)(i % c8);
+        const long long r = i / c8;
+        tap = (int)(r % d.ntaps);
+        n = (int)(r / d.ntaps);
+        const floatx4* src = reinterpret_cast<const floatx4*>(d.w + ((long long)n * d.ntaps + tap) * C + k8 * 8);
+        const floatx4 a = src[0], b = src[1];
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+      } else {             // n fastest: neighbouring threads read neighbouring input channels of the same 8 filters
+        n = (int)(i % N);
+        const long long r = i / N;
+        k8 = (int)(r % c8);
+        tap = (int)(r / c8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = d.w[((long long)(k8 * 8 + e) * d.ntaps + tap) * d.Cin + n];
+      }
+      pk_bf16x8 fh, fm, fl;
+      pk_split8(floatx4{v[0], v[1], v[2], v[3]}, floatx4{v[4], v[5], v[6], v[7]}, fh, fm, fl);
+      const int cb = k8 >> 2, st = (k8 >> 1) & 1, hh = k8 & 1;
+      const long long chunk = ((long long)tap * cpt + cb) * ntn + (n >> 6);
+      char* o = out + chunk * PK_BCH + ((((n >> 5) & 1) * 2 + st) * 3) * 1024 + (hh * 32 + (n & 31)) * 16;
+      *reinterpret_cast<pk_bf16x8*>(o) = fh;
+      *reinterpret_cast<pk_bf16x8*>(o + 1024) = fm;
+      *reinterpret_cast<pk_bf16x8*>(o + 2048) = fl;
+    }
+    return;
+  }
   if (d.mode != 0) {     // Winograd-transformed weights of a 3x3 layer (wino.hip): mode 1 / 3 forward, 2 / 4 input gradient;
     const bool fwd = d.mode & 1;       // 1, 2 in wino_kernel's fragment order, 3, 4 in wino2_kernel's
     wino_weight_elements(d.w, d.wt, fwd ? d.Cout : d.Cin, fwd ? d.Cin : d.Cout, d.Cin, !fwd,
@@ -2212,15 +2307,34 @@ static int epi_code(const ConvArgs& a) {
   return a.relu ? EPI_ANY : 0;
 }
 
-template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED, int EPI>
-static void launch_pk_e(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED, int EPI, bool BS>
+static void launch_pk_eb(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = igemm_pk_kernel<WM, WN, TM, TN, MODE, STRIDED, EPI>;
+  auto kern = igemm_pk_kernel<WM, WN, TM, TN, MODE, STRIDED, EPI, BS>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, a);
+}
+
+// pre-split weights (ConvArgs::wsp) are consumed by the 128 x 64 tile with the epilogues convolution layers use
+template <int WM, int WN, int TM, int TN, int EPI>
+constexpr bool pk_takes_split() {
+  return PK_SPLIT && WM == 4 && WN == 1 && TM == 1 && TN == 2 && (EPI == 0 || EPI == 1 || EPI == 8 || EPI == 9);
+}
+
+template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED, int EPI>
+static void launch_pk_e(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
+  if constexpr (pk_takes_split<WM, WN, TM, TN, EPI>()) {
+    if (a.wsp) {
+      constexpr int BM = WM * TM * 32;
+      const size_t lds3 = sizeof(float) * 2 * (BM * LDK + PK_BCH / 4) + (STRIDED ? sizeof(int) * 2 * BM : 0);
+      launch_pk_eb<WM, WN, TM, TN, MODE, STRIDED, EPI, true>(a, grid, lds3, s);
+      return;
+    }
+  }
+  launch_pk_eb<WM, WN, TM, TN, MODE, STRIDED, EPI, false>(a, grid, lds, s);
 }
 
 template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
@@ -2693,6 +2807,8 @@ static void fill_common(ConvArgs& a, const avid_conv_desc* d) {
   a.part_row_begin = 0;
   a.add_s[0] = a.add_s[1] = a.add_s[2] = 1;
   a.add_n[0] = a.add_n[1] = a.add_n[2] = 0;
+  a.wsp = nullptr;
+  a.wsp_nrec = a.wsp_kstep = 0;
 }
 
 // C[M][N] = A[M][K] . Bq[N][K]^T, optionally combined with Cin by min / max — the similarity GEMMs of
@@ -2718,6 +2834,8 @@ int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin,
   a.mgW = a.mgH = a.mgT = 0; a.shW = a.shH = a.shT = 0;
   a.add_s[0] = a.add_s[1] = a.add_s[2] = 1;
   a.add_n[0] = a.add_n[1] = a.add_n[2] = 0;
+  a.wsp = nullptr;
+  a.wsp_nrec = a.wsp_kstep = 0;
   // persistent kernel, no K-split (K = 128: 4 k-tiles per tile, thousands of tiles): 54 -> ~90 TFLOP/s
   if (pk_enabled()) return dispatch_igemm<0>(a, nullptr, 0, s);
   return launch_igemm<4, 1, 1, 2, 0>(a, s);
@@ -2726,6 +2844,43 @@ int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin,
 }  // namespace avid
 
 using namespace avid;
+
+// Does this layer's forward (which 0) / input gradient (1) run on the 128 x 64 tile of igemm_pk_kernel, which takes its
+// weights pre-split (avid_wt_desc mode 5 / 6) as `u`?  Mirrors avid_conv_fwd / avid_conv_dgrad / dispatch_igemm.
+static bool conv_takes_split(const avid_conv_desc* d, int which) {
+#ifdef AVID_NO_PRESPLIT   // (tools/build_variant.sh: A/B against the fp32 instruction on one box)
+  return false;
+#endif
+  if (!PK_SPLIT || d->x_channel_first) return false;
+  if (which == 0) {
+    if (d->Cin % 32 || d->Cout % 64 || wino_supported(d, 0)) return false;
+    const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
+    return plan_pk(M, d->Cout, trim_taps(d).d.kt * d->kh * d->kw * (d->Cin / BK), 0).tile == 1;
+  }
+  if (d->Cin % 64 || d->Cout % 32 || d->st > 2 || d->sh > 2 || d->sw > 2 || wino_supported(d, 1)) return false;
+  const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
+  if (d->st > 1 || d->sh > 1 || d->sw > 1) return M * d->Cin * 4 < (1ll << 31) && d->Cin % 128 != 0;
+  return plan_pk(M, d->Cin, trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK), 1).tile == 1;
+}
+
+extern "C" int avid_conv_uses_split(const avid_conv_desc* d, int which) {
+  if (!d || validate(d) || which < 0 || which > 1) return 0;
+  return conv_takes_split(d, which) ? 1 : 0;
+}
+
+extern "C" size_t avid_conv_split_bytes(const avid_conv_desc* d) {
+  if (!d || validate(d)) return 0;
+  return (size_t)6 * d->Cout * d->kt * d->kh * d->kw * d->Cin;
+}
+
+// ConvArgs::wsp for an operand of N rows x (taps x C) pre-split into chunks, the first dt0 temporal taps skipped
+static void set_split_operand(ConvArgs& a, const void* planes, int N, int C, int ntaps_full, int khw, int dt0) {
+  const int kstep = (N / 64) * PK_BCH;
+  const long long off = (long long)dt0 * khw * (C / BK) * kstep, total = (long long)ntaps_full * (C / BK) * kstep;
+  a.wsp = static_cast<const char*>(planes) + off;
+  a.wsp_nrec = (int)(total - off);
+  a.wsp_kstep = kstep;
+}
 
 extern "C" size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
@@ -2775,6 +2930,7 @@ extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const floa
     a.w_row = (int)(tr.kt_full * tapsz);
     a.w_nrec = (int)(((long long)d->Cout * a.w_row - off) * 4);
   }
+  if (u && conv_takes_split(d, 0)) set_split_operand(a, u, d->Cout, d->Cin, d->kt * d->kh * d->kw, d->kh * d->kw, tr.dt0);
   a.Ts = d->Ti; a.Hs = d->Hi; a.Ws = d->Wi; a.Cs = d->Cin;
   a.Td = d->To; a.Hd = d->Ho; a.Wd = d->Wo; a.Cd = d->Cout;
   a.M = d->B * d->To * d->Ho * d->Wo;
@@ -2878,6 +3034,8 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
     return wino_conv(d, 1, dy, w, u, dx, addend, nullptr, bn, ws, s);   // (u: this layer's pre-transformed weights)
   const int ntaps = d->kt * d->kh * d->kw;
   const float* wt = wt_in;
+  const bool split = u && conv_takes_split(d, 1);      // (u: this layer's pre-split transposed weights; wt is not read)
+  if (split) wt = w;
   if (!wt) {
     float* wt_ws = static_cast<float*>(ws);
     const long long nw = (long long)d->Cout * ntaps * d->Cin;
@@ -2900,6 +3058,7 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
     a.w_row = (int)(tr.kt_full * tapsz);
     a.w_nrec = (int)(((long long)d->Cin * a.w_row - off) * 4);
   }
+  if (split) set_split_operand(a, u, d->Cin, d->Cout, ntaps, d->kh * d->kw, tr.dt0);
   a.Ts = d->To; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
   a.Td = d->Ti; a.Hd = d->Hi; a.Wd = d->Wi; a.Cd = d->Cin;
   a.M = d->B * d->Ti * d->Hi * d->Wi;

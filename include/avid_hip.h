@@ -78,7 +78,8 @@ size_t avid_conv_fwd_workspace_bytes(const avid_conv_desc* d);
 int avid_conv_fwd_stats_rows(const avid_conv_desc* d);
 /* u (or NULL): for a layer on the Winograd path (v = avid_conv_uses_wino(d, 0) != 0), its weights already transformed by
  * avid_weight_transpose_batched (a descriptor of mode 1 if v == 1, mode 3 if v == 2; current for this w): the call then
- * skips its own transform launch.  Ignored by every other layer. */
+ * skips its own transform launch.  For a layer with avid_conv_uses_split(d, 0) != 0 (version >= 120): its mode-5 table
+ * (the weights pre-split into bf16 terms).  Ignored by every other layer. */
 int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* u, const float* addend,
                   const float* bias, int relu, float* y, float* bn_partials, void* ws, size_t ws_bytes,
                   avid_stream_t stream);
@@ -89,7 +90,9 @@ int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const
  * u (nullable, version >= 110: its own argument): for a layer whose input gradient runs on the Winograd path
  * (v = avid_conv_uses_wino(d, 1) != 0) its mode-2 (v == 1) or mode-4 (v == 2) transform from
  * avid_weight_transpose_batched; NULL = transform inside the call.  Each pointer is read only by the path it belongs
- * to: a Winograd-eligible layer that falls through to the implicit GEMM (compact addend) reads wt, never u. */
+ * to: a Winograd-eligible layer that falls through to the implicit GEMM (compact addend) reads wt, never u.
+ * A layer with avid_conv_uses_split(d, 1) != 0 (version >= 120) takes its mode-6 table as u and then reads neither wt
+ * nor the repack scratch. */
 size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d);
 /* bn (or NULL): dx is the COMPLETE gradient of the output of a training-mode BatchNorm(+ReLU) whose input was
  * bn->x (shape of dx) — the usual conv <- ReLU <- BN chain of models/network_blocks.py:30-60.  The dgrad epilogue
@@ -128,7 +131,12 @@ typedef struct avid_wt_desc {
                    weights U in the operand-fragment order of the kernel that will read them — 1 / 3: for the forward
                    (pass it as `u` to avid_conv_fwd), 2 / 4: with flipped taps and swapped channel roles for the input
                    gradient (pass it as `u` to avid_conv_dgrad); 1, 2 for wino_kernel, 3, 4 for wino2_kernel
-                   (avid_conv_uses_wino says which of the two a layer runs on) */
+                   (avid_conv_uses_wino says which of the two a layer runs on);
+                   5 / 6: the weights (5) / their [Cin][taps][Cout] transpose (6) split into three bf16 terms (hi, mid, lo:
+                   w = hi + mid + lo to fp32 accuracy) in the operand-fragment order of igemm_pk_kernel's 128 x 64 tile,
+                   6 bytes per weight (avid_conv_split_bytes) — pass it as `u` to avid_conv_fwd (5) / avid_conv_dgrad (6)
+                   of a layer for which avid_conv_uses_split answers 1; needs Cout % 64 == 0 and Cin % 32 == 0 (5) or
+                   Cin % 64 == 0 and Cout % 32 == 0 (6) */
 } avid_wt_desc;
 int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_dev, int64_t max_elems, avid_stream_t stream);
 
@@ -138,6 +146,12 @@ int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* buf, int len
 /* Nonzero if this layer's forward (which 0) / input gradient (1) / weight gradient (2) runs on the Winograd kernels;
  * for which 0 / 1: 1 = wino_kernel, 2 = wino2_kernel (layers with >= 1.5 rounds of 64-tile units for the CUs). */
 int avid_conv_uses_wino(const avid_conv_desc* d, int which);
+/* Nonzero if this layer's forward (which 0) / input gradient (1) runs on the implicit-GEMM tile that reads its weights
+ * pre-split into bf16 terms: `u` of avid_conv_fwd / avid_conv_dgrad is then the avid_wt_desc mode 5 / 6 table of this
+ * layer (avid_conv_split_bytes bytes).  Without it (u = NULL) the same layer runs with the fp32 matrix instruction on the
+ * weights as they are (and avid_conv_dgrad on wt): both forms are fp32-accurate, their roundings differ. */
+int avid_conv_uses_split(const avid_conv_desc* d, int which);
+size_t avid_conv_split_bytes(const avid_conv_desc* d);
 
 /* Dispatch switches of the Winograd path (defaults: on, layers of >= 6000 output pixels, <= 256 output channels and
  * pixels x max(Cin, Cout) >= 1e6; environment AVID_WINO / AVID_WINO_MIN_M / AVID_WINO_MAXC / AVID_WINO_MIN_WORK — an

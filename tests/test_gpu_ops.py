@@ -99,6 +99,66 @@ def test_conv_fwd_dgrad_wgrad(case, gpu_device, kernel_log, wino_variant):
         assert log.launches("wino_kernel") + log.launches("wino2_kernel") == 0 and log.launches("wino_wgrad_kernel") == 0
 
 
+@pytest.mark.parametrize("mode", [5, 6])
+@pytest.mark.parametrize("cout,cin,k", [(64, 64, (1, 3, 3)), (192, 128, (3, 1, 1)), (64, 256, (1, 1, 1))])
+def test_presplit_weight_tables_hold_the_weights(cout, cin, k, mode, gpu_device):
+    """avid_wt_desc mode 5 / 6 (what igemm_pk_kernel's 128 x 64 tile reads instead of fp32 weights): three bf16 terms per
+    weight, hi + mid + lo == w to 2^-24 of |w|, each at the fragment position the kernel reads it from —
+    [tap][32-channel block][64-row block][row half][k-step of 16][term][lane = 32 * (k / 8 % 2) + row % 32][k % 8]."""
+    from avid_hip import ops
+    w = ops.make_weight(cout, cin, *k)
+    w.copy_(T(detgen.det_param(f"split:{cout}:{cin}:{k}", (cout, cin) + k)))
+    w = w.to(gpu_device)
+    planes = ops._split_for(w, mode)
+    torch.cuda.synchronize()
+    taps = k[0] * k[1] * k[2]
+    W = w.permute(0, 2, 3, 4, 1).reshape(cout, taps, cin).cpu().numpy()      # [row][tap][channel] of the forward operand
+    if mode == 6:
+        W = W.transpose(2, 1, 0)                                               # input gradient: rows = Cin, channels = Cout
+    N, _, Cc = W.shape
+    raw = planes.cpu().numpy().view(np.uint16).astype(np.uint32) << 16
+    terms = raw.view(np.float32).reshape(taps, Cc // 32, N // 64, 2, 2, 3, 2, 32, 8).astype(np.float64)
+    got = terms.sum(axis=5)                                                    # [tap][cb][nt][j][st][h][l31][e]
+    want = W.reshape(N // 64, 2, 32, taps, Cc // 32, 2, 2, 8).transpose(3, 4, 0, 1, 5, 6, 2, 7)   # nt j l31 tap cb st h e ->
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 2.0 ** -23 * np.abs(W).max()
+    hi = terms[:, :, :, :, :, 0]
+    assert np.abs(hi - want).max() <= 2.0 ** -8 * np.abs(W).max()             # hi alone is the bf16 rounding of w
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] in ("spt_s1", "tmp_s2_odd", "big_ragged_333", "dead_taps_333_T1",
+                                                                    "tmp_odd_T")], ids=lambda c: c[0])
+def test_conv_presplit_weights_against_the_fp32_instruction(case, gpu_device, monkeypatch):
+    """The same layer with its weights pre-split (six bf16 matrix instructions per product tile) and without (u = NULL:
+    the fp32 matrix instruction): both within the usual 2e-5 of float64, and within 1e-5 of each other."""
+    from avid_hip import ops
+    name, cin, cout, k, stride, pad, (B, Ti, Hi, Wi) = case
+    x = T(detgen.det_normalish(f"conv:{name}:x", (B, cin, Ti, Hi, Wi)))
+    w = T(detgen.det_param(f"conv:{name}:w.weight", (cout, cin) + k))
+    yr = F.conv3d(x.double().requires_grad_(True), w.double(), stride=stride, padding=pad)
+    gy = T(detgen.det_uniform(f"conv:{name}:gy", tuple(yr.shape)))
+    d = ops._desc_cached((B, Ti, Hi, Wi), cin, cout, k, stride, pad, False)[0]
+    assert d.split_fwd and d.split_dgrad, "case does not run on the 128 x 64 tile"
+    outs = []
+    for presplit in (True, False):
+        if not presplit:
+            monkeypatch.setattr(ops, "_split_for", lambda w_, mode: None)
+        xd = cl(x).to(gpu_device).requires_grad_(True)
+        wd = ops.make_weight(cout, cin, *k)
+        wd.copy_(w)
+        wd = wd.to(gpu_device).requires_grad_(True)
+        y = ops.conv_cl(xd, wd, stride, pad)
+        y.backward(cl(gy).to(gpu_device))
+        outs.append((ncdhw(y.detach()).cpu(), ncdhw(xd.grad).cpu()))
+    xr = x.double().requires_grad_(True)
+    yr = F.conv3d(xr, w.double(), stride=stride, padding=pad)
+    (yr * gy.double()).sum().backward()
+    for y, dx in outs:
+        assert relerr(y, yr.detach()) < 2e-5 and relerr(dx, xr.grad) < 2e-5
+    assert relerr(outs[0][0], outs[1][0].double()) < 1e-5 and relerr(outs[0][1], outs[1][1].double()) < 1e-5
+    assert not torch.equal(outs[0][0], outs[1][0])        # (two different instruction sequences really ran)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 9, 11), (4, 8, 48, 48), (5, 7, 45, 47), (64, 1, 4, 4)])
 @pytest.mark.parametrize("cout", [64, 128, 256])
 @pytest.mark.parametrize("cin", [64, 128])
