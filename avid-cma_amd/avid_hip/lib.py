@@ -48,6 +48,12 @@ class WgradItem(C.Structure):
     _fields_ = [("d", ConvDesc), ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p)]
 
 
+class WtDesc(C.Structure):
+    """avid_wt_desc (include/avid_hip.h)."""
+    _fields_ = [("w", C.c_void_p), ("wt", C.c_void_p), ("Cout", C.c_int32), ("ntaps", C.c_int32), ("Cin", C.c_int32),
+                ("mode", C.c_int32)]
+
+
 class Ref(C.Structure):
     """Mirror of ``avid_ref``: (slot, byte offset); slot < 0 = NULL."""
     _fields_ = [("slot", C.c_int32), ("reserved", C.c_int32), ("off", C.c_int64)]
@@ -108,6 +114,7 @@ SIGNATURES = {
     "avid_conv_dgrad_bn_rows": (_i, [_dp]),
     "avid_conv_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_weight_transpose_batched": (_i, [_i, _vp, _i64, _vp]),
+    "avid_weight_transform": (_i, [_vp, _vp]),
     "avid_conv_wgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_wgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_conv_wgrad_groupable": (_i, [_dp]),

@@ -434,6 +434,9 @@ def _grad_done(i):
         _SLOTS.on_ready(i)
 
 
+U_FLOATS = 24        # a Winograd-transformed weight table: 96 bytes per (Cout, Cin) pair (avid_wt_desc modes 1 - 4)
+
+
 class TransposedWeights:
     """[Cin][taps][Cout] copies of every conv / linear weight that can need an input gradient, repacked by ONE
     launch (avid_weight_transpose_batched) instead of one small launch inside every avid_conv_dgrad call.
@@ -485,10 +488,10 @@ class TransposedWeights:
         self.uwant = {}
         ps = [self.wparams[k[0]] for k in keys]
         dev = ps[0].device
-        self.ubuf = torch.empty(sum(16 * p.shape[0] * p.shape[1] for p in ps), dtype=torch.float32, device=dev)
+        self.ubuf = torch.empty(sum(U_FLOATS * p.shape[0] * p.shape[1] for p in ps), dtype=torch.float32, device=dev)
         recs, off, self.umap = {0: [], 1: []}, 0, {}
         for (ptr, code), p in zip(keys, ps):
-            u = self.ubuf[off:off + 16 * p.shape[0] * p.shape[1]]
+            u = self.ubuf[off:off + U_FLOATS * p.shape[0] * p.shape[1]]
             off += u.numel()
             recs[1 - (code & 1)].append(struct.pack("<QQiiii", p.data_ptr(), u.data_ptr(), p.shape[0], 9, p.shape[1], code))
             self.umap[(ptr, code)] = u
@@ -599,17 +602,16 @@ def _split_for(w, mode):
     6: the transpose, for the input gradient): made by one small launch per call on this per-layer path (the launch
     programs of avid_hip.plan keep every layer's in their per-step table).  Same terms either way: bit-identical results."""
     key = (w.data_ptr(), tuple(w.shape), mode)
-    hit = _SPLIT_CACHE.get(key)
-    if hit is None:
-        k = _kdims(w)
+    planes = _SPLIT_CACHE.get(key)
+    if planes is None:
         planes = torch.empty(6 * w.numel(), dtype=torch.uint8, device=w.device)
-        rec = struct.pack("<QQiiii", w.data_ptr(), planes.data_ptr(), w.shape[0], k[0] * k[1] * k[2], w.shape[1], mode)
-        hit = (planes, torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(w.device))
         if len(_SPLIT_CACHE) >= 1024:
             _SPLIT_CACHE.clear()
-        _SPLIT_CACHE[key] = hit
-    lib.call("avid_weight_transpose_batched", 1, _p(hit[1]), w.numel(), _stream())
-    return hit[0]
+        _SPLIT_CACHE[key] = planes
+    k = _kdims(w)
+    desc = lib.WtDesc(w.data_ptr(), planes.data_ptr(), w.shape[0], k[0] * k[1] * k[2], w.shape[1], mode)
+    lib.call("avid_weight_transform", C.addressof(desc), _stream())
+    return planes
 
 
 def _fwd_u(w, d, plain=True):

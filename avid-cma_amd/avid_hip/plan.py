@@ -183,7 +183,7 @@ class Builder:
         if key not in self.wt_off:
             self.wt_off[key] = self.aux_size
             self.wt_recs.append((w, self.aux_size, w.shape[0], 9, w.shape[1], code))
-            self.aux_size += _align(4 * 16 * w.shape[0] * w.shape[1])
+            self.aux_size += _align(4 * ops.U_FLOATS * w.shape[0] * w.shape[1])
         return (S_AUX, self.wt_off[key])
 
     def want_split(self, w, mode):

@@ -93,12 +93,59 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return base + pos;
 }
 
+// wino2_kernel computes its products as split-bf16 (three bf16 terms per operand, six v_mfma_f32_32x32x16_bf16 per product
+// block: DESIGN.md 8e) and reads U already split; -DAVID_W2_FP32 (every source file) builds the fp32 instruction instead.
+#ifdef AVID_W2_FP32
+constexpr bool W2_SPLIT = false;
+#else
+constexpr bool W2_SPLIT = true;
+#endif
+
+// (x0, x1) -> three packed bf16 pairs h, m, l (element 0 in the low half) with x = h + m + l to fp32 accuracy: h = bf16(x),
+// m = bf16(x - h), l = bf16(x - h - m), round to nearest even.  Plain vector code on purpose — v_cvt_pk_bf16_f32, v_lshl /
+// v_and, v_add: as inline assembly the same instructions came out with a wait state behind every packed subtraction
+// and could not be moved by the scheduler (wino2_kernel: 160 -> 146 us on conv2x).
+typedef float floatx2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_bf16(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const floatx2_t x = {x0, x1};
+  const bf16x2_t hb = __builtin_convertvector(x, bf16x2_t);
+  const floatx2_t r = x - __builtin_convertvector(hb, floatx2_t);
+  const bf16x2_t mb = __builtin_convertvector(r, bf16x2_t);
+  const floatx2_t t = r - __builtin_convertvector(mb, floatx2_t);
+  const bf16x2_t lb = __builtin_convertvector(t, bf16x2_t);
+  h = __builtin_bit_cast(unsigned, hb);
+  m = __builtin_bit_cast(unsigned, mb);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+
+// The same split with the conversions as inline assembly (the subtractions stay scalar): what the kernels with two
+// waves per SIMD and their own instruction interleave run faster with (same box: stem_wgrad3_kernel 0.567 against 0.611
+// ms, stem_fwd3_kernel 0.629 / 0.649, wgrad_tab_kernel 0.337 / 0.356; igemm_pk_kernel and wino2_kernel prefer the form above).
+__device__ __forceinline__ void split2_bf16_asm(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m) : "v"(r0), "v"(r1));
+  const float t0 = r0 - __uint_as_float(m << 16), t1 = r1 - __uint_as_float(m & 0xffff0000u);
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l) : "v"(t0), "v"(t1));
+}
+
+// x = h + m + l to fp32 accuracy, each term a bf16 (round to nearest even): the scalar form of the packed splits in
+// conv.hip / stem.hip / wino.hip (same instruction, same roundings)
+__device__ __forceinline__ void split3_bf16(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+  unsigned ph, pm, pl;
+  split2_bf16(x, 0.f, ph, pm, pl);
+  h = (unsigned short)ph; m = (unsigned short)pm; l = (unsigned short)pl;
+}
+
 // U[(xi * Cn + n) * Cr + k] = (G g G^T)[xi / 4][xi % 4],  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], for the elements
 // i = first, first + stride, ... of the Cn x Cr (n, k) pairs.  flip = 0: g[a][b] = w[n][a][b][k] (forward); flip = 1:
 // g[a][b] = w[k][2-a][2-b][n] (input gradient).  Shared by wino_weight_kernel and weight_transpose_batched_kernel.
 // U in the operand-fragment order of the kernel that consumes it (one contiguous KB per wave load instruction):
 // frag = 2 (wino_kernel):  U[xi][n / 32][k / 32][q = (k % 16) / 4][lane = 32 ((k % 32) / 16) + n % 32][k % 4]
 // frag = 1 (wino2_kernel): U[xi][n / 64][(n % 64) / 32][k / 16][q = (k % 8) / 4][lane = 32 ((k % 16) / 8) + n % 32][k % 4]
+// frag = 3 (wino2_kernel, split-bf16): bf16 U[xi][n / 64][(n % 64) / 32][k / 16][term: hi, mid, lo][lane = 32 ((k % 16) / 8) + n % 32][k % 8]
+//           (6 bytes per element: 16 * Cn * Cr * 6 bytes in all)
 __device__ __forceinline__ void wino_weight_elements(const float* __restrict__ w, float* __restrict__ U, int Cn, int Cr, int Cin, int flip,
                                      long long first, long long stride, int frag) {
   for (long long i = first; i < (long long)Cn * Cr; i += stride) {
@@ -123,6 +170,21 @@ __device__ __forceinline__ void wino_weight_elements(const float* __restrict__ w
                   u3 = t[a][2];
       const long long st = (long long)Cn * Cr;
       long long o;
+      if (frag == 3) {
+        unsigned short* U16 = reinterpret_cast<unsigned short*>(U);
+        const long long blk = ((long long)(n >> 6) * 2 + ((n >> 5) & 1)) * (Cr >> 4) + (k >> 4);
+        const long long o16 = (long long)(a * 4) * st * 3 + blk * 1536 + ((((k & 15) >> 3) * 32 + (n & 31)) << 3) + (k & 7);
+        const float uu[4] = {u0, u1, u2, u3};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          unsigned short th, tm, tl;
+          split3_bf16(uu[b], th, tm, tl);
+          U16[o16 + b * st * 3] = th;
+          U16[o16 + b * st * 3 + 512] = tm;
+          U16[o16 + b * st * 3 + 1024] = tl;
+        }
+        continue;
+      }
       if (frag == 2) {
         const int kk = k & 31;
         o = (long long)(a * 4) * st +

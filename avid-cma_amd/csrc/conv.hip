@@ -404,14 +404,7 @@ __device__ __forceinline__ void pk_split8(const floatx4& v0, const floatx4& v1, 
   const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
   unsigned h[4], m[4], l[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float x0 = v[2 * i], x1 = v[2 * i + 1];
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h[i]) : "v"(x0), "v"(x1));
-    const float r0 = x0 - __uint_as_float(h[i] << 16), r1 = x1 - __uint_as_float(h[i] & 0xffff0000u);
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m[i]) : "v"(r0), "v"(r1));
-    const float t0 = r0 - __uint_as_float(m[i] << 16), t1 = r1 - __uint_as_float(m[i] & 0xffff0000u);
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l[i]) : "v"(t0), "v"(t1));
-  }
+  for (int i = 0; i < 4; ++i) split2_bf16(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
   fh = __builtin_bit_cast(pk_bf16x8, pk_uintx4{h[0], h[1], h[2], h[3]});
   fm = __builtin_bit_cast(pk_bf16x8, pk_uintx4{m[0], m[1], m[2], m[3]});
   fl = __builtin_bit_cast(pk_bf16x8, pk_uintx4{l[0], l[1], l[2], l[3]});
@@ -1517,14 +1510,7 @@ typedef unsigned wg_uintx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& fh, wg_bf16x8& fm, wg_bf16x8& fl) {
   unsigned h[4], m[4], l[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float x0 = v[2 * i], x1 = v[2 * i + 1];
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h[i]) : "v"(x0), "v"(x1));
-    const float r0 = x0 - __uint_as_float(h[i] << 16), r1 = x1 - __uint_as_float(h[i] & 0xffff0000u);
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m[i]) : "v"(r0), "v"(r1));
-    const float t0 = r0 - __uint_as_float(m[i] << 16), t1 = r1 - __uint_as_float(m[i] & 0xffff0000u);
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l[i]) : "v"(t0), "v"(t1));
-  }
+  for (int i = 0; i < 4; ++i) split2_bf16_asm(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
   fh = __builtin_bit_cast(wg_bf16x8, wg_uintx4{h[0], h[1], h[2], h[3]});
   fm = __builtin_bit_cast(wg_bf16x8, wg_uintx4{m[0], m[1], m[2], m[3]});
   fl = __builtin_bit_cast(wg_bf16x8, wg_uintx4{l[0], l[1], l[2], l[3]});
@@ -2008,9 +1994,7 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
 // all weights of a model in one launch: blockIdx.y picks the descriptor; a block walks 32(co) x 32(ci) tiles of
 // one tap through LDS so that both the read (rows of ci) and the write (rows of co) are contiguous — the
 // element-wise version read with a stride of taps*Cin floats between lanes and took 0.19 ms per step
-__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const avid_wt_desc* __restrict__ descs) {
-  __shared__ float tile[32][33];
-  const avid_wt_desc d = descs[blockIdx.y];
+__device__ __forceinline__ void weight_transform_body(const avid_wt_desc& d, float (*tile)[33]) {
   if (d.mode >= 5) {     // three-bf16-term split in igemm_pk_kernel<.., BS>'s fragment order: 5 of w, 6 of its transpose
     const int N = d.mode == 5 ? d.Cout : d.Cin, C = d.mode == 5 ? d.Cin : d.Cout;   // operand rows, channels per tap
     const int c8 = C / 8, cpt = C / 32, ntn = N / 64;
@@ -2049,7 +2033,7 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const avi
   if (d.mode != 0) {     // Winograd-transformed weights of a 3x3 layer (wino.hip): mode 1 / 3 forward, 2 / 4 input gradient;
     const bool fwd = d.mode & 1;       // 1, 2 in wino_kernel's fragment order, 3, 4 in wino2_kernel's
     wino_weight_elements(d.w, d.wt, fwd ? d.Cout : d.Cin, fwd ? d.Cin : d.Cout, d.Cin, !fwd,
-                         (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, d.mode <= 2 ? 2 : 1);
+                         (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, d.mode <= 2 ? 2 : (W2_SPLIT ? 3 : 1));
     return;
   }
   const int tco = (d.Cout + 31) / 32, tci = (d.Cin + 31) / 32;
@@ -2073,6 +2057,18 @@ __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const avi
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const avid_wt_desc* __restrict__ descs) {
+  __shared__ float tile[32][33];
+  const avid_wt_desc d = descs[blockIdx.y];
+  weight_transform_body(d, tile);
+}
+
+// one descriptor, passed by value (no table in device memory: usable inside a stream capture)
+__global__ __launch_bounds__(256) void weight_transform_kernel(const avid_wt_desc d) {
+  __shared__ float tile[32][33];
+  weight_transform_body(d, tile);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2974,6 +2970,19 @@ extern "C" int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_de
   if (gx > 256) gx = 256;
   hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, s, descs_dev);
   return check_launch("weight_transpose_batched");
+}
+
+extern "C" int avid_weight_transform(const avid_wt_desc* desc, avid_stream_t stream) {
+  AVID_REQUIRE(desc && desc->w && desc->wt && desc->Cout > 0 && desc->Cin > 0 && desc->ntaps > 0 && desc->mode >= 0 && desc->mode <= 6,
+               AVID_E_BADARG, "weight_transform: bad descriptor");
+  AVID_REQUIRE(desc->mode < 5 || (desc->mode == 5 ? desc->Cout % 64 == 0 && desc->Cin % 32 == 0 : desc->Cin % 64 == 0 && desc->Cout % 32 == 0),
+               AVID_E_UNSUPPORTED, "weight_transform: mode %d needs 64 | rows and 32 | channels", desc->mode);
+  hipStream_t s = (hipStream_t)stream;
+  ScopedTimer t(s, "weight_transform_kernel", 0.0, 0.0);
+  long long gx = ceil_div((long long)desc->Cout * desc->ntaps * desc->Cin, 1024);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(weight_transform_kernel, dim3((unsigned)gx), dim3(256), 0, s, *desc);
+  return check_launch("weight_transform");
 }
 
 // rows of BatchNorm-backward partial sums a dgrad of this layer writes (0: this layer cannot — strided, or not on

@@ -305,17 +305,8 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned uintx4_t __attribute__((ext_vector_type(4)));
 constexpr int S3_STEP_BYTES = 2 * 3 * 1024;     // weight fragments of one k-step: 2 column tiles x (hi | mid | lo) x 1 KB
 
-__device__ __forceinline__ unsigned s3_cvt_pk(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 __device__ __forceinline__ void s3_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  h = s3_cvt_pk(x0, x1);
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-  m = s3_cvt_pk(r0, r1);
-  const float t0 = r0 - __uint_as_float(m << 16), t1 = r1 - __uint_as_float(m & 0xffff0000u);
-  l = s3_cvt_pk(t0, t1);
+  split2_bf16_asm(x0, x1, h, m, l);
 }
 
 // Wf[s][tile][plane][lane][e]: element e of lane (j = lane & 31, g = lane >> 5) = w[n = 32 tile + j][row 2s + (e >> 2)][dw = g + 2 (e & 3)]

@@ -429,6 +429,18 @@ constexpr int W2_T0 = AVID_W2_T0;
 #define AVID_W2_STAGGER 1
 #endif
 constexpr int W2_TB = 64, W2_CK = 16;
+typedef __bf16 w2_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned w2_uintx4 __attribute__((ext_vector_type(4)));
+// 8 fp32 values -> three bf16x8 fragments (hi, mid, lo: common.h split2_bf16)
+__device__ __forceinline__ void w2_split8(const floatx4& v0, const floatx4& v1, w2_bf16x8& fh, w2_bf16x8& fm, w2_bf16x8& fl) {
+  const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) split2_bf16(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+  fh = __builtin_bit_cast(w2_bf16x8, w2_uintx4{h[0], h[1], h[2], h[3]});
+  fm = __builtin_bit_cast(w2_bf16x8, w2_uintx4{m[0], m[1], m[2], m[3]});
+  fl = __builtin_bit_cast(w2_bf16x8, w2_uintx4{l[0], l[1], l[2], l[3]});
+}
 constexpr int W2_STAGE = 16 * W2_TB * W2_CK;                 // floats per stage
 constexpr int W2_TAB_OFF = 2 * W2_STAGE;                     // three tile tables of 64 x int4
 constexpr int W2_LDS_FLOATS = W2_TAB_OFF + 3 * W2_TB * 4;
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(256) void wino2_kernel(const WinoArgs p) {
   const int H = p.H, W = p.W, TW = p.TW, TPF = p.TH * p.TW, Cr = p.Cr, Cn = p.Cn;
   const __amdgpu_buffer_rsrc_t rsX =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((long long)p.F * H * W * Cr * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, 16 * Cn * Cr * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, 16 * Cn * Cr * (W2_SPLIT ? 6 : 4), 0x00020000);
   const int dbytes = (int)((long long)p.F * H * W * Cn * 4);
   const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst, 0, dbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI & 2) ? p.addend : p.src), 0, (EPI & 2) ? dbytes : 0, 0x00020000);
@@ -531,16 +543,23 @@ __global__ __launch_bounds__(256) void wino2_kernel(const WinoArgs p) {
   const int ptile = 32 * th + l31;
   const int psw = (l31 >> 2) & 3;
   const int rd_off0 = ptile * W2_CK + (((2 * h) ^ psw) << 2), rd_off1 = ptile * W2_CK + (((2 * h + 1) ^ psw) << 2);
-  // U in fragment order (wino_weight_elements, frag = 1): one contiguous KB per load instruction
-  const unsigned u_voff = (unsigned)(lane * 16), u_voff2 = u_voff + 1024u;
-  const int u_xi = Cn * Cr * 4;
+  // U in fragment order (wino_weight_elements, frag = 1; split-bf16: frag = 3, three terms): one contiguous KB per load
+  // instruction, UP of them per (transform point, 32 output channels, chunk)
+  constexpr int UP = W2_SPLIT ? 3 : 2;
+  const unsigned u_voff = (unsigned)(lane * 16);
+  const int u_xi = Cn * Cr * (W2_SPLIT ? 6 : 4);
   // (nh is wave-uniform, which the compiler cannot see: without readfirstlane every U load sits in a waterfall loop)
-  const int u_base = __builtin_amdgcn_readfirstlane((cb * 2 + nh) * nchunks * 2048), u_ck = 2048;
-  floatx4 bv[4][2], av[2][2];
+  const int u_ck = UP * 1024;
+  const int u_base = __builtin_amdgcn_readfirstlane((cb * 2 + nh) * nchunks * u_ck);
+  floatx4 bv[4][UP], av[2][2];
   auto load_u = [&](int slot, int xi, int ck) {
-    bv[slot][0] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsU, u_voff, u_base + xi * u_xi + ck * u_ck, 0));
-    bv[slot][1] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsU, u_voff2, u_base + xi * u_xi + ck * u_ck, 0));
+#pragma unroll
+    for (int q = 0; q < UP; ++q)
+      bv[slot][q] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsU, u_voff + 1024u * q, u_base + xi * u_xi + ck * u_ck, 0));
   };
+  // split-bf16: the lane's 8 V values of a transform point (channels 8 h .. 8 h + 7 of its tile) as three bf16x8 fragments
+  w2_bf16x8 vs[2][3];
+  auto split_v = [&](int slot) { w2_split8(av[slot][0], av[slot][1], vs[slot][0], vs[slot][1], vs[slot][2]); };
   auto read_v = [&](const float* Vst, int slot, int xi) {
     av[slot][0] = *reinterpret_cast<const floatx4*>(Vst + xi * (W2_TB * W2_CK) + rd_off0);
     av[slot][1] = *reinterpret_cast<const floatx4*>(Vst + xi * (W2_TB * W2_CK) + rd_off1);
@@ -591,10 +610,19 @@ __global__ __launch_bounds__(256) void wino2_kernel(const WinoArgs p) {
     const float* Vst = sm + stage * W2_STAGE;
     float* Wst = sm + (stage ^ 1) * W2_STAGE;
     read_v(Vst, 0, 0);
+    if (W2_SPLIT) {
+      read_v(Vst, 1, 1);
+      split_v(0);
+    }
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) {
       if (!(W2_DBG & 4)) { if (xi + 3 < 16) load_u((xi + 3) & 3, xi + 3, ck); else load_u((xi + 3) & 3, xi + 3 - 16, ck_n); }
-      if (!(W2_DBG & 16) && xi + 1 < 16) read_v(Vst, (xi + 1) & 1, xi + 1);
+      if (W2_SPLIT) {     // V of point xi + 1 is split beside the products of xi, V of xi + 2 is on its way from LDS
+        if (xi + 1 < 16) split_v((xi + 1) & 1);
+        if (xi + 2 < 16) read_v(Vst, xi & 1, xi + 2);
+      } else if (!(W2_DBG & 16) && xi + 1 < 16) {
+        read_v(Vst, (xi + 1) & 1, xi + 1);
+      }
       if (!(W2_DBG & 2) && FIRST && xi < 4) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) ld_issue(xi, b);
@@ -611,13 +639,30 @@ __global__ __launch_bounds__(256) void wino2_kernel(const WinoArgs p) {
           if (k < n) ld_issue((base + k) >> 2, (base + k) & 3);
         if (j == 5) ld_advance();
       }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (FIRST && e == 0) {
+      if (W2_SPLIT) {
+        const w2_bf16x8 uh = __builtin_bit_cast(w2_bf16x8, bv[xi & 3][0]), um = __builtin_bit_cast(w2_bf16x8, bv[xi & 3][1]),
+                        ul = __builtin_bit_cast(w2_bf16x8, bv[xi & 3][UP - 1]);
+        const w2_bf16x8 vh = vs[xi & 1][0], vm = vs[xi & 1][1], vl = vs[xi & 1][2];
+        if (FIRST) {
           const floatx16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[xi & 3][0][0], av[xi & 1][0][0], z16, 0, 0, 0);
+          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vl, z16, 0, 0, 0);
         } else {
-          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[xi & 3][e >> 2][e & 3], av[xi & 1][e >> 2][e & 3], acc[xi], 0, 0, 0);
+          acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vl, acc[xi], 0, 0, 0);
+        }
+        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, vh, acc[xi], 0, 0, 0);
+        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vm, acc[xi], 0, 0, 0);
+        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vm, acc[xi], 0, 0, 0);
+        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vh, acc[xi], 0, 0, 0);
+        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vh, acc[xi], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (FIRST && e == 0) {
+            const floatx16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[xi & 3][0][0], av[xi & 1][0][0], z16, 0, 0, 0);
+          } else {
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[xi & 3][e >> 2][e & 3], av[xi & 1][e >> 2][e & 3], acc[xi], 0, 0, 0);
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1103,9 +1148,9 @@ bool wino_supported(const avid_conv_desc* d, int mode) {
   return big < (1ll << 31);
 }
 
-size_t wino_ws_bytes(const avid_conv_desc* d, int mode) {
+size_t wino_ws_bytes(const avid_conv_desc* d, int mode) {   // U: 16 transform points x 4 bytes, or x 6 (three bf16 terms)
   (void)mode;
-  return sizeof(float) * 16 * (size_t)d->Cin * d->Cout;
+  return (size_t)96 * d->Cin * d->Cout;
 }
 
 // wino2_kernel (one workgroup per CU, 64-tile units) where the layer has at least 1.5 rounds of units for the CUs
@@ -1187,7 +1232,8 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
     a.U = U;
     const long long n = (long long)a.Cn * a.Cr;
     ScopedTimer t(s, "wino_weight_kernel", 0.0, 4.0 * n * 25);
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, w, U, a.Cn, a.Cr, d->Cin, mode, a.v2 ? 1 : 2);
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, w, U, a.Cn, a.Cr, d->Cin, mode,
+                       a.v2 ? (W2_SPLIT ? 3 : 1) : 2);
     rc = check_launch("wino_weight");
     if (rc) return rc;
   }

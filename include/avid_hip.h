@@ -128,7 +128,8 @@ typedef struct avid_wt_desc {
   float* wt;
   int32_t Cout, ntaps, Cin;
   int32_t mode; /* 0: wt[Cin][taps][Cout]; 3x3 layers on the Winograd path (ntaps = 9): wt = the 16 x Cout x Cin transformed
-                   weights U in the operand-fragment order of the kernel that will read them — 1 / 3: for the forward
+                   weights U in the operand-fragment order (and element format: fp32, or three bf16 terms) of the kernel that
+                   will read them, a buffer of 96 * Cout * Cin bytes whatever the format — 1 / 3: for the forward
                    (pass it as `u` to avid_conv_fwd), 2 / 4: with flipped taps and swapped channel roles for the input
                    gradient (pass it as `u` to avid_conv_dgrad); 1, 2 for wino_kernel, 3, 4 for wino2_kernel
                    (avid_conv_uses_wino says which of the two a layer runs on);
@@ -139,6 +140,9 @@ typedef struct avid_wt_desc {
                    Cin % 64 == 0 and Cout % 32 == 0 (6) */
 } avid_wt_desc;
 int avid_weight_transpose_batched(int n, const avid_wt_desc* descs_dev, int64_t max_elems, avid_stream_t stream);
+/* The same for ONE descriptor in HOST memory (passed to the kernel by value: nothing to upload, legal inside a stream
+ * capture) — what a per-layer caller without a per-step table uses. */
+int avid_weight_transform(const avid_wt_desc* desc, avid_stream_t stream);
 
 /* Which kernel instantiation a descriptor dispatches to (which: 0 fwd, 1 dgrad, 2 wgrad), e.g.
  * "igemm_kernel<4,1,1,2,1>" — lets bench.py attribute HIP-event timings to rocprofv3 kernel names. */

@@ -55,4 +55,6 @@ def test_kernel_switches_agree_to_summation_noise(default_run, env):
     a, b = np.array(got["grad_probe"]), np.array(default_run["grad_probe"])
     # (a different convolution algorithm flips a few near-zero ReLU inputs / pooling near-ties; the gradients of the earliest
     #  layers see every one of them: per-layer parity is pinned in test_gpu_ops.py / test_gpu_model.py)
-    assert np.abs(a - b).max() <= (2e-2 if "AVID_WINO" in env else 1e-3) * np.abs(b).max() + 1e-7
+    #  (the stem's switch changes the roundings of the first layer, i.e. the input of every other one)
+    loose = "AVID_WINO" in env or "AVID_STEM_BF16X3" in env
+    assert np.abs(a - b).max() <= (2e-2 if loose else 1e-3) * np.abs(b).max() + 1e-7

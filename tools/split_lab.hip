@@ -44,6 +44,83 @@ __device__ __forceinline__ void split_trunc(const float (&v)[8], bf16x8& fh, bf1
   fl = __builtin_bit_cast(bf16x8, uintx4{l[0], l[1], l[2], l[3]});
 }
 
+__device__ __forceinline__ floatx2 pk_sub(floatx2 a, floatx2 b) {
+  floatx2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// RNE split with packed subtractions: 36 instructions (w2_split8 of wino.hip)
+__device__ __forceinline__ void split_pk(const float (&v)[8], bf16x8& fh, bf16x8& fm, bf16x8& fl) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const floatx2 x = {v[2 * i], v[2 * i + 1]};
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h[i]) : "v"(x[0]), "v"(x[1]));
+    const floatx2 r = pk_sub(x, floatx2{__uint_as_float(h[i] << 16), __uint_as_float(h[i] & 0xffff0000u)});
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m[i]) : "v"(r[0]), "v"(r[1]));
+    const floatx2 t = pk_sub(r, floatx2{__uint_as_float(m[i] << 16), __uint_as_float(m[i] & 0xffff0000u)});
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l[i]) : "v"(t[0]), "v"(t[1]));
+  }
+  fh = __builtin_bit_cast(bf16x8, uintx4{h[0], h[1], h[2], h[3]});
+  fm = __builtin_bit_cast(bf16x8, uintx4{m[0], m[1], m[2], m[3]});
+  fl = __builtin_bit_cast(bf16x8, uintx4{l[0], l[1], l[2], l[3]});
+}
+
+// software-pipelined: the split of step u + 1 sits between the six MFMAs of step u.  PAIR: two accumulators alternate
+// (no MFMA waits for the previous one's result); HINT: sched_group_barrier 1 MFMA : 6 VALU
+template <bool PAIR, bool HINT>
+__global__ __launch_bounds__(256) void kp(float* out, const float* in, int iters) {
+  const int tid = threadIdx.x;
+  float v[8];
+  for (int i = 0; i < 8; ++i) v[i] = in[(tid * 8 + i) & 4095];
+  floatx16 acc0, acc1;
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  bf16x8 bh, bm, bl, ah[2], am[2], al[2];
+  split_pk(v, bh, bm, bl);
+  split_pk(v, ah[0], am[0], al[0]);
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = u & 1, n = c ^ 1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[i]) : "v"(1e-3f));
+      split_pk(v, ah[n], am[n], al[n]);
+      floatx16& acc = (PAIR && c) ? acc1 : acc0;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[c], bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[c], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], bh, acc, 0, 0, 0);
+      if (HINT) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+  if (s == 1234.5f) out[tid] = s;
+}
+
+template <bool PAIR, bool HINT>
+static float time_p(float* out, const float* in, int iters) {
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL((kp<PAIR, HINT>), dim3(256), dim3(256), 0, 0, out, in, iters);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((kp<PAIR, HINT>), dim3(256), dim3(256), 0, 0, out, in, iters);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms;
+}
+
 // KIND: 0 cvt split only, 1 trunc split only, 2 six MFMAs only, 3 cvt split + MFMAs, 4 trunc split + MFMAs
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters) {
@@ -130,5 +207,10 @@ int main() {
   const char* names[] = {"split cvt alone", "split trunc alone", "6 MFMA alone", "split cvt + 6 MFMA", "split trunc + 6 MFMA"};
   float t[5] = {time_it<0>(out, in, iters), time_it<1>(out, in, iters), time_it<2>(out, in, iters), time_it<3>(out, in, iters), time_it<4>(out, in, iters)};
   for (int i = 0; i < 5; ++i) printf("%-22s %8.3f ms  %7.1f ns per step (8 values%s)\n", names[i], t[i], t[i] * 1e6 / (iters * 4.0), i >= 2 ? ", 6 MFMA = 192 matrix cycles" : "");
+  printf("pipelined (split of the next step between this step's MFMAs), 36-instruction split:\n");
+  printf("  one accumulator          %7.1f ns per step\n", time_p<false, false>(out, in, iters) * 1e6 / (iters * 4.0));
+  printf("  one accumulator, hints   %7.1f ns per step\n", time_p<false, true>(out, in, iters) * 1e6 / (iters * 4.0));
+  printf("  two accumulators         %7.1f ns per step\n", time_p<true, false>(out, in, iters) * 1e6 / (iters * 4.0));
+  printf("  two accumulators, hints  %7.1f ns per step\n", time_p<true, true>(out, in, iters) * 1e6 / (iters * 4.0));
   return 0;
 }
