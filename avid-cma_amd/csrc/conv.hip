@@ -1979,6 +1979,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_scatter_kernel(const float* 
   reinterpret_cast<floatx4*>(dw)[i] = s;
 }
 
+// dx of a strided 1x1x1 convolution (the blocks' residual convolution, models/network_blocks.py:49) from its COMPACT
+// form: the dense input gradient over the sub-sampled grid [B][To][Ho][Wo][C] lands at the positions divisible by the
+// strides, every other position is zero (+ the addend everywhere).  One 16-byte item per thread; HBM-bound on writing dx.
+__global__ __launch_bounds__(256) void dx_scatter_strided_kernel(const float* __restrict__ compact, const float* __restrict__ addend,
+                                                                 float* __restrict__ dx, long long n4, int c4, int Ti, int Hi, int Wi,
+                                                                 int To, int Ho, int Wo, int st, int sh, int sw) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % c4);
+    long long r = i / c4;
+    const int w = (int)(r % Wi); r /= Wi;
+    const int h = (int)(r % Hi); r /= Hi;
+    const int t = (int)(r % Ti);
+    const long long b = r / Ti;
+    floatx4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t % st == 0 && h % sh == 0 && w % sw == 0)
+      v = reinterpret_cast<const floatx4*>(compact)[((((b * To + t / st) * Ho + h / sh) * Wo + w / sw)) * c4 + c];
+    if (addend) v += reinterpret_cast<const floatx4*>(addend)[i];
+    reinterpret_cast<floatx4*>(dx)[i] = v;
+  }
+}
+
 // w[co][tap][ci] -> wT[ci][tap][co]
 __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int ntaps, int Ci) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2947,8 +2968,28 @@ static size_t dgrad_wt_bytes(const avid_conv_desc* d) {
   return (sizeof(float) * (size_t)d->Cout * d->kt * d->kh * d->kw * d->Cin + 255) / 256 * 256;
 }
 
+// A strided 1x1x1 layer's input gradient as a dense problem over the sub-sampled grid + a scatter (standalone calls only:
+// inside a block the residual convolution's gradient rides compact in spt_conv1's input gradient, see add_s)
+static bool dgrad_compactable(const avid_conv_desc* d) {
+  return d->kt == 1 && d->kh == 1 && d->kw == 1 && (d->st > 1 || d->sh > 1 || d->sw > 1) && d->pt == 0 && d->ph == 0 &&
+         d->pw == 0 && !d->x_channel_first && d->Cin % 4 == 0;
+}
+static avid_conv_desc dgrad_compact_desc(const avid_conv_desc* d) {
+  avid_conv_desc c = *d;
+  c.Ti = d->To; c.Hi = d->Ho; c.Wi = d->Wo;
+  c.st = c.sh = c.sw = 1;
+  return c;
+}
+static size_t dgrad_compact_bytes(const avid_conv_desc* d) {
+  return (sizeof(float) * (size_t)d->B * d->To * d->Ho * d->Wo * d->Cin + 255) / 256 * 256;
+}
+
 extern "C" size_t avid_conv_dgrad_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
+  if (dgrad_compactable(d)) {
+    const avid_conv_desc c = dgrad_compact_desc(d);
+    return dgrad_compact_bytes(d) + avid_conv_dgrad_workspace_bytes(&c);
+  }
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
   const int nk = trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK);
   size_t fl = igemm_ws_floats(M, d->Cin, nk, 1);
@@ -3039,6 +3080,20 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
   AVID_REQUIRE(d->st <= 2 && d->sh <= 2 && d->sw <= 2, AVID_E_UNSUPPORTED, "conv_dgrad: stride > 2");
   AVID_REQUIRE(ws_bytes >= dgrad_wt_bytes(d), AVID_E_BADARG, "conv_dgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
+  if (dgrad_compactable(d) && !bn && !sparse_add && ws_bytes >= avid_conv_dgrad_workspace_bytes(d)) {
+    const avid_conv_desc c = dgrad_compact_desc(d);
+    float* compact = static_cast<float*>(ws);
+    const size_t cb = dgrad_compact_bytes(d);
+    rc = avid_conv_dgrad(&c, dy, w, wt_in, u, nullptr, nullptr, compact, nullptr, static_cast<char*>(ws) + cb, ws_bytes - cb, stream);
+    if (rc) return rc;
+    const long long n4 = (long long)d->B * d->Ti * d->Hi * d->Wi * (d->Cin / 4);
+    long long grid = ceil_div(n4, 256 * 4);
+    if (grid > 4096) grid = 4096;
+    ScopedTimer t(s, "dx_scatter_strided_kernel", 0.0, 16.0 * n4 * (1 + (addend ? 1 : 0)) + 16.0 * n4 / (d->st * d->sh * d->sw));
+    hipLaunchKernelGGL(dx_scatter_strided_kernel, dim3((unsigned)grid), dim3(256), 0, s, compact, addend, dx, n4, d->Cin / 4, d->Ti,
+                       d->Hi, d->Wi, d->To, d->Ho, d->Wo, d->st, d->sh, d->sw);
+    return check_launch("dx_scatter_strided");
+  }
   if (wino_supported(d, 1) && !sparse_add && (u || ws_bytes >= wino_ws_bytes(d, 1)))
     return wino_conv(d, 1, dy, w, u, dx, addend, nullptr, bn, ws, s);   // (u: this layer's pre-transformed weights)
   const int ntaps = d->kt * d->kh * d->kw;
