@@ -109,6 +109,7 @@ class Builder:
         self.S = ST_MAIN                           # compute stream of the records being emitted
         self.pending = {ST_MAIN: [], ST_AUDIO: []}  # queued weight gradients per compute stream
         self.trail_used = set()
+        self.tables_waited = set()                 # streams whose forward has waited for the weight-transform launch
         self.wt, self.wt_off = {}, {}              # transposed weights / Winograd transforms: param slot -> aux offset
         self.aux_size = 0
         self.wt_recs = []                          # (param tensor, aux offset, Cout, taps, Cin, mode)
@@ -199,7 +200,18 @@ class Builder:
         return (S_AUX, self.wt_off[key])
 
     def fwd_u(self, w, d):
-        return self.want_split(w, 5) if d.split_fwd else None
+        """`u` of a forward convolution on stream self.S.  The pre-split weights (want_split mode 5) come out of the step's
+        weight-transform launch on the trailing stream, which is issued beside the video stem and starves behind its
+        persistent workgroups (parallel.py: forward_backward): the FIRST layer of a stream that reads a table waits for
+        that launch — on the video tower that is conv2x's temporal convolution, 0.2 ms behind the stem, and costs nothing;
+        a wait right behind the stem stalled the compute stream for the time the tables were late (10.07-10.3 against
+        10.03-10.09 ms per step on one box)."""
+        if not d.split_fwd:
+            return None
+        if self.trailing and self.S not in self.tables_waited:
+            self.wait(self.S, ST_TRAIL)
+            self.tables_waited.add(self.S)
+        return self.want_split(w, 5)
 
     def dgrad_wt_u(self, w, d):
         """(wt, u) of an input gradient: the Winograd transform, the pre-split transpose, or the plain transpose."""
@@ -434,10 +446,6 @@ class Builder:
                      self.ext(bn.num_batches_tracked), stats))
         stem = {"d": d, "w": w, "x": x, "y": y, "am": am, "s4": s4, "bn": bn, "dims": (B, T, H, W, Cc)}
         h = Sym(p, (B, T, Ho, Wo, Cc))
-        # the pre-split weights of the layers from here on (want_split mode 5) come from the step's weight-transform launch
-        # on the trailing stream, issued beside the stem
-        if self.trailing:
-            self.wait(ST_MAIN, ST_TRAIL)
         if after_stem is not None:
             after_stem()
         blocks = []
