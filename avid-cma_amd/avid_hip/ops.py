@@ -1362,14 +1362,14 @@ def cma_negatives(positive_set, y, rand_idx):
     return pos, neg
 
 
-def adam_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, step_dev=None, lr_dev=None):
+def adam_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, step_dev=None, lr_dev=None, advance=True):
     """``step_dev`` (optional 0-d int64 device tensor): advanced by one on the stream, then read by the
     kernel for the bias corrections (hipGraph-replay safe); otherwise ``step`` is used by value.
     ``lr_dev`` (optional 0-d fp32 device tensor): the learning rate is read from it (a captured graph freezes
     ``lr``; a scheduler writes the device word)."""
     _need_cuda(p, g, m, v)
     st = _stream()
-    if step_dev is not None:
+    if step_dev is not None and advance:     # (advance = False: a second launch of the same optimizer step over another slice)
         lib.call("avid_counter_add", _p(step_dev), 1, st)
     lib.call("avid_adam_flat", p.numel(), _p(p), _p(g), _p(m), _p(v), float(lr), float(beta1), float(beta2),
              float(eps), float(wd), int(step), _p(step_dev), _p(lr_dev), float(grad_scale), st)

@@ -298,6 +298,7 @@ class TrainStep:
     def _plan_backward(self, pl, fa, video, audio, dv, da):
         """The backward launch program of the model (called from its autograd node): in one piece, or — with gradient
         collectives — cut where a bucket becomes complete, so that its all-reduce starts under the rest of the pass."""
+        self._step_plan = pl
         if not self.buckets.comm or self.buckets._capturing():
             pl.backward(fa, video, audio, dv, da, self.flat.grad)
             return
@@ -401,6 +402,22 @@ class TrainStep:
                       self.eps, self.wd, self.t, grad_scale=1.0 / self.buckets.world, step_dev=self.t_dev,
                       lr_dev=self.lr_dev)
 
+    def _optimizer_step_overlapped(self, pl):
+        """The same update in two launches: every parameter but the video stem's three on the fourth stream, which the
+        backward program made wait for exactly their gradients (plan.Plan: ``adam_early``) — it runs beside the stem's
+        weight gradient, the step's last kernel — then the stem's on the compute stream.  Same arithmetic per element."""
+        from . import ops
+        self.t += 1
+        n0 = pl.adam_early
+        f, g, m, v = self.flat.flat, self.flat.grad, self.m, self.v
+        kw = dict(grad_scale=1.0 / self.buckets.world, step_dev=self.t_dev, lr_dev=self.lr_dev)
+        main, fourth = torch.cuda.current_stream(), pl.stream_objs[3]
+        with torch.cuda.stream(fourth):
+            ops.adam_flat(f[:n0], g[:n0], m[:n0], v[:n0], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t, **kw)
+        main.wait_stream(fourth)
+        ops.adam_flat(f[n0:], g[n0:], m[n0:], v[n0:], self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                      advance=False, **kw)
+
     # ---- optimizer / sampler state in torch.optim.Adam's format (main-avid.py:115,127,138 save and restore
     # ``optimizer.state_dict()``; utils/main_utils.py:250-261 builds Adam over model.parameters())
     def _param_order(self):
@@ -466,8 +483,13 @@ class TrainStep:
             ops.poll_device_errors(self.flat.flat.device)
 
     def step(self, video, audio, index):
+        self._step_plan = None
         loss = self.forward_backward(video, audio, index)
-        self.optimizer_step()
+        pl = self._step_plan
+        if pl is not None and pl.adam_early and not self.buckets.comm and not lib_timing():
+            self._optimizer_step_overlapped(pl)
+        else:
+            self.optimizer_step()
         self._poll_errors()
         return loss.detach()
 

@@ -578,12 +578,25 @@ class Plan:
         b.S = A_S
         da = b.head_bwd(self._AH, (S_DA, 0))
         b.audio_bwd(A, da)
-        b.S = ST_MAIN
-        b.video_stem_bwd(V, dh)
+        # Everything but the video stem's three parameters has its gradient here: the engine's optimizer can update those
+        # (nearly all of the 134 MB) on the fourth stream WHILE the stem's backward — one LDS-bound full-chip kernel of
+        # 0.57 ms on the trailing stream, the step's last — still runs (parallel.TrainStep.step; the HBM-bound Adam pass and
+        # that kernel overlap).  The fourth stream waits here for the three streams that hold those gradients.
         for S in (ST_MAIN, ST_AUDIO):
             b.S = S
             b.flush_group(S)
         b.S = ST_MAIN
+        self.adam_early = None
+        if trailing and A_S != ST_MAIN:
+            stem_conv, stem_bn = model.video_model.conv1[0], model.video_model.conv1[1]
+            idx = sorted(b.pindex[id(p)] for p in (stem_conv.weight, stem_bn.weight, stem_bn.bias))
+            n = len(b.params)
+            if idx == [n - 3, n - 2, n - 1]:                   # (the engine's flat layout: parameters in reverse order)
+                for S in (ST_MAIN, A_S, ST_TRAIL):
+                    b.wait(ST_COMM, S)
+                self.adam_early = b.goff[n - 3]
+        b.video_stem_bwd(V, dh)
+        b.flush_group(ST_MAIN)
         if A_S != ST_MAIN:
             b.wait(ST_MAIN, A_S)
         for tr in sorted(b.trail_used):

@@ -91,6 +91,34 @@ def test_engine_step_through_programs_is_bit_identical(gpu_device, bs, hw):
         assert torch.equal(sd0[k], sd1[k]), k
 
 
+def test_overlapped_optimizer_step_changes_nothing(gpu_device):
+    """TrainStep.step() updates everything but the video stem's three parameters on the fourth stream, beside the stem's
+    weight gradient, and the stem's afterwards (parallel._optimizer_step_overlapped): parameters, Adam moments and the
+    step counter after three steps are bit-identical to forward_backward() + optimizer_step()."""
+    from avid_hip.parallel import TrainStep
+    dev = gpu_device
+    video, audio, ids = _data(dev, bs=4, steps=3, hw=64)
+    out = []
+    for fused in (True, False):
+        m, crit = _model(dev), _crit(dev)
+        eng = TrainStep(m, crit)
+        used = []
+        for i in range(3):
+            if fused:
+                eng.step(video, audio, ids[i])
+                used.append(eng._step_plan is not None and bool(eng._step_plan.adam_early))
+            else:
+                eng.forward_backward(video, audio, ids[i])
+                eng.optimizer_step()
+        torch.cuda.synchronize()
+        if fused:
+            assert all(used), "step() did not take the overlapped optimizer path"
+        out.append((eng.flat.flat.clone(), eng.m.clone(), eng.v.clone(), int(eng.t_dev) if eng.t_dev is not None else eng.t))
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert torch.equal(a, b)
+    assert out[0][3] == out[1][3] == 3
+
+
 def test_reference_loop_through_programs(gpu_device):
     """main-avid.py:155-180 as written — model(), criterion(), loss.item(), zero_grad, backward, torch.optim.Adam.step —
     takes the program path (one autograd node for the model) and ends where the step engine ends: same losses, and the
