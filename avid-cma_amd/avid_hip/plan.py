@@ -178,8 +178,8 @@ class Builder:
             self.aux_size += _align(4 * w.numel())
         return (S_AUX, self.wt_off[key])
 
-    def want_u(self, w, variant):
-        code = 2 + 2 * (variant - 1)                 # input gradient in wino_kernel's (2) / wino2_kernel's (4) order
+    def want_u(self, w, variant, forward=False):
+        code = (1 if forward else 2) + 2 * (variant - 1)   # forward (1 / 3) or input gradient (2 / 4), wino_kernel's / wino2_kernel's order
         key = (id(w), code)
         if key not in self.wt_off:
             self.wt_off[key] = self.aux_size
@@ -206,6 +206,13 @@ class Builder:
         that launch — on the video tower that is conv2x's temporal convolution, 0.2 ms behind the stem, and costs nothing;
         a wait right behind the stem stalled the compute stream for the time the tables were late (10.07-10.3 against
         10.03-10.09 ms per step on one box)."""
+        if d.wino_fwd:
+            # a Winograd layer behind that wait takes its transformed weights from the same launch (mode 1 / 3) instead of
+            # transforming them in front of its own kernel (one 6 us launch per layer on the compute stream); the first
+            # one of the video tower sits right behind the stem and keeps its own
+            if self.trailing and self.S in self.tables_waited:
+                return self.want_u(w, d.wino_fwd, forward=True)
+            return None
         if not d.split_fwd:
             return None
         if self.trailing and self.S not in self.tables_waited:
