@@ -2157,38 +2157,6 @@ static int device_cus() {
   return cus;
 }
 
-// ---- tile / split-K plan (shared by the launcher, the workspace query and the name query)
-struct IgemmPlan {
-  int tile;    // 0: 128x128, 1: 128x64, 3: 64x64
-  int BM, BN;
-  int nsplit, ksteps_per_split;
-};
-static const char* kTileName[4] = {"2,2,2,2", "4,1,1,2", "1,4,1,1", "2,2,1,1"};
-
-static IgemmPlan plan_igemm(long long M, int Cd, int nk_total, bool allow_split) {
-  IgemmPlan pl;
-  const long long t128 = (M + 127) / 128;
-  if (Cd % 128 == 0 && t128 * (Cd / 128) >= 2 * 256) {
-    pl.tile = 0; pl.BM = 128; pl.BN = 128;       // plenty of work: the biggest tile
-  } else if (M > 64) {
-    pl.tile = 1; pl.BM = 128; pl.BN = 64;
-  } else {
-    pl.tile = 3; pl.BM = 64; pl.BN = 64;         // heads at tiny batch
-  }
-  const long long tiles = ((((M + pl.BM - 1) / pl.BM) + 1) / 2) * (Cd / pl.BN);  // workgroups (2 M-tiles each)
-  int ns = 1;
-  if (allow_split && tiles < 256) {              // fewer than one workgroup per CU: split GEMM-K
-    ns = (int)(2 * 256 / tiles);
-    const int max_ns = nk_total / 4 > 0 ? nk_total / 4 : 1;  // >= 4 k-steps per split
-    if (ns > max_ns) ns = max_ns;
-    if (ns > 64) ns = 64;
-    if (ns < 1) ns = 1;
-  }
-  pl.ksteps_per_split = (nk_total + ns - 1) / ns;
-  pl.nsplit = (nk_total + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
-  return pl;
-}
-
 template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
 static int launch_igemm(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -2237,7 +2205,6 @@ struct PkPlan {
   long long tail_row0;   // rows [tail_row0, M) are produced by splitk_reduce_kernel from f slabs
   size_t ws_floats;
 };
-static bool pk_enabled() { return true; }   // (the persistent kernel had an off switch while the plain one was the reference for it)
 static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_out, int mode) {
   PkPlan k{};
   const int cus = device_cus();
@@ -2386,30 +2353,6 @@ static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
   return check_launch("igemm_pk");
 }
 
-// Tail split of a launch with more workgroups than resident slots (see dispatch_igemm).
-struct TailPlan {
-  int tail_m, f;
-  long long tail_rows;
-};
-static TailPlan plan_tail(const IgemmPlan& pl, long long M, int Cd, int nk_total) {
-  TailPlan t{0, 1, 0};
-  if (pl.nsplit > 1) return t;
-  const int ntn = Cd / pl.BN;
-  const int mt2 = (int)(((M + pl.BM - 1) / pl.BM + 1) / 2);
-  const long long slots = (pl.tile == 0 ? 1 : 2) * device_cus();
-  const long long wgs = (long long)mt2 * ntn;
-  const int slots_m = (int)(slots / ntn);
-  if (wgs <= slots || slots_m <= 0) return t;
-  const int tail_m = mt2 % slots_m;
-  if (tail_m == 0) return t;
-  int f = (int)(slots / ((long long)tail_m * ntn));
-  if (f > nk_total / 3) f = nk_total / 3;
-  if (f < 2 || nk_total < 12) return t;   // short K loops: the extra prologue + slab pass costs more than the idle round
-  t.tail_m = tail_m;
-  t.f = f;
-  t.tail_rows = M - (long long)(mt2 - tail_m) * 2 * pl.BM;
-  return t;
-}
 
 // Parity-class table of a strided dgrad (strides are 1 or 2 per axis).
 static void build_classes(ConvArgs& a, int BM) {
@@ -2565,7 +2508,7 @@ static StridedPlan plan_strided(ConvArgs& k, int BM, int BN, size_t ws_floats) {
 
 template <int MODE>
 static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s) {
-  if (MODE == 1 && (a.st > 1 || a.sh > 1 || a.sw > 1) && pk_enabled() && (long long)a.M * a.Cd * 4 < (1ll << 31) &&
+  if (MODE == 1 && (a.st > 1 || a.sh > 1 || a.sw > 1) && (long long)a.M * a.Cd * 4 < (1ll << 31) &&
       a.st <= 2 && a.sh <= 2 && a.sw <= 2) {
     // strided dgrad on the persistent kernel: (class tile, K piece) units dealt round-robin, heavy classes first
     ConvArgs k = a;
@@ -2629,7 +2572,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
   }
   const int nk_total = a.kt * a.kh * a.kw * (a.Cs / BK);
   // Everything dense goes to the persistent kernel (whole rounds + K-split tail in one launch).
-  if (pk_enabled()) {
+  {
     PkPlan pk = plan_pk(a.M, a.Cd, nk_total, MODE);
     if (pk.f > 1 && (ws == nullptr || ws_bytes < sizeof(float) * pk.ws_floats)) {   // no scratch: unsplit
       AVID_REQUIRE(!a.stats, AVID_E_BADARG, "conv: BatchNorm partials need the planned workspace");
@@ -2685,70 +2628,10 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
                        a.addend ? a.addend + off : nullptr, a.bias, n4, a.Cd / 4, pk.f, a.relu);
     return check_launch("splitk_reduce");
   }
-  const long long row0 = 0;
-  const long long Mr = a.M - row0;
-  IgemmPlan pl = plan_igemm(Mr, a.Cd, nk_total, true);
-  if (pl.nsplit > 1 && (ws == nullptr || ws_bytes < sizeof(float) * (size_t)pl.nsplit * Mr * a.Cd)) {
-    pl = plan_igemm(Mr, a.Cd, nk_total, false);  // no scratch: single pass
-  }
-  auto launch = [&](ConvArgs& x) {
-    switch (pl.tile) {
-      case 0: return launch_igemm<2, 2, 2, 2, MODE>(x, s);
-      case 1: return launch_igemm<4, 1, 1, 2, MODE>(x, s);
-      default: return launch_igemm<2, 2, 1, 1, MODE>(x, s);
-    }
-  };
-  auto reduce = [&](const ConvArgs& x, int nsplit) {
-    const long long rows = x.M - x.part_row_begin, n4 = rows * x.Cd / 4;
-    long long grid = ceil_div(n4, 256);
-    if (grid > 2048) grid = 2048;
-    const long long off = (long long)x.part_row_begin * x.Cd;
-    ScopedTimer t(s, "splitk_reduce_kernel", 0.0, 4.0 * rows * x.Cd * (nsplit + 1 + (x.addend ? 1 : 0)));
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, x.part, x.dst + off,
-                       x.addend ? x.addend + off : nullptr, x.bias, n4, x.Cd / 4, nsplit, x.relu);
-    return check_launch("splitk_reduce");
-  };
-  const int pair = 2 * pl.BM;                                       // rows per workgroup of igemm_kernel
-  const int mt2_0 = (int)(row0 / pair);                             // row0 is a multiple of 256
-  const int mt2 = (int)((Mr + pair - 1) / pair);                    // M pair-tiles of the remainder
-  a.mt2_begin = mt2_0;
-  a.mt2_count = mt2;
-  a.part_row_begin = (int)row0;
-  a.nsplit = pl.nsplit;
-  a.ksteps_per_split = pl.ksteps_per_split;
-  a.part = static_cast<float*>(ws);
-  if (pl.nsplit > 1) {   // small-M problem: the whole launch is split-K
-    int rc = launch(a);
-    return rc ? rc : reduce(a, pl.nsplit);
-  }
-  // Tail split: whole rounds of workgroups run as is; a nearly empty last round (<= half the slots) is cut
-  // in K so that it fills the chip for a fraction of a tile time instead of idling it for a full one.
-  const TailPlan tp = plan_tail(pl, Mr, a.Cd, nk_total);
-  const int tail_m = tp.tail_m, f = tp.f;
-  const bool tail_split = tail_m > 0 && ws != nullptr && ws_bytes >= sizeof(float) * (size_t)f * tp.tail_rows * a.Cd;
-  if (!tail_split) return launch(a);
-  a.mt2_count = mt2 - tail_m;
-  int rc = launch(a);
-  if (rc) return rc;
-  ConvArgs t = a;
-  t.mt2_begin = mt2_0 + mt2 - tail_m;
-  t.mt2_count = tail_m;
-  t.part_row_begin = (int)row0 + (mt2 - tail_m) * pair;
-  t.ksteps_per_split = (nk_total + f - 1) / f;
-  t.nsplit = (nk_total + t.ksteps_per_split - 1) / t.ksteps_per_split;
-  rc = launch(t);
-  return rc ? rc : reduce(t, t.nsplit);
 }
 
 // scratch floats the non-strided igemm dispatch wants for an M x Cd problem (mirrors dispatch_igemm)
-static size_t igemm_ws_floats(long long M, int Cd, int nk, int mode) {
-  if (pk_enabled()) return plan_pk(M, Cd, nk, mode).ws_floats;
-  const long long Mr = M;
-  const IgemmPlan pl = plan_igemm(Mr, Cd, nk, true);
-  if (pl.nsplit > 1) return (size_t)pl.nsplit * Mr * Cd;
-  const TailPlan tp = plan_tail(pl, Mr, Cd, nk);
-  return (size_t)tp.f * tp.tail_rows * Cd;
-}
+static size_t igemm_ws_floats(long long M, int Cd, int nk, int mode) { return plan_pk(M, Cd, nk, mode).ws_floats; }
 
 static int launch_gather(const ConvArgs& a, hipStream_t s) {
   const long long M = a.M;
@@ -2789,7 +2672,7 @@ static Trim trim_taps(const avid_conv_desc* d) {
     const char* e = getenv("AVID_TRIM_TAPS");
     on = e ? atoi(e) != 0 : 1;
   }
-  if (!on || !pk_enabled() || d->x_channel_first || d->kt <= 1 || d->Cin % 64 || d->Cout % 64) return t;
+  if (!on || d->x_channel_first || d->kt <= 1 || d->Cin % 64 || d->Cout % 64) return t;
   int lo = d->kt, hi = -1;
   for (int dt = 0; dt < d->kt; ++dt)
     for (int to = 0; to < d->To; ++to) {
@@ -2854,8 +2737,7 @@ int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin,
   a.wsp = nullptr;
   a.wsp_nrec = a.wsp_kstep = 0;
   // persistent kernel, no K-split (K = 128: 4 k-tiles per tile, thousands of tiles): 54 -> ~90 TFLOP/s
-  if (pk_enabled()) return dispatch_igemm<0>(a, nullptr, 0, s);
-  return launch_igemm<4, 1, 1, 2, 0>(a, s);
+  return dispatch_igemm<0>(a, nullptr, 0, s);
 }
 
 }  // namespace avid
@@ -2916,7 +2798,7 @@ extern "C" int avid_conv_fwd_stats_rows(const avid_conv_desc* d) {
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
   if (!vec) return stem_fwd_supported(d) ? stem_fwd_grid(d) : 0;     // LDS-patch stems: one row per workgroup
   if (wino_supported(d, 0)) return wino_grid(d, 0);
-  if (!pk_enabled() || d->Cout > 1024 || (256 % (d->Cout / 4)) != 0) return 0;
+  if (d->Cout > 1024 || (256 % (d->Cout / 4)) != 0) return 0;
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
   const PkPlan pk = plan_pk(M, d->Cout, trim_taps(d).d.kt * d->kh * d->kw * (d->Cin / BK), 0);
   return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cout)) : 0);
@@ -3032,7 +2914,7 @@ extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   if (d->x_channel_first || d->Cin % 64 || d->Cout % 32 || d->st > 2 || d->sh > 2 || d->sw > 2) return 0;
   if (wino_supported(d, 1)) return wino_grid(d, 1);
-  if (!pk_enabled() || d->Cin > 1024 || (256 % (d->Cin / 4)) != 0) return 0;
+  if (d->Cin > 1024 || (256 % (d->Cin / 4)) != 0) return 0;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
   if (d->st > 1 || d->sh > 1 || d->sw > 1) {   // strided: the plan of dispatch_igemm<1>'s parity-class branch
     if (M * d->Cin * 4 >= (1ll << 31)) return 0;
@@ -3062,7 +2944,7 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
       AVID_REQUIRE(addend_stride[x] == 1 || addend_stride[x] == 2, AVID_E_UNSUPPORTED, "conv_dgrad: addend strides must be 1 or 2");
       sparse_add |= addend_stride[x] == 2;
     }
-    AVID_REQUIRE(!sparse_add || (pk_enabled() && (d->st > 1 || d->sh > 1 || d->sw > 1) &&
+    AVID_REQUIRE(!sparse_add || ((d->st > 1 || d->sh > 1 || d->sw > 1) &&
                                  (long long)d->B * d->Ti * d->Hi * d->Wi * d->Cin * 4 < (1ll << 31)),
                  AVID_E_UNSUPPORTED, "conv_dgrad: a compact addend needs a strided layer on the persistent kernel");
   }
@@ -3501,24 +3383,20 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
         snprintf(buf, len, "igemm_gather_kernel<%s>", ((M + 127) / 128) * (d->Cout / 64) >= 256 ? "4,1,1,2" : "2,2,1,1");
     } else if (wino_supported(d, 0)) {
       snprintf(buf, len, "wino_kernel<0> grid=%d", wino_grid(d, 0));
-    } else if (pk_enabled()) {
-      pk_name(M, d->Cout, ktl * d->kh * d->kw * (d->Cin / BK), 0);
     } else {
-      IgemmPlan pl = plan_igemm(M, d->Cout, d->kt * d->kh * d->kw * (d->Cin / BK), true);
-      snprintf(buf, len, "igemm_kernel<%s,0> splitk=%d", kTileName[pl.tile], pl.nsplit);
+      pk_name(M, d->Cout, ktl * d->kh * d->kw * (d->Cin / BK), 0);
     }
   } else if (which == 1) {
     const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
     const bool strided = d->st > 1 || d->sh > 1 || d->sw > 1;
     if (wino_supported(d, 1)) {
       snprintf(buf, len, "wino_kernel<1> grid=%d", wino_grid(d, 1));
-    } else if (pk_enabled() && strided) {
+    } else if (strided && dgrad_compactable(d)) {
+      snprintf(buf, len, "igemm_pk_kernel over the sub-sampled grid + dx_scatter_strided_kernel");
+    } else if (strided) {
       snprintf(buf, len, "igemm_pk_kernel<%s,1>s2 (stride-parity classes)", d->Cin % 128 == 0 ? "2,2,2,2" : "4,1,1,2");
-    } else if (pk_enabled()) {
-      pk_name(M, d->Cin, ktl * d->kh * d->kw * (d->Cout / BK), 1);
     } else {
-      IgemmPlan pl = plan_igemm(M, d->Cin, d->kt * d->kh * d->kw * (d->Cout / BK), true);
-      snprintf(buf, len, "igemm_kernel<%s,1> splitk=%d", kTileName[pl.tile], pl.nsplit);
+      pk_name(M, d->Cin, ktl * d->kh * d->kw * (d->Cout / BK), 1);
     }
   } else {
     WgradPlan pl = wgrad_plan(&tr.d);
