@@ -82,3 +82,21 @@ def test_program_executor_rejects_malformed_programs():
     assert run(prog, 0, 2, slots, 4, streams, ws, 2) == 0
     need = (C.c_size_t * 2)()
     assert lib.raw("avid_program_workspace_bytes")(prog, 0, 2, 2, need) == 0 and list(need) == [0, 0]
+
+
+def test_weight_transform_rejects_bad_descriptors():
+    """avid_weight_transform (one avid_wt_desc by value) checks its descriptor before it launches anything: null
+    pointers, an unknown mode, and shapes the split-bf16 fragment order cannot hold (rows % 64, channels % 32)."""
+    import ctypes as C
+    from avid_hip import lib
+    call = lib.raw("avid_weight_transform")
+    buf = (C.c_float * 16)()
+    p = C.addressof(buf)
+    BADARG, UNSUPPORTED = -1, -4           # include/avid_hip.h: AVID_E_BADARG, AVID_E_UNSUPPORTED
+    assert call(None, None) == BADARG
+    for desc, code in ((lib.WtDesc(0, p, 64, 1, 64, 0), BADARG), (lib.WtDesc(p, 0, 64, 1, 64, 0), BADARG),
+                       (lib.WtDesc(p, p, 64, 1, 64, 7), BADARG), (lib.WtDesc(p, p, 0, 1, 64, 0), BADARG),
+                       (lib.WtDesc(p, p, 48, 1, 64, 5), UNSUPPORTED), (lib.WtDesc(p, p, 64, 1, 48, 5), UNSUPPORTED),
+                       (lib.WtDesc(p, p, 64, 9, 96, 6), UNSUPPORTED)):
+        assert call(C.addressof(desc), None) == code, (desc.Cout, desc.Cin, desc.mode)
+        assert lib.last_error()

@@ -89,3 +89,27 @@ def test_unknown_module_falls_back(compiled):
     m.video_model.conv2x[0] = torch.nn.Identity()
     with pytest.raises(plan.Unsupported):
         plan.Plan(m, (2, 3, 8, 64, 64), (2, 1, 40, 100), torch.device("cpu"), True, True, True)
+
+
+def test_weight_tables_and_the_tail_of_the_backward(compiled):
+    """The per-step weight-transform table holds, for every weight, the forms its consumers read — plain transposes
+    (mode 0), Winograd transforms for the forward (1 / 3) and the input gradient (2 / 4), bf16-split weights for the forward
+    (5) and the input gradient (6) — and no plain transpose for a layer whose input gradient reads the split form.  The
+    backward program makes the fourth stream wait for the three others right in front of the video stem's backward: the
+    optimizer may update everything but the stem's three parameters from there (``adam_early``)."""
+    from avid_hip import plan
+    m, pl = compiled
+    modes = {}
+    for w, off, cout, taps, cin, mode in pl.wt_recs:
+        modes.setdefault(id(w), set()).add(mode)
+        assert 0 <= off < pl.table_off
+    all_modes = set().union(*modes.values())
+    assert {0, 5, 6} <= all_modes and all_modes <= {0, 1, 2, 3, 4, 5, 6}
+    assert not any({0, 6} <= v and not (v & {2, 4}) for v in modes.values()), "a transposed copy nobody reads"
+    stem = m.video_model.conv1
+    tail = [pl.goff[[id(p) for p in pl.params].index(id(p))] for p in (stem[0].weight, stem[1].weight, stem[1].bias)]
+    assert pl.adam_early == min(tail) and max(tail) < pl.gnumel
+    waits = [k for k in range(pl.n_bwd) if pl.bwd_prog[k].op == plan.OP_WAIT and pl.bwd_prog[k].i[0] == plan.ST_COMM]
+    assert sorted(pl.bwd_prog[k].i[1] for k in waits) == [plan.ST_MAIN, plan.ST_AUDIO, plan.ST_TRAIL]
+    first_stem = min(k for k in range(pl.n_bwd) if pl.bwd_prog[k].op == plan.OP_BN_POOL_BWD)
+    assert max(waits) < first_stem
