@@ -159,6 +159,9 @@ SIGNATURES = {
     "avid_xmodal_fused_workspace_bytes": (_sz, [_i, _i]),
     "avid_xmodal_fused": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp,
                                _sz, _vp, _vp]),
+    "avid_cma_fused_workspace_bytes": (_sz, [_i, _i, _i]),
+    "avid_cma_fused": (_i, [_i, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _f, _f, _vp, _vp, _vp, _vp,
+                            _vp, _vp, _sz, _vp, _vp]),
     "avid_bank_update2": (_i, [_i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp]),
     "avid_cma_negatives": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avid_cma_topk_workspace_bytes": (_sz, [_i64, _i, _i]),

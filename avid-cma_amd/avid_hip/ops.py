@@ -1351,6 +1351,46 @@ def xmodal_fused(v_emb, a_emb, y, idx, bank_v, bank_a, Z, inv_T, coeff, ws):
     return _XModalFused.apply(v_emb, a_emb, y, idx, bank_v, bank_a, Z, inv_T, coeff, ws)
 
 
+class _CMAFused(Function):
+    """The AVID+CMA criterion of a steady-state step (cross-modal instance + within-modal positive terms) in one kernel
+    (``avid_cma_fused``): returns (total loss, losses[8], hats); as ``_XModalFused`` the gradient with respect to both raw
+    embeddings is formed in the forward pass and only scaled in backward."""
+
+    @staticmethod
+    def forward(ctx, v_emb, a_emb, y, pos, idx, bank_v, bank_a, Z, inv_T, Kw, coeff_inst, coeff_pos, ws):
+        _need_cuda(v_emb, a_emb, y, pos, idx, bank_v, bank_a, Z, ws)
+        v_emb, a_emb, y, pos, idx = v_emb.contiguous(), a_emb.contiguous(), y.contiguous(), pos.contiguous(), idx.contiguous()
+        bs, D = v_emb.shape
+        P, K = pos.shape[1], idx.shape[1]
+        if any(t.dtype != torch.int64 for t in (y, pos, idx)) or not bank_v.is_contiguous() or not bank_a.is_contiguous():
+            raise AvidHipError("cma_fused: y / pos / idx must be int64 and the banks contiguous")
+        dev = v_emb.device
+        hats = torch.empty((2, bs, D), dtype=torch.float32, device=dev)
+        grads = torch.empty((2, bs, D), dtype=torch.float32, device=dev)
+        losses = torch.empty(8, dtype=torch.float32, device=dev)
+        lib.call("avid_cma_fused", bs, P, K, int(Kw), D, bank_v.shape[0], _p(v_emb), _p(a_emb), _p(y), _p(pos), _p(idx),
+                 _p(bank_v), _p(bank_a), float(inv_T), _p(Z), float(coeff_inst), float(coeff_pos), _p(hats[0]), _p(hats[1]),
+                 _p(losses), _p(grads[0]), _p(grads[1]), _p(ws), ws.numel(), DeviceErrors.get(dev).ptr(), _stream())
+        ctx.save_for_backward(grads)
+        total = losses[6]
+        ctx.mark_non_differentiable(losses, hats)
+        return total, losses, hats
+
+    @staticmethod
+    def backward(ctx, dtotal, _dl, _dh):
+        (grads,) = ctx.saved_tensors
+        g = grads * dtotal
+        return (g[0], g[1]) + (None,) * 11
+
+
+def cma_fused_workspace(device, bs, P, K):
+    return torch.zeros(int(lib.raw("avid_cma_fused_workspace_bytes")(int(bs), int(P), int(K))), dtype=torch.uint8, device=device)
+
+
+def cma_fused(v_emb, a_emb, y, pos, idx, bank_v, bank_a, Z, inv_T, Kw, coeff_inst, coeff_pos, ws):
+    return _CMAFused.apply(v_emb, a_emb, y, pos, idx, bank_v, bank_a, Z, inv_T, Kw, coeff_inst, coeff_pos, ws)
+
+
 def cma_negatives(positive_set, y, rand_idx):
     _need_cuda(positive_set, y, rand_idx)
     bs, K = rand_idx.shape

@@ -110,6 +110,33 @@ class AVIDSimilarityPositiveExpansion(AVIDSimilarityMemoryBank):
         ops.poll_device_errors(y.device)
         return scores
 
+    def fused_ok(self, video_emb, audio_emb):
+        """The one-kernel steady-state path (ops.cma_fused): the stock term set — cross-modal instance + within-modal
+        positives (InstX-...-PosW-..., the config of configs/main/avid-cma) — on 128-d fp32 embeddings on the GPU."""
+        return (ops.FUSED_CRITERION and self.xModalInst and self.wModalPos and not self.wModalInst and not self.xModalPos
+                and self.sampling_args['pos_k'] > 0 and video_emb.is_cuda and video_emb.dim() == 2
+                and video_emb.shape[1] == 128 and self.view1_mem.shape[1] == 128
+                and video_emb.dtype == torch.float32 and audio_emb.dtype == torch.float32)
+
+    def forward_fused(self, video_emb, audio_emb, y, Z, coeff_inst, coeff_pos):
+        """forward() + the four NCE terms (nce.py:38-58, Z frozen) + their gradient in one kernel, then ONE bank-update
+        launch.  Returns (total loss, losses[8])."""
+        ops.poll_device_errors(y.device)
+        with torch.no_grad():
+            pos_idx, neg_idx = self.memory_sampling(y)
+        P, K = pos_idx.shape[1], neg_idx.shape[1]
+        Kw = K if self.num_negatives_within is None else min(int(self.num_negatives_within), K)
+        ws = getattr(self, "_fused_ws", None)
+        key = (y.shape[0], P, K, video_emb.device)
+        if ws is None or self._fused_key != key:
+            ws = self._fused_ws = ops.cma_fused_workspace(video_emb.device, y.shape[0], P, K)
+            self._fused_key = key
+        total, losses, hats = ops.cma_fused(video_emb, audio_emb, y, pos_idx, neg_idx, self.view1_mem, self.view2_mem, Z,
+                                            1.0 / self.temperature, Kw, coeff_inst, coeff_pos, ws)
+        self.update_memory(hats[0], hats[1], y)
+        ops.poll_device_errors(y.device)
+        return total, losses
+
     def memory_sampling(self, y):
         """avid_cma.py:196-209: positives = positive_set[y]; negatives skip the (sorted) positives."""
         bs = y.shape[0]
@@ -172,6 +199,13 @@ class AVID_CMA(nn.Module):
 
     def forward(self, emb1, emb2, target):
         tb_log = {}
+        # steady state (Z frozen after the first batch, nce.py:22-24) with the stock term set: one fused kernel
+        if self.nce_average.fused_ok(emb1, emb2) and self.criterion.z_ready():
+            total_loss, losses = self.nce_average.forward_fused(emb1, emb2, target, self.criterion.avg_exp_score,
+                                                                self.xModalInstCoeff, self.wModalPosCoeff)
+            for k, name in enumerate(('inst-v2a', 'inst-a2v', 'pos-v2v', 'pos-a2a')):
+                tb_log[f'Loss/{name}'] = losses[k]
+            return total_loss, tb_log
         scores = self.nce_average(emb1, emb2, target)
         terms = {k: self.criterion(*pair) for k, pair in scores.items()}
         total_loss, _ = combine_losses(terms, [(('inst-v2a', 'inst-a2v'), self.xModalInstCoeff),

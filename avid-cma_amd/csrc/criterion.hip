@@ -370,19 +370,29 @@ struct XModalArgs {
   long long N;
   int bs, K, S;
   float inv_T, coeff;
+  // CMA form (criterions/avid_cma.py:150-194 with cross-modal instance + within-modal positive terms): rows = self | P
+  // positives (pos[b][.]) | K negatives; the first Kw negatives also serve the within-modal terms; cI / cP: the two
+  // groups' normalised coefficients (folded into the gradients as they are accumulated: coeff = 1 then)
+  const long long* pos;
+  int P, Kw;
+  float cI, cP;
 };
 
 // Lane layout (round 4): SIXTEEN lanes per bank row (8 consecutive floats each: two 16-byte loads per row and bank), four
 // rows per wave at a time — a row's dot product is a 4-step reduction inside its lane group instead of a 6-step one over
 // the wave, the exp / log / divide chain of four rows runs in parallel lanes, and a wave issues 64 16-byte loads instead of
 // 64 4-byte ones for the same 16 rows (29.3 -> see DESIGN 3.6).
+// CMA: four score sets per gathered row pair instead of two — inst-v2a / inst-a2v (self row positive, the K negatives) and
+// pos-v2v / pos-a2a (the P positives, each 1 / P of the positive term; the first Kw negatives): the same rows of both
+// banks, two more dot products per row, and both embeddings receive gradient from both banks.
+template <bool CMA>
 __global__ __launch_bounds__(256) void xmodal_fused_kernel(const XModalArgs p) {
-  constexpr int D = 128, RPW = SC_ROWS_PER_BLOCK / 4, NU = RPW / 4;
+  constexpr int D = 128, RPW = SC_ROWS_PER_BLOCK / 4, NU = RPW / 4, NL = CMA ? 4 : 2;
   __shared__ float sh_g[4][2][D];
-  __shared__ double sh_l[4][2];
+  __shared__ double sh_l[4][NL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & 15, grp = lane >> 4;
-  const int b = blockIdx.y, split = blockIdx.x, R = p.K + 1;
+  const int b = blockIdx.y, split = blockIdx.x, R = (CMA ? p.P : 0) + p.K + 1;
   auto group_sum = [](float v) {                       // over the 16 lanes of a row group
     v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
     return v;
@@ -415,12 +425,15 @@ __global__ __launch_bounds__(256) void xmodal_fused_kernel(const XModalArgs p) {
     }
   }
   const float KZ = (float)p.K * p.Z[0];
+  const float KZw = CMA ? (float)p.Kw * p.Z[0] : 0.f;
+  const int PP = CMA ? p.P : 0;
   const int j0 = split * SC_ROWS_PER_BLOCK, j1 = min(j0 + SC_ROWS_PER_BLOCK, R);
   const int jw = j0 + wave * RPW;
-  // row j = 0 is the positive (the sample's own row y), rows 1..K the negatives idx[b][j - 1]
+  // row j = 0 is the positive (the sample's own row y), [CMA: rows 1..P the positives pos[b][j - 1],] then the negatives
   long long mine = 0;
   if (lane < RPW && jw + lane < j1) {
-    mine = jw + lane == 0 ? p.y[b] : p.idx[(long long)b * p.K + jw + lane - 1];
+    const int jj = jw + lane;
+    mine = jj == 0 ? p.y[b] : (jj <= PP ? p.pos[(long long)b * PP + jj - 1] : p.idx[(long long)b * p.K + jj - 1 - PP]);
     if (mine < 0 || mine >= p.N) {
       if (p.err) atomicOr(p.err, AVID_DEVERR_BANK_INDEX);
       mine = mine < 0 ? 0 : p.N - 1;
@@ -438,19 +451,59 @@ __global__ __launch_bounds__(256) void xmodal_fused_kernel(const XModalArgs p) {
   float gv[8], ga[8];                    // d L_v2a / d v_hat, d L_a2v / d a_hat (x T, unscaled): this group's rows
 #pragma unroll
   for (int k = 0; k < 8; ++k) gv[k] = ga[k] = 0.f;
-  double lv = 0, la = 0;
+  double lv = 0, la = 0, lw = 0, lx = 0;
+  const float invP = CMA ? 1.f / (float)p.P : 0.f;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int j = jw + u * 4 + grp;
-    float d1 = 0.f, d2 = 0.f;
+    float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       d1 = fmaf(ra[u][0][k], ev[k], d1); d1 = fmaf(ra[u][1][k], ev[4 + k], d1);
       d2 = fmaf(rv[u][0][k], ea[k], d2); d2 = fmaf(rv[u][1][k], ea[4 + k], d2);
+      if (CMA) {
+        d3 = fmaf(rv[u][0][k], ev[k], d3); d3 = fmaf(rv[u][1][k], ev[4 + k], d3);
+        d4 = fmaf(ra[u][0][k], ea[k], d4); d4 = fmaf(ra[u][1][k], ea[4 + k], d4);
+      }
     }
     const float s1 = group_sum(d1) * p.inv_T;     // v2a: video embedding . audio bank
     const float s2 = group_sum(d2) * p.inv_T;     // a2v
-    if (j < j1) {
+    if (CMA) {
+      const float s3 = group_sum(d3) * p.inv_T;   // v2v: video embedding . video bank
+      const float s4 = group_sum(d4) * p.inv_T;   // a2a
+      if (j < j1) {
+        const int n = j - 1 - PP;                 // index among the negatives (< 0: self / positive)
+        float g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
+        if (j == 0 || n >= 0) {                   // instance terms: self positive, every negative
+          const float e1 = expf(s1), e2 = expf(s2);
+          if (j == 0) {
+            if (sub == 0) { lv += (double)(-logf(e1 / (e1 + KZ))); la += (double)(-logf(e2 / (e2 + KZ))); }
+            g1 = -(KZ / (e1 + KZ)); g2 = -(KZ / (e2 + KZ));
+          } else {
+            if (sub == 0) { lv += (double)(-logf(KZ / (e1 + KZ))); la += (double)(-logf(KZ / (e2 + KZ))); }
+            g1 = e1 / (e1 + KZ); g2 = e2 / (e2 + KZ);
+          }
+        }
+        if (j != 0 && n < p.Kw) {                 // within-modal terms: the positives (mean over P), the first Kw negatives
+          const float e3 = expf(s3), e4 = expf(s4);
+          if (n < 0) {
+            if (sub == 0) { lw += (double)(-logf(e3 / (e3 + KZw)) * invP); lx += (double)(-logf(e4 / (e4 + KZw)) * invP); }
+            g3 = -(KZw / (e3 + KZw)) * invP; g4 = -(KZw / (e4 + KZw)) * invP;
+          } else {
+            if (sub == 0) { lw += (double)(-logf(KZw / (e3 + KZw))); lx += (double)(-logf(KZw / (e4 + KZw))); }
+            g3 = e3 / (e3 + KZw); g4 = e4 / (e4 + KZw);
+          }
+        }
+        g1 *= p.cI; g2 *= p.cI; g3 *= p.cP; g4 *= p.cP;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          gv[k] = fmaf(g1, ra[u][0][k], gv[k]); gv[4 + k] = fmaf(g1, ra[u][1][k], gv[4 + k]);
+          gv[k] = fmaf(g3, rv[u][0][k], gv[k]); gv[4 + k] = fmaf(g3, rv[u][1][k], gv[4 + k]);
+          ga[k] = fmaf(g2, rv[u][0][k], ga[k]); ga[4 + k] = fmaf(g2, rv[u][1][k], ga[4 + k]);
+          ga[k] = fmaf(g4, ra[u][0][k], ga[k]); ga[4 + k] = fmaf(g4, ra[u][1][k], ga[4 + k]);
+        }
+      }
+    } else if (j < j1) {
       const float e1 = expf(s1), e2 = expf(s2);
       float g1, g2;
       if (j == 0) {            // -log(e / (e + KZ));  d / ds = -KZ / (e + KZ)
@@ -475,29 +528,37 @@ __global__ __launch_bounds__(256) void xmodal_fused_kernel(const XModalArgs p) {
   }
   lv += __shfl_xor(lv, 16, 64); lv += __shfl_xor(lv, 32, 64);
   la += __shfl_xor(la, 16, 64); la += __shfl_xor(la, 32, 64);
+  if (CMA) {
+    lw += __shfl_xor(lw, 16, 64); lw += __shfl_xor(lw, 32, 64);
+    lx += __shfl_xor(lx, 16, 64); lx += __shfl_xor(lx, 32, 64);
+  }
   if (grp == 0) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sh_g[wave][0][sub * 8 + k] = gv[k]; sh_g[wave][1][sub * 8 + k] = ga[k]; }
   }
-  if (lane == 0) { sh_l[wave][0] = lv; sh_l[wave][1] = la; }
+  if (lane == 0) {
+    sh_l[wave][0] = lv; sh_l[wave][1] = la;
+    if (CMA) { sh_l[wave][2] = lw; sh_l[wave][3] = lx; }
+  }
   __syncthreads();
   float* pg = p.part_g + ((long long)b * p.S + split) * 2 * D;
   {
     const int t = threadIdx.x;                       // 256 threads = 2 x 128 gradient components
     pg[t] = ((&sh_g[0][0][0])[t] + (&sh_g[1][0][0])[t]) + ((&sh_g[2][0][0])[t] + (&sh_g[3][0][0])[t]);   // [which][d] contiguous
   }
-  if (threadIdx.x == 0) {
-    double* pl = p.part_l + ((long long)b * p.S + split) * 2;
-    pl[0] = (sh_l[0][0] + sh_l[1][0]) + (sh_l[2][0] + sh_l[3][0]);
-    pl[1] = (sh_l[0][1] + sh_l[1][1]) + (sh_l[2][1] + sh_l[3][1]);
+  if (threadIdx.x < NL) {
+    double* pl = p.part_l + ((long long)b * p.S + split) * NL;
+    const int q = threadIdx.x;
+    pl[q] = (sh_l[0][q] + sh_l[1][q]) + (sh_l[2][q] + sh_l[3][q]);
   }
 }
 
 // second launch of the fused criterion: one block per sample folds the S partial gradients in split order (the kernel
 // boundary makes them visible: no fences around the 1088 producer blocks), applies the backward of F.normalize and
 // leaves the sample's two loss terms; the last of the bs blocks (device ticket, re-armed) folds those in sample order.
+template <bool CMA>
 __global__ __launch_bounds__(256) void xmodal_finish_kernel(const XModalArgs p) {
-  constexpr int D = 128;
+  constexpr int D = 128, NL = CMA ? 4 : 2;
   __shared__ float sh_dot[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, which = t >> 7, d = t & 127;
   const int b = blockIdx.x;
@@ -522,40 +583,59 @@ __global__ __launch_bounds__(256) void xmodal_finish_kernel(const XModalArgs p) 
   (which == 0 ? p.dv : p.da)[(long long)b * D + d] = (g - eh * full) / nrm;
   if (wave != 0) return;
   // the sample's loss terms: lanes 0..S-1 fetch the partials, fixed-order sum by lane 0
-  double l0 = 0, l1 = 0;
+  double l[NL];
   {
-    const double* pl = p.part_l + (long long)b * p.S * 2;
-    double a0 = 0, a1 = 0;
+    const double* pl = p.part_l + (long long)b * p.S * NL;
+#pragma unroll
+    for (int q = 0; q < NL; ++q) l[q] = 0;
     for (int base = 0; base < p.S; base += 64) {
       const int i = base + lane;
-      const double v0 = i < p.S ? pl[2 * i] : 0.0, v1 = i < p.S ? pl[2 * i + 1] : 0.0;
-      for (int k = 0; k < 64 && base + k < p.S; ++k) { a0 += __shfl(v0, k, 64); a1 += __shfl(v1, k, 64); }
+      double v[NL];
+#pragma unroll
+      for (int q = 0; q < NL; ++q) v[q] = i < p.S ? pl[NL * i + q] : 0.0;
+      for (int k = 0; k < 64 && base + k < p.S; ++k) {
+#pragma unroll
+        for (int q = 0; q < NL; ++q) l[q] += __shfl(v[q], k, 64);
+      }
     }
-    l0 = a0; l1 = a1;
   }
   unsigned last = 0;
   if (lane == 0) {
-    __hip_atomic_store(p.samp_l + 2 * b, l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(p.samp_l + 2 * b + 1, l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int q = 0; q < NL; ++q) __hip_atomic_store(p.samp_l + NL * b + q, l[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
     last = atomicAdd(&p.tickets[0], 1u) == (unsigned)p.bs - 1 ? 1u : 0u;
   }
   last = __shfl(last, 0, 64);
   if (!last) return;
   __threadfence();
-  double t0 = 0, t1 = 0;
+  double tot[NL];
+#pragma unroll
+  for (int q = 0; q < NL; ++q) tot[q] = 0;
   for (int base = 0; base < p.bs; base += 64) {      // 64 samples per trip in flight, summed in sample order
     const int i = base + lane;
-    const double v0 = i < p.bs ? __hip_atomic_load(p.samp_l + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    const double v1 = i < p.bs ? __hip_atomic_load(p.samp_l + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    for (int k = 0; k < 64 && base + k < p.bs; ++k) { t0 += __shfl(v0, k, 64); t1 += __shfl(v1, k, 64); }
+    double v[NL];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) v[q] = i < p.bs ? __hip_atomic_load(p.samp_l + NL * i + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    for (int k = 0; k < 64 && base + k < p.bs; ++k) {
+#pragma unroll
+      for (int q = 0; q < NL; ++q) tot[q] += __shfl(v[q], k, 64);
+    }
   }
   if (lane == 0) {
-    const float L0 = (float)(t0 / (double)p.bs), L1 = (float)(t1 / (double)p.bs);
-    p.losses[0] = L0; p.losses[1] = L1;
-    const float xl = L0 / 2.f + L1 / 2.f;            // criterions/avid.py:221-222
-    p.losses[2] = xl;
-    p.losses[3] = xl * p.coeff;
+    float L[NL];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) { L[q] = (float)(tot[q] / (double)p.bs); p.losses[q] = L[q]; }
+    if (CMA) {     // criterions/avid_cma.py:338-358: every group the mean of its two directions, the total their weighted sum
+      const float gi = L[0] / 2.f + L[1] / 2.f, gp = L[2] / 2.f + L[3] / 2.f;
+      p.losses[4] = gi;
+      p.losses[5] = gp;
+      p.losses[6] = gi * p.cI + gp * p.cP;
+    } else {
+      const float xl = L[0] / 2.f + L[1] / 2.f;      // criterions/avid.py:221-222
+      p.losses[2] = xl;
+      p.losses[3] = xl * p.coeff;
+    }
     __hip_atomic_store(&p.tickets[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm
   }
 }
@@ -736,9 +816,32 @@ extern "C" int avid_cma_negatives(int bs, int K, int P, int64_t N, const int32_t
   return check_launch("cma_negatives");
 }
 
-extern "C" size_t avid_xmodal_fused_workspace_bytes(int bs, int K) {
-  const size_t S = (size_t)ceil_div(K + 1, SC_ROWS_PER_BLOCK);
-  return (size_t)bs * S * 2 * 128 * 4 + (size_t)bs * S * 2 * 8 + (size_t)bs * 2 * 8 + ((size_t)bs + 1) * 4 + (size_t)bs * 2 * 4 + 64;
+static size_t fused_ws_bytes(int bs, int rows, int nl) {
+  const size_t S = (size_t)ceil_div(rows, SC_ROWS_PER_BLOCK);
+  return (size_t)bs * S * 2 * 128 * 4 + (size_t)bs * S * nl * 8 + (size_t)bs * nl * 8 + ((size_t)bs + 1) * 4 + (size_t)bs * 2 * 4 + 64;
+}
+extern "C" size_t avid_xmodal_fused_workspace_bytes(int bs, int K) { return fused_ws_bytes(bs, K + 1, 2); }
+extern "C" size_t avid_cma_fused_workspace_bytes(int bs, int P, int K) { return fused_ws_bytes(bs, 1 + P + K, 4); }
+
+// scratch layout + the two launches shared by avid_xmodal_fused / avid_cma_fused
+template <bool CMA>
+static int fused_launch(XModalArgs& a, int rows, void* ws, hipStream_t s) {
+  constexpr int NL = CMA ? 4 : 2;
+  a.S = (int)ceil_div(rows, SC_ROWS_PER_BLOCK);
+  char* w = static_cast<char*>(ws);                 // (zero-filled once by the caller: the tickets re-arm themselves)
+  a.part_l = reinterpret_cast<double*>(w); w += (size_t)a.bs * a.S * NL * 8;
+  a.samp_l = reinterpret_cast<double*>(w); w += (size_t)a.bs * NL * 8;
+  a.part_g = reinterpret_cast<float*>(w); w += (size_t)a.bs * a.S * 2 * 128 * 4;
+  a.tickets = reinterpret_cast<unsigned*>(w); w += ((size_t)a.bs + 1) * 4;
+  a.norms = reinterpret_cast<float*>(w);
+  // bytes: the gathered rows of both banks, read once
+  ScopedTimer t(s, CMA ? "cma_fused_kernel" : "xmodal_fused_kernel", (CMA ? 2.0 : 1.0) * 2.0 * 2.0 * 2.0 * a.bs * rows * 128,
+                2.0 * 4.0 * a.bs * rows * 128.0);
+  hipLaunchKernelGGL(xmodal_fused_kernel<CMA>, dim3((unsigned)a.S, (unsigned)a.bs), dim3(256), 0, s, a);
+  int rc = check_launch(CMA ? "cma_fused" : "xmodal_fused");
+  if (rc) return rc;
+  hipLaunchKernelGGL(xmodal_finish_kernel<CMA>, dim3((unsigned)a.bs), dim3(256), 0, s, a);
+  return check_launch(CMA ? "cma_finish" : "xmodal_finish");
 }
 
 extern "C" int avid_xmodal_fused(int bs, int K, int D, int64_t N, const float* v_emb, const float* a_emb, const int64_t* y,
@@ -752,22 +855,25 @@ extern "C" int avid_xmodal_fused(int bs, int K, int D, int64_t N, const float* v
   XModalArgs a;
   a.v_emb = v_emb; a.a_emb = a_emb; a.y = (const long long*)y; a.idx = (const long long*)idx;
   a.bank_v = bank_v; a.bank_a = bank_a; a.Z = Z; a.v_hat = v_hat; a.a_hat = a_hat; a.losses = losses; a.dv = dv; a.da = da;
-  a.S = (int)ceil_div(K + 1, SC_ROWS_PER_BLOCK);
-  char* w = static_cast<char*>(ws);                 // (zero-filled once by the caller: the tickets re-arm themselves)
-  a.part_l = reinterpret_cast<double*>(w); w += (size_t)bs * a.S * 2 * 8;
-  a.samp_l = reinterpret_cast<double*>(w); w += (size_t)bs * 2 * 8;
-  a.part_g = reinterpret_cast<float*>(w); w += (size_t)bs * a.S * 2 * 128 * 4;
-  a.tickets = reinterpret_cast<unsigned*>(w); w += ((size_t)bs + 1) * 4;
-  a.norms = reinterpret_cast<float*>(w);
   a.err = err; a.N = N; a.bs = bs; a.K = K; a.inv_T = inv_T; a.coeff = coeff;
-  hipStream_t s = (hipStream_t)stream;
-  // bytes: the gathered rows of both banks, read once
-  ScopedTimer t(s, "xmodal_fused_kernel", 2.0 * 2.0 * 2.0 * bs * (K + 1) * 128, 2.0 * 4.0 * bs * (K + 1) * 128.0);
-  hipLaunchKernelGGL(xmodal_fused_kernel, dim3((unsigned)a.S, (unsigned)bs), dim3(256), 0, s, a);
-  int rc = check_launch("xmodal_fused");
-  if (rc) return rc;
-  hipLaunchKernelGGL(xmodal_finish_kernel, dim3((unsigned)bs), dim3(256), 0, s, a);
-  return check_launch("xmodal_finish");
+  a.pos = nullptr; a.P = 0; a.Kw = 0; a.cI = a.cP = 0.f;
+  return fused_launch<false>(a, K + 1, ws, (hipStream_t)stream);
+}
+
+extern "C" int avid_cma_fused(int bs, int P, int K, int Kw, int D, int64_t N, const float* v_emb, const float* a_emb,
+                              const int64_t* y, const int64_t* pos, const int64_t* idx, const float* bank_v, const float* bank_a,
+                              float inv_T, const float* Z, float coeff_inst, float coeff_pos, float* v_hat, float* a_hat,
+                              float* losses, float* dv, float* da, void* ws, size_t ws_bytes, int32_t* err, avid_stream_t stream) {
+  AVID_REQUIRE(bs > 0 && P > 0 && K > 0 && Kw > 0 && Kw <= K && N > 0 && v_emb && a_emb && y && pos && idx && bank_v && bank_a && Z &&
+                   v_hat && a_hat && losses && dv && da && ws, AVID_E_BADARG, "cma_fused: bad argument");
+  AVID_REQUIRE(D == 128, AVID_E_UNSUPPORTED, "cma_fused: D=%d unsupported (128 only; use the unfused ops)", D);
+  AVID_REQUIRE(ws_bytes >= avid_cma_fused_workspace_bytes(bs, P, K), AVID_E_BADARG, "cma_fused: workspace too small");
+  XModalArgs a;
+  a.v_emb = v_emb; a.a_emb = a_emb; a.y = (const long long*)y; a.idx = (const long long*)idx;
+  a.bank_v = bank_v; a.bank_a = bank_a; a.Z = Z; a.v_hat = v_hat; a.a_hat = a_hat; a.losses = losses; a.dv = dv; a.da = da;
+  a.err = err; a.N = N; a.bs = bs; a.K = K; a.inv_T = inv_T; a.coeff = 1.f;
+  a.pos = (const long long*)pos; a.P = P; a.Kw = Kw; a.cI = coeff_inst; a.cP = coeff_pos;
+  return fused_launch<true>(a, 1 + P + K, ws, (hipStream_t)stream);
 }
 
 extern "C" int avid_bank_update2(int B, int D, int64_t N, float* bank0, float* bank1, const int64_t* y, const float* emb0,

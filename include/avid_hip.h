@@ -339,6 +339,20 @@ int avid_xmodal_fused(int bs, int K, int D, int64_t N, const float* v_emb, const
                       const int64_t* idx, const float* bank_v, const float* bank_a, float inv_T, const float* Z,
                       float coeff, float* v_hat, float* a_hat, float* losses, float* dv, float* da, void* ws,
                       size_t ws_bytes, int32_t* err, avid_stream_t stream);
+/* The same for the AVID+CMA criterion in its stock form — cross-modal instance terms + within-modal positive terms
+ * (criterions/avid_cma.py:150-194, 338-358 with xModalInst and wModalPos on; Z frozen): rows gathered once from both
+ * banks = the sample's own row y | its P positives pos[bs][P] (avid_cma_negatives) | the K negatives idx[bs][K]; four
+ * score sets per row pair (inst-v2a / inst-a2v over self + K negatives, pos-v2v / pos-a2a over the P positives — mean
+ * over P, criterions/nce.py:44 — and the first Kw negatives, avid_cma.py:184-190), their NCE terms, and the gradient of
+ *   total = coeff_inst (L_inst-v2a + L_inst-a2v) / 2 + coeff_pos (L_pos-v2v + L_pos-a2a) / 2
+ * with respect to both raw embeddings (each receives gradient through rows of BOTH banks).
+ *   losses [8]: L_inst-v2a, L_inst-a2v, L_pos-v2v, L_pos-a2a, the two group means, the total, (unused).
+ * Everything else as avid_xmodal_fused (ws: avid_cma_fused_workspace_bytes(bs, P, K), zero-filled once). */
+size_t avid_cma_fused_workspace_bytes(int bs, int P, int K);
+int avid_cma_fused(int bs, int P, int K, int Kw, int D, int64_t N, const float* v_emb, const float* a_emb, const int64_t* y,
+                   const int64_t* pos, const int64_t* idx, const float* bank_v, const float* bank_a, float inv_T,
+                   const float* Z, float coeff_inst, float coeff_pos, float* v_hat, float* a_hat, float* losses, float* dv,
+                   float* da, void* ws, size_t ws_bytes, int32_t* err, avid_stream_t stream);
 /* avid_bank_update for both banks in one launch (criterions/avid.py:118-129): bank0 <- emb0 (momentum0), bank1 <- emb1; bit-identical to two avid_bank_update calls. */
 int avid_bank_update2(int B, int D, int64_t N, float* bank0, float* bank1, const int64_t* y, const float* emb0,
                       const float* emb1, float momentum0, float momentum1, int32_t* err, avid_stream_t stream);

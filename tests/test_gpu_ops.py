@@ -724,6 +724,81 @@ def test_xmodal_fused_vs_unfused_ops_and_fp64(bs, K, N, gpu_device):
     ops.check_device_errors(gpu_device)
 
 
+@pytest.mark.parametrize("bs,P,K,Kw,N", [(6, 32, 1024, 64, 5000), (64, 32, 1024, 64, 240000), (3, 5, 70, 70, 300), (4, 1, 33, 7, 200)])
+def test_cma_fused_vs_fp64_and_the_criterion_it_replaces(bs, P, K, Kw, N, gpu_device, monkeypatch):
+    """ops.cma_fused (the AVID+CMA criterion's stock term set in one kernel: criterions/avid_cma.py:150-194, 338-358 +
+    criterions/nce.py:38-58 with a frozen Z) against the same arithmetic in float64 on the CPU — four losses, the two
+    group means and the total 2e-6, gradients 2e-5 of their scale, normalised embeddings 1e-6, repeated calls
+    bit-identical — and, through criterions.AVID_CMA, against the chain of unfused ops (AVID_FUSED_CRITERION=0)."""
+    from avid_hip import ops
+    gen = torch.Generator().manual_seed(bs * 1000 + K + P)
+    v1 = F.normalize(torch.randn(N, 128, generator=gen), dim=1)
+    v2 = F.normalize(torch.randn(N, 128, generator=gen), dim=1)
+    ve = torch.randn(bs, 128, generator=gen) * 2
+    ae = torch.randn(bs, 128, generator=gen) * 0.5
+    y = torch.randperm(N, generator=gen)[:bs]
+    pos = torch.randint(0, N, (bs, P), generator=gen)
+    idx = torch.randint(0, N, (bs, K), generator=gen)
+    Z, cI, cP, T_ = torch.tensor(0.83), 0.4, 0.6, 0.07
+    vr, ar = ve.double().requires_grad_(True), ae.double().requires_grad_(True)
+    vh, ah = F.normalize(vr, dim=1), F.normalize(ar, dim=1)
+    rows = torch.cat([y[:, None], pos, idx], 1)
+    sc = lambda bank, e: torch.bmm(bank.double()[rows], e.unsqueeze(2)).squeeze(-1) / T_
+    s_v2a, s_a2v, s_v2v, s_a2a = sc(v2, vh), sc(v1, ah), sc(v1, vh), sc(v2, ah)
+    neg = slice(1 + P, None)
+    wneg = slice(1 + P, 1 + P + Kw)
+    l = [O.nce_loss(s_v2a[:, :1], s_v2a[:, neg], Z.double())[0], O.nce_loss(s_a2v[:, :1], s_a2v[:, neg], Z.double())[0],
+         O.nce_loss(s_v2v[:, 1:1 + P], s_v2v[:, wneg], Z.double())[0], O.nce_loss(s_a2a[:, 1:1 + P], s_a2a[:, wneg], Z.double())[0]]
+    gi, gp = l[0] / 2 + l[1] / 2, l[2] / 2 + l[3] / 2
+    tot = gi * cI + gp * cP
+    tot.backward()
+    b1, b2 = v1.to(gpu_device), v2.to(gpu_device)
+    vd, ad = ve.to(gpu_device).requires_grad_(True), ae.to(gpu_device).requires_grad_(True)
+    ws = ops.cma_fused_workspace(gpu_device, bs, P, K)
+    outs = [ops.cma_fused(vd, ad, y.to(gpu_device), pos.to(gpu_device), idx.to(gpu_device), b1, b2, Z.to(gpu_device), 1 / T_,
+                          Kw, cI, cP, ws) for _ in range(3)]
+    total, losses, hats = outs[0]
+    assert all(torch.equal(o[0], total) and torch.equal(o[1][:7], losses[:7]) and torch.equal(o[2], hats) for o in outs[1:])
+    (total * 2.0).backward()
+    np.testing.assert_allclose(losses[:7].cpu().numpy(), [float(v) for v in l] + [float(gi), float(gp), float(tot)], rtol=2e-6)
+    assert relerr(hats[0], vh.detach()) < 1e-6 and relerr(hats[1], ah.detach()) < 1e-6
+    assert relerr(vd.grad, 2.0 * vr.grad) < 2e-5 and relerr(ad.grad, 2.0 * ar.grad) < 2e-5
+    ops.check_device_errors(gpu_device)
+
+
+def test_avid_cma_criterion_fused_step_equals_the_unfused_one(gpu_device, monkeypatch):
+    """criterions.AVID_CMA: the second step (Z frozen) through ops.cma_fused against the same step with
+    AVID_FUSED_CRITERION=0 — same negatives (same sampler stream), loss and tb_log 3e-6, embedding gradients 2e-5, banks
+    after the update 1e-6."""
+    import criterions
+    from avid_hip import ops
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSED_CRITERION", fused)
+        torch.manual_seed(5)
+        c = criterions.AVID_CMA(num_data=3000, embedding_dim=128, num_negatives=256, num_negatives_within=32, momentum=0.5,
+                                xModalInstCoeff=1., wModalInstCoeff=0., xModalPosCoeff=0., wModalPosCoeff=1.,
+                                sampling_args={"type": "consensus", "pos_k": 8}, device=gpu_device.index or 0)
+        g = torch.Generator().manual_seed(11)
+        out = []
+        for step in range(2):
+            v = torch.randn(6, 128, generator=g).to(gpu_device).requires_grad_(True)
+            a = torch.randn(6, 128, generator=g).to(gpu_device).requires_grad_(True)
+            yy = torch.randperm(3000, generator=g)[:6].to(gpu_device)
+            loss, tb = c(v, a, yy)
+            loss.backward()
+            out.append((float(loss), {k: float(x) for k, x in tb.items()}, v.grad.clone(), a.grad.clone()))
+        res.append((out, c.nce_average.view1_mem.clone(), c.nce_average.view2_mem.clone()))
+    (f, fb1, fb2), (u, ub1, ub2) = res
+    assert f[0][0] == u[0][0]                              # the first step is the unfused path either way
+    np.testing.assert_allclose(f[1][0], u[1][0], rtol=3e-6)
+    assert set(f[1][1]) == set(u[1][1])
+    for k in f[1][1]:
+        np.testing.assert_allclose(f[1][1][k], u[1][1][k], rtol=3e-6)
+    assert relerr(f[1][2], u[1][2]) < 2e-5 and relerr(f[1][3], u[1][3]) < 2e-5
+    assert relerr(fb1, ub1) < 1e-6 and relerr(fb2, ub2) < 1e-6
+
+
 def test_cma_negatives_bit_exact(golden, gpu_device):
     from avid_hip import ops
     g = golden("cma")

@@ -22,6 +22,9 @@ def short_name(name):
             strided, args = args[5] == "true", args[:5]
         elif short.startswith(("igemm", "stem")) and args[-1] in ("true", "false"):   # trailing bool = STRIDED
             strided, args = args[-1] == "true", args[:-1]
+        elif short in ("xmodal_fused_kernel", "xmodal_finish_kernel") and args[-1] in ("true", "false"):   # <CMA>: the timers' names
+            short = short.replace("xmodal", "cma") if args[-1] == "true" else short
+            args = args[:-1]
         elif short.startswith("wgrad_") and args[-1] in ("true", "false"):            # trailing bool = SPLIT (split-bf16 products): same timer name
             args = args[:-1]
         short += ("<" + ",".join(args) + ">" if args else "") + ("s2" if strided else "")
