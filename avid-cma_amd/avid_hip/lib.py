@@ -126,6 +126,8 @@ SIGNATURES = {
     "avid_conv_split_bytes": (_sz, [_dp]),
     "avid_wino_configure": (_i, [_i, _i64, _i]),
     "avid_wino2_configure": (_i, [_i]),
+    "avid_set_cu_budget": (_i, [_i]),
+    "avid_cu_budget": (_i, []),
     "avid_bn_workspace_bytes": (_sz, [_i64, _i]),
     "avid_bn_fwd_train": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "avid_bn_fwd_eval": (_i, [_i64, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),

@@ -342,6 +342,21 @@ def wino2_configure(min_rounds_x10=-1):
     _WINO_EPOCH[0] += 1
 
 
+def set_cu_budget(cus=0):
+    """CUs the persistent kernels plan for (``avid_set_cu_budget``; 0 = all): leaves the rest to co-running kernels such as
+    RCCL's collectives.  Drops the cached per-layer plans and bumps the epoch the compiled launch programs are keyed by;
+    returns the effective count."""
+    got = int(lib.raw("avid_set_cu_budget")(int(cus)))
+    _DESC_CACHE.clear()
+    _GROUP_WS_BYTES.clear()
+    _WINO_EPOCH[0] += 1
+    return got
+
+
+def cu_budget():
+    return int(lib.raw("avid_cu_budget")())
+
+
 def _bn_ws_bytes(M, Cc):
     key = (M, Cc)
     nb = _BN_WS_CACHE.get(key)

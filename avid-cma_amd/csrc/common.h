@@ -31,6 +31,10 @@ inline int check_launch(const char* what) {
     }                                 \
   } while (0)
 
+// CUs the persistent kernels size their grids for: the device's, or avid_set_cu_budget()'s / AVID_CU_RESERVE's fewer
+// (a multiple of 8: whole CUs per XCD) — common.hip
+int device_cus();
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Optional per-kernel timing with HIP events recorded on the launch stream (avid_timing_enable /

@@ -1,5 +1,6 @@
 // Error plumbing + device query for libavid_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <map>
 #include <string>
@@ -47,7 +48,43 @@ ScopedTimer::ScopedTimer(hipStream_t stream, const char* name, double flops, dou
 ScopedTimer::~ScopedTimer() {
   if (slot >= 0) (void)hipEventRecord(g_recs[slot].e1, s);
 }
+
+// ---- CU budget of the persistent kernels (include/avid_hip.h: avid_set_cu_budget)
+static int g_cu_budget = -1;      // -1: not configured (AVID_CU_RESERVE from the environment on first use); 0: every CU
+
+static int physical_cus() {       // per device: a process may touch more than one
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cus[dev]) {
+    hipDeviceProp_t pr;
+    int n = 0;
+    if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    cus[dev] = n > 0 ? n : 256;
+  }
+  return cus[dev];
+}
+
+int device_cus() {
+  const int phys = physical_cus();
+  if (g_cu_budget < 0) {
+    const char* e = getenv("AVID_CU_RESERVE");
+    const int reserve = e ? atoi(e) : 0;
+    g_cu_budget = reserve > 0 && reserve < phys ? phys - reserve : 0;
+  }
+  if (g_cu_budget <= 0 || g_cu_budget >= phys) return phys;
+  // whole CUs per XCD (the logical workgroup numberings deal a contiguous eighth of every round to each XCD), at least one
+  const int c = g_cu_budget / 8 * 8;
+  return c >= 8 ? c : 8;
+}
 }  // namespace avid
+
+extern "C" int avid_set_cu_budget(int cus) {
+  avid::g_cu_budget = cus > 0 ? cus : 0;
+  return avid::device_cus();
+}
+
+extern "C" int avid_cu_budget(void) { return avid::device_cus(); }
 
 extern "C" int avid_timing_enable(int on) {
   using namespace avid;

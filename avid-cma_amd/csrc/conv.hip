@@ -2146,17 +2146,6 @@ static void fill_src_strides(const avid_conv_desc* d, long long& sB, long long& 
   }
 }
 
-static int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
-
 template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED = false>
 static int launch_igemm(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;

@@ -1042,7 +1042,7 @@ size_t stem_fwd_ws_bytes(const avid_conv_desc* d) {
   const size_t split_path = stem_fwd3_ok(d) ? (size_t)stem_fwd3_steps(d) * S3_STEP_BYTES : 0;
   return fp32_path > split_path ? fp32_path : split_path;
 }
-int stem_wgrad_groups() { return 256; }
+int stem_wgrad_groups() { return device_cus(); }
 size_t stem_wgrad_ws_bytes(const avid_conv_desc* d) {
   return sizeof(float) * (size_t)stem_wgrad_groups() * 64 * d->Cin * d->kt * 7 * 8;
 }
@@ -1065,7 +1065,7 @@ static int stem_fwd_launch(const avid_conv_desc* d, const float* x, const float*
   const double M = (double)d->B * d->To * d->Ho * d->Wo, K = (double)CIN * KT * 49;
   ScopedTimer t(s, CIN == 3 ? "stem_fwd_kernel<3,3>" : "stem_fwd_kernel<1,1>", 2.0 * M * 64 * K,
                 4.0 * ((double)d->B * CIN * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
-  const int slots = (8 / WAVES) * 256;                    // workgroups resident on the 256 CUs
+  const int slots = (8 / WAVES) * device_cus();           // workgroups resident on the CUs
   const int grid = a.ntiles < slots ? a.ntiles : slots;
   hipLaunchKernelGGL((stem_fwd_kernel<CIN, KT, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s, a);
   return check_launch("stem_fwd");
@@ -1147,7 +1147,7 @@ static int stem_fwd3_launch(const avid_conv_desc* d, const float* x, const float
   const double M = (double)d->B * d->To * d->Ho * d->Wo, K = (double)CIN * KT * 49;
   ScopedTimer t(s, "stem_fwd3_kernel<3,3>", 2.0 * M * 64 * K,
                 4.0 * ((double)d->B * CIN * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
-  const int grid = a.ntiles < 256 ? a.ntiles : 256;
+  const int grid = a.ntiles < device_cus() ? a.ntiles : device_cus();
   hipLaunchKernelGGL((stem_fwd3_kernel<CIN, KT>), dim3(grid), dim3(512), stem_fwd3_lds(d), s, a);
   return check_launch("stem_fwd3");
 }
@@ -1157,13 +1157,13 @@ int stem_fwd_grid(const avid_conv_desc* d) {
   if (stem_fwd3_ok(d)) {
     StemArgs a{};
     stem_geometry(d, a, 256);
-    return a.ntiles < 256 ? a.ntiles : 256;
+    return a.ntiles < device_cus() ? a.ntiles : device_cus();
   }
   const int tile = stem_fwd_tile(d);
   if (!tile) return 0;
   StemArgs a{};
   stem_geometry(d, a, tile);
-  const int slots = tile == 128 ? 512 : 256;
+  const int slots = (tile == 128 ? 2 : 1) * device_cus();
   return a.ntiles < slots ? a.ntiles : slots;
 }
 

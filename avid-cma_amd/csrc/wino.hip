@@ -1090,18 +1090,7 @@ static int wino_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-static int wino_cus() {      // per device: a process may touch more than one
-  static int cus[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!cus[dev]) {
-    hipDeviceProp_t pr;
-    int n = 0;
-    if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
-    cus[dev] = n > 0 ? n : 256;
-  }
-  return cus[dev];
-}
+static int wino_cus() { return device_cus(); }
 
 // The switches of this path: AVID_WINO / AVID_WINO_MIN_M / AVID_WINO_MAXC from the environment, unless
 // avid_wino_configure() (include/avid_hip.h) has overridden them — tests force small fixtures through the kernel.

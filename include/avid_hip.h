@@ -171,6 +171,18 @@ int avid_wino_configure(int enabled, int64_t min_pixels, int max_channels);
  * layer through wino2_kernel (tests), negative restores the environment / default. */
 int avid_wino2_configure(int min_rounds_x10);
 
+/* CU budget of the persistent kernels.  igemm_pk_kernel, the stem kernels, the Winograd kernels and the grouped weight
+ * gradient size their grids for — and deal their tiles over — every CU of the device; a workgroup that cannot be placed
+ * (another kernel's long-lived workgroups hold the CU: RCCL's, when the gradient all-reduce of
+ * utils/main_utils.py:112 runs beside the backward pass) costs such a kernel a whole extra round.  cus > 0: plan for that
+ * many CUs (rounded down to a multiple of 8 = whole CUs per XCD, at least 8); cus <= 0: every CU (the default; the
+ * environment variable AVID_CU_RESERVE = n starts the process at device CUs - n).  Returns the effective count, as does
+ * avid_cu_budget().  Like the Winograd switches it changes what the *_workspace_bytes / *_rows queries answer: callers
+ * that cache them must drop the cache (ops.set_cu_budget does).  Results stay deterministic at any budget; they are
+ * bit-identical across budgets only for layers whose K-split / slab plan does not depend on the CU count. */
+int avid_set_cu_budget(int cus);
+int avid_cu_budget(void);
+
 /* dw[Cout][kt][kh][kw][Cin] = sum_m dy[m][:]^T x_col[m][:]  (deterministic split-M + tree reduce). */
 size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d);
 int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,

@@ -34,7 +34,9 @@ IDENTICAL = [{"AVID_PLAN": "0"}, {"AVID_OVERLAP_TOWERS": "0"}, {"AVID_DEFER_WGRA
              {"AVID_HIP_LIB": os.path.join(os.path.dirname(HERE), "avid-cma_amd", "avid_hip", "libavid_hip.so")}]
 CLOSE = [{"AVID_GROUP_WGRAD": "0"}, {"AVID_WGRAD_BF16X3": "0"}, {"AVID_FUSE_BN_BWD": "0"}, {"AVID_FUSE_BN_STATS": "0"}, {"AVID_FUSE_RES": "0"},
          {"AVID_FUSE_STEM_TAIL": "0"}, {"AVID_FUSED_CRITERION": "0"}, {"AVID_WINO": "0"}, {"AVID_WINO_WGRAD": "0"},
-         {"AVID_TRIM_TAPS": "0"}, {"AVID_STEM_BF16X3": "0"}]
+         {"AVID_TRIM_TAPS": "0"}, {"AVID_STEM_BF16X3": "0"},
+         # eight CUs (one per XCD) left to co-running kernels: other K-splits / slab counts, i.e. another summation order
+         {"AVID_CU_RESERVE": "8"}]
 
 
 @pytest.mark.parametrize("env", IDENTICAL, ids=lambda e: ",".join(f"{k}={v if len(v) < 9 else '...'}" for k, v in e.items()))
@@ -58,3 +60,21 @@ def test_kernel_switches_agree_to_summation_noise(default_run, env):
     #  (the stem's switch changes the roundings of the first layer, i.e. the input of every other one)
     loose = "AVID_WINO" in env or "AVID_STEM_BF16X3" in env
     assert np.abs(a - b).max() <= (2e-2 if loose else 1e-3) * np.abs(b).max() + 1e-7
+
+
+def test_cu_budget_is_deterministic_and_reported(gpu_device):
+    """A budget changes the persistent kernels' plans (tile deal, K-splits, slab counts), never the arithmetic: two runs at
+    the same budget are bit-identical, and the library reports the CUs it plans for (a multiple of 8)."""
+    a = _probe({"AVID_CU_RESERVE": "8"})
+    b = _probe({"AVID_CU_RESERVE": "8"})
+    assert a["losses"] == b["losses"] and a["grad_sha"] == b["grad_sha"]
+    import torch
+    from avid_hip import ops
+    full = ops.cu_budget()
+    try:
+        assert ops.set_cu_budget(full - 8) == (full - 8) // 8 * 8
+        assert ops.set_cu_budget(full - 3) == (full - 3) // 8 * 8
+        assert ops.set_cu_budget(1) == 8
+        assert ops.set_cu_budget(10 * full) == full
+    finally:
+        assert ops.set_cu_budget(0) == full == torch.cuda.get_device_properties(0).multi_processor_count

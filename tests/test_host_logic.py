@@ -144,3 +144,30 @@ def test_model_checkpoint_interchange(tmp_path):
     torch.save({"model": {"module." + k: v for k, v in back.items()}}, path)
     again = torch.load(path, map_location="cpu")["model"]
     assert all(torch.equal(again["module." + k].contiguous(), ref_sd["module." + k]) for k in back)
+
+
+def test_bench_launcher_argument_handling():
+    """`python bench.py --gpus N` starts its own ranks (as main-avid.py:69-78 does with mp.spawn) unless it already is one."""
+    import importlib.util
+    import os
+    import pytest
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # a plain one-GPU run and a rank started by torch.distributed.run are not re-launched
+    assert bench.launcher_command(1, ["--steps", "3"], 1, {}) is None
+    assert bench.launcher_command(8, ["--gpus", "8"], 8, {"WORLD_SIZE": "8", "RANK": "3"}) is None
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "7"], 8, {})
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert bench.launcher_command(2, [], 2, {"MASTER_PORT": "29999"})[8] == "29999"
+    # the one-rank RCCL group of the 1-GPU box check goes the same way
+    forced = bench.launcher_command(1, [], 1, {"AVID_FORCE_DIST": "1"})
+    assert "--nproc-per-node=1" in forced
+    # more ranks than GPUs: the message names the device count
+    with pytest.raises(SystemExit) as e:
+        bench.launcher_command(2, ["--gpus", "2"], 1, {})
+    assert "shows 1 GPU" in str(e.value) and "--gpus 2" in str(e.value)
+    with pytest.raises(SystemExit):
+        bench.launcher_command(8, [], 0, {})
