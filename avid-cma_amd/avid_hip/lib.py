@@ -124,6 +124,7 @@ SIGNATURES = {
     "avid_conv_uses_wino": (_i, [_dp, _i]),
     "avid_conv_uses_split": (_i, [_dp, _i]),
     "avid_conv_split_bytes": (_sz, [_dp]),
+    "avid_debug_presplit_launches": (C.c_longlong, []),
     "avid_wino_configure": (_i, [_i, _i64, _i]),
     "avid_wino2_configure": (_i, [_i]),
     "avid_set_cu_budget": (_i, [_i]),

@@ -74,21 +74,44 @@ class FlatBuffers:
     per step on every rank and is identical everywhere by construction."""
 
     def __init__(self, module: torch.nn.Module):
-        own = getattr(module, "_bn_flat", None)          # (models.AV_Wrapper's own flat buffer for DDP: superseded here)
-        self.bufs = [b for b in module.buffers() if b.is_floating_point() and b is not own]
+        # ONE owner.  models.AV_Wrapper keeps its floating-point buffers in its own flat tensor (`_bn_flat`, what torch's DDP
+        # broadcasts) and re-seats them there on every forward: a second flat tensor here would be orphaned by the first
+        # evaluation / per-layer forward, and sync_buffers() would then broadcast a tensor nobody reads.  So the module's
+        # buffer is ADOPTED (looked up at every use: `.to()` / `.cuda()` re-create it), and only a module without one gets
+        # a flat tensor of this class's making.
+        self.module = module if (hasattr(module, "_seat_flat_buffers") and getattr(module, "_bn_flat", None) is not None) else None
+        if self.module is not None:
+            module._seat_flat_buffers()
+            mods = dict(module.named_modules())
+            self.bufs, self.offsets = [], []
+            for n, off, cnt in module._bn_layout:
+                owner, _, leaf = n.rpartition(".")
+                self.bufs.append(getattr(mods[owner], leaf))
+                self.offsets.append(off)
+            self.numel = module._bn_flat.numel()
+            self._flat = None
+            return
+        self.bufs = [b for b in module.buffers() if b.is_floating_point()]
         self.offsets, off = [], 0
         for b in self.bufs:
             self.offsets.append(off)
             off += (b.numel() + 3) // 4 * 4
         self.numel = off
         if not self.bufs:
-            self.flat = None
+            self._flat = None
             return
-        self.flat = torch.zeros(off, dtype=self.bufs[0].dtype, device=self.bufs[0].device)
+        self._flat = torch.zeros(off, dtype=self.bufs[0].dtype, device=self.bufs[0].device)
         for b, o in zip(self.bufs, self.offsets):
-            view = self.flat[o:o + b.numel()].view(b.shape)
+            view = self._flat[o:o + b.numel()].view(b.shape)
             view.copy_(b)
             b.data = view
+
+    @property
+    def flat(self):
+        if self.module is not None:
+            self.module._seat_flat_buffers()             # (no-op unless the buffers were re-created since)
+            return self.module._bn_flat
+        return self._flat
 
     def broadcast(self, src=0, async_op=False):
         if self.flat is None or not _dist_on():
@@ -123,7 +146,8 @@ class GradBuckets:
         self.launched = [False] * len(self.bounds)        # bucket b's collective has been issued this step
         self.works = []
         self.hooks = []
-        self.comm_used = None         # the collectives' stream, if a bucket went out on it this step
+        self.comm_used = []           # every collectives' stream a bucket went out on this step (normally one)
+        self.step_set = None          # the step's StreamSet, resolved once per step (first bucket)
         self.measure = False          # bench.py: event-time the compute stream's wait for the collectives in finish()
         self.wait_events = []
         self.producers = [set() for _ in self.bounds]     # streams that issued gradients of each bucket
@@ -173,14 +197,20 @@ class GradBuckets:
             return
         from . import lib, streams
         dev = self.flat.grad.device
-        ss = streams.current_set(dev)
+        # ONE StreamSet per step: the first bucket resolves it (from whichever of the set's streams is current — the
+        # per-layer path reports deferred weight gradients with the trailing stream current), the rest of the step reuses
+        # it, so every bucket goes out on the same comm stream of the same RCCL communicator
+        ss = self.step_set
+        if ss is None:
+            ss = self.step_set = streams.current_set(dev)
         prod = self.producers[b] or {ss.main, ss.side, ss.trail}      # unknown producers: everything
         cs = ss.comm
         for st in prod:
             lib.call("avid_stream_wait", cs.cuda_stream, st.cuda_stream)
         with torch.cuda.stream(cs):
             dist.all_reduce(self.flat.grad[s:e])
-        self.comm_used = cs
+        if all(cs is not c for c in self.comm_used):
+            self.comm_used.append(cs)
 
     def exposed_wait_ms(self):
         """Mean time per step the compute stream spent waiting for the gradient collectives in ``finish()`` since
@@ -219,13 +249,14 @@ class GradBuckets:
                 e0.record()
             for w in self.works:
                 w.wait()                             # (CPU tensors: gloo)
-            if self.comm_used is not None:
-                torch.cuda.current_stream(self.flat.grad.device).wait_stream(self.comm_used)
-                self.comm_used = None
+            for cs in self.comm_used:
+                torch.cuda.current_stream(self.flat.grad.device).wait_stream(cs)
+            self.comm_used = []
             if timed:
                 e1.record()
                 self.wait_events.append((e0, e1))
         self.works = []
+        self.step_set = None
         self.pending = list(self.counts)
         self.launched = [False] * len(self.bounds)
         for p in self.producers:

@@ -84,7 +84,7 @@ def place(device=None):
     if torch.cuda.is_current_stream_capturing() or os.environ.get("AVID_STREAM_PROBE", "1") != "1":
         s = [torch.cuda.Stream(device) for _ in range(3)]
         hit = _PLACED[key] = StreamSet(main, s[0], s[1], s[2], {"probed": False})
-        _BY_SIDE[(device.index, hit.side.cuda_stream)] = hit
+        _register(device, hit)
         return hit
     with torch.cuda.device(device):
         _alone_us(main)                                       # (first launch: module load)
@@ -104,20 +104,30 @@ def place(device=None):
     report = {"probed": True, "alone_us": round(alone, 1), "candidates": tried, "rejected": rejected,
               "independent": len(set(id(c) for c in chosen))}
     hit = _PLACED[key] = StreamSet(main, chosen[1], chosen[2], chosen[3], report)
-    _BY_SIDE[(device.index, hit.side.cuda_stream)] = hit
+    _register(device, hit)
     return hit
 
 
-_BY_SIDE = {}
+_BY_MEMBER = {}
+
+
+def _register(device, ss):
+    """Reverse lookup: every helper stream of a set names the set (first registration wins: a helper never becomes the
+    compute stream of another set behind the step's back)."""
+    for st in (ss.side, ss.trail, ss.comm):
+        _BY_MEMBER.setdefault((device.index, st.cuda_stream), ss)
 
 
 def current_set(device):
-    """The StreamSet the current stream belongs to — as its compute stream or as its audio-tower stream (autograd runs
-    the audio tower's backward nodes with that stream current) — placing one if the stream is new."""
+    """The StreamSet the current stream belongs to — as its compute stream, or as one of its helpers: autograd runs the
+    audio tower's backward nodes with the tower's stream current, the per-layer path reports deferred weight gradients
+    with the trailing stream current (``GradBuckets.ready`` -> ``_issue``), a collective may be issued from the
+    collectives' stream.  Only a stream that belongs to no set is placed: probing (host-blocking, up to 24 new streams)
+    never happens in the middle of a backward pass, and a bucket never goes out on a second comm stream."""
     raw = torch._C._cuda_getCurrentRawStream(device.index)
     hit = _PLACED.get((device.index, raw))
     if hit is None:
-        hit = _BY_SIDE.get((device.index, raw))
+        hit = _BY_MEMBER.get((device.index, raw))
     return hit if hit is not None else place(device)
 
 

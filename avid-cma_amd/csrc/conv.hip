@@ -2297,10 +2297,13 @@ constexpr bool pk_takes_split() {
   return PK_SPLIT && WM == 4 && WN == 1 && TM == 1 && TN == 2 && (EPI == 0 || EPI == 1 || EPI == 8 || EPI == 9);
 }
 
+static long long g_presplit_launches = 0;    // avid_debug_presplit_launches (tests: which instruction sequence a layer ran)
+
 template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED, int EPI>
 static void launch_pk_e(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
   if constexpr (pk_takes_split<WM, WN, TM, TN, EPI>()) {
     if (a.wsp) {
+      ++g_presplit_launches;
       constexpr int BM = WM * TM * 32;
       const size_t lds3 = sizeof(float) * 2 * (BM * LDK + PK_BCH / 4) + (STRIDED ? sizeof(int) * 2 * BM : 0);
       launch_pk_eb<WM, WN, TM, TN, MODE, STRIDED, EPI, true>(a, grid, lds3, s);
@@ -2750,6 +2753,8 @@ static bool conv_takes_split(const avid_conv_desc* d, int which) {
   if (d->st > 1 || d->sh > 1 || d->sw > 1) return M * d->Cin * 4 < (1ll << 31) && d->Cin % 128 != 0;
   return plan_pk(M, d->Cin, trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK), 1).tile == 1;
 }
+
+extern "C" long long avid_debug_presplit_launches(void) { return g_presplit_launches; }
 
 extern "C" int avid_conv_uses_split(const avid_conv_desc* d, int which) {
   if (!d || validate(d) || which < 0 || which > 1) return 0;

@@ -4,6 +4,7 @@
 // binding would make one by one (avid-cma_amd/avid_hip/ops.py), so results are bit-identical — and places the
 // cross-stream dependencies itself.  Host cost per record: reference resolution (a few adds) + the entry point's own
 // dispatch + hipLaunchKernel; no interpreter, no allocator, no autograd node.
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -12,9 +13,14 @@ namespace avid {
 
 // Events for AVID_OP_WAIT.  An event may be re-recorded while an earlier wait on it is still pending: a
 // hipStreamWaitEvent captures the record that is current when it is called.  One pool per device, round-robin.
+// The index is atomic: the thread that runs the forward program and autograd's thread (the backward program) both draw
+// from the pool; the events themselves are created on first use under a flag (the first call of a process is the
+// forward's).  Contract (include/avid_hip.h, avid_stream_wait): an event is re-used after 64 draws — a wait is "consumed"
+// the moment hipStreamWaitEvent returns, so re-recording never disturbs an earlier wait.
 struct EventPool {
-  std::vector<hipEvent_t> ev;
-  size_t next = 0;
+  hipEvent_t ev[64];
+  std::atomic<unsigned> next{0};
+  std::atomic<int> ready{0};      // 0: empty, 1: being filled, 2: filled
 };
 static EventPool g_wait_events[16];
 
@@ -22,13 +28,17 @@ static hipEvent_t wait_event() {
   int dev = 0;
   (void)hipGetDevice(&dev);
   EventPool& p = g_wait_events[dev & 15];
-  if (p.ev.empty()) {
-    p.ev.resize(64);
-    for (auto& e : p.ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  int st = p.ready.load(std::memory_order_acquire);
+  if (st != 2) {
+    int expect = 0;
+    if (p.ready.compare_exchange_strong(expect, 1)) {
+      for (auto& e : p.ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      p.ready.store(2, std::memory_order_release);
+    } else {
+      while (p.ready.load(std::memory_order_acquire) != 2) {}
+    }
   }
-  hipEvent_t e = p.ev[p.next];
-  p.next = (p.next + 1) % p.ev.size();
-  return e;
+  return p.ev[p.next.fetch_add(1, std::memory_order_relaxed) & 63];
 }
 
 static inline size_t maxz(size_t a, size_t b) { return a > b ? a : b; }
@@ -136,13 +146,30 @@ extern "C" int avid_program_run(const avid_instr* prog, int begin, int end, void
                                 const avid_stream_t* streams, const avid_stream_ws* ws, int n_streams) {
   AVID_REQUIRE(prog && slots && streams && ws && begin >= 0 && end >= begin && n_streams > 0, AVID_E_BADARG,
                "program_run: bad arguments");
-  int bad_slot = 0;
+  // every tensor reference of [begin, end) is resolved BEFORE the first launch: a reference to an empty or out-of-range
+  // slot would otherwise become a null OPTIONAL operand (addend, statistics, pre-split weights ...) and run the record
+  // with other semantics, behind records that have already been launched
+  constexpr int NREF = (int)(sizeof(prog[0].t) / sizeof(prog[0].t[0]));
+  for (int k = begin; k < end; ++k) {
+    const avid_instr& in = prog[k];
+    if (in.op == AVID_OP_NOP) continue;
+    AVID_REQUIRE(in.op > AVID_OP_NOP && in.op < AVID_OP_COUNT_, AVID_E_BADARG, "program record %d: unknown kind %d", k, in.op);
+    if (in.op == AVID_OP_WAIT) {
+      AVID_REQUIRE(in.i[0] >= 0 && in.i[0] < n_streams && in.i[1] >= 0 && in.i[1] < n_streams, AVID_E_BADARG,
+                   "program record %d: wait %d <- %d of %d streams", k, in.i[0], in.i[1], n_streams);
+      continue;
+    }
+    if (in.op != AVID_OP_WGRAD_ITEM)
+      AVID_REQUIRE(in.stream >= 0 && in.stream < n_streams, AVID_E_BADARG, "program record %d: stream %d of %d", k, in.stream, n_streams);
+    for (int j = 0; j < NREF; ++j) {
+      const int sl = in.t[j].slot;
+      AVID_REQUIRE(sl < 0 || (sl < n_slots && slots[sl]), AVID_E_BADARG,
+                   "program record %d (kind %d): tensor reference %d names slot %d — outside [0, %d) or empty; nothing was launched",
+                   k, in.op, j, sl, n_slots);
+    }
+  }
   auto P = [&](const avid_ref& r) -> char* {
     if (r.slot < 0) return nullptr;
-    if (r.slot >= n_slots || !slots[r.slot]) {
-      bad_slot = 1;
-      return nullptr;
-    }
     return static_cast<char*>(slots[r.slot]) + r.off;
   };
 #define F(r) reinterpret_cast<float*>(P(r))
@@ -266,10 +293,6 @@ extern "C" int avid_program_run(const avid_instr* prog, int begin, int end, void
       default:
         set_error("program record %d: unknown kind %d", k, in.op);
         return AVID_E_BADARG;
-    }
-    if (bad_slot) {
-      set_error("program record %d (kind %d): a tensor reference names slot outside [0, %d) or an empty slot", k, in.op, n_slots);
-      return AVID_E_BADARG;
     }
     if (rc != AVID_OK) {
       char msg[400];

@@ -86,6 +86,16 @@ class AV_Wrapper(nn.Module):
             self._ddp_params_and_buffers_to_ignore = [n for n, _ in named]
         self._bn_seated = None
 
+    def _apply(self, fn, *args, **kwargs):
+        # `.to()` / `.cuda()` / `.float()` re-create every buffer: seat them again at once, so that whoever looks at
+        # `_bn_flat` next — DistributedDataParallel's construction-time `_sync_module_states`, which skips the ignored
+        # per-layer buffers and broadcasts this one — finds the real statistics in it, not zeros
+        out = super()._apply(fn, *args, **kwargs)
+        if "_bn_layout" in self.__dict__:
+            self._bn_seated = None
+            self._seat_flat_buffers()
+        return out
+
     def _seat_flat_buffers(self):
         """Make every floating-point BatchNorm buffer a view of `_bn_flat` (again: `.to()` / `.cuda()` re-create buffers)."""
         flat = getattr(self, "_bn_flat", None)

@@ -156,6 +156,9 @@ int avid_conv_uses_wino(const avid_conv_desc* d, int which);
  * weights as they are (and avid_conv_dgrad on wt): both forms are fp32-accurate, their roundings differ. */
 int avid_conv_uses_split(const avid_conv_desc* d, int which);
 size_t avid_conv_split_bytes(const avid_conv_desc* d);
+/* Launches of igemm_pk_kernel that consumed a pre-split weight table since the library was loaded (tests assert that
+ * avid_conv_uses_split and the kernel that ran agree; the HIP-event log names both forms igemm_pk_kernel<...>). */
+long long avid_debug_presplit_launches(void);
 
 /* Dispatch switches of the Winograd path (defaults: on, layers of >= 6000 output pixels, <= 256 output channels and
  * pixels x max(Cin, Cout) >= 1e6; environment AVID_WINO / AVID_WINO_MIN_M / AVID_WINO_MAXC / AVID_WINO_MIN_WORK — an
@@ -509,7 +512,14 @@ int avid_probe_spin(int us, avid_stream_t stream);
 int avid_clock_probe(int us, long long* out2, avid_stream_t stream);
 /* Everything issued to `waiter` after this call runs behind everything issued to `waited` before it (one event of the
  * executor's pool: record + wait) — what AVID_OP_WAIT does inside a program, for a binding that orders its collectives'
- * stream behind the streams that produced a gradient bucket. */
+ * stream behind the streams that produced a gradient bucket.
+ * The event pool's contract: 64 events per device, drawn round-robin through an atomic index by avid_stream_wait and by
+ * every AVID_OP_WAIT record (the forward's thread and autograd's backward thread may both draw).  An event is re-recorded
+ * after 64 further draws whether or not the GPU has passed the earlier wait: that is safe because hipStreamWaitEvent
+ * captures the record that is current WHEN IT IS CALLED (a later hipEventRecord on the same event does not move an
+ * earlier wait), and the pair record + wait is issued back to back on the calling thread.  It would NOT be safe for a
+ * caller to keep an event of its own across calls, and none is handed out.  Under a stream capture the same pair
+ * becomes a graph dependency. */
 int avid_stream_wait(avid_stream_t waiter, avid_stream_t waited);
 /* sizeof(avid_instr) as the library was compiled: a binding checks its mirror of the record against it. */
 size_t avid_program_instr_bytes(void);

@@ -78,7 +78,20 @@ def test_program_executor_rejects_malformed_programs():
     prog[0].op = 1                                         # a wait between streams 0 and 5 of 2
     prog[0].i[0], prog[0].i[1] = 0, 5
     assert run(prog, 0, 1, slots, 4, streams, ws, 2) < 0 and "wait" in lib.last_error()
-    prog[0].op = 0                                         # nop records run to the end
+    # a tensor reference to an empty / out-of-range slot is refused before ANY record is dispatched (a null optional
+    # operand would run the record with other semantics): record 1 is bad, record 0 (a memset that would fault) never runs
+    for j in range(12):
+        prog[0].t[j].slot = prog[1].t[j].slot = -1
+    prog[0].op, prog[0].stream, prog[0].n[0] = 2, 0, 1 << 40
+    prog[0].t[0].slot = 1
+    slots[1] = 0xdead0000
+    prog[1].op, prog[1].stream = 15, 0
+    prog[1].t[0].slot, prog[1].t[1].slot = 1, 9
+    assert run(prog, 0, 2, slots, 4, streams, ws, 2) < 0
+    assert "record 1" in lib.last_error() and "slot 9" in lib.last_error() and "nothing was launched" in lib.last_error()
+    prog[1].t[1].slot = 2                                  # in range, but empty
+    assert run(prog, 0, 2, slots, 4, streams, ws, 2) < 0 and "slot 2" in lib.last_error()
+    prog[0].op = prog[1].op = 0                            # nop records run to the end
     assert run(prog, 0, 2, slots, 4, streams, ws, 2) == 0
     need = (C.c_size_t * 2)()
     assert lib.raw("avid_program_workspace_bytes")(prog, 0, 2, 2, need) == 0 and list(need) == [0, 0]

@@ -103,9 +103,12 @@ class _RecordUpdates:
 
 
 # ----------------------------------------------------------------------------------------------- workers
-def _train_job(rank, world, out):
+def _train_job(rank, world, out, per_layer=False):
     import torch.distributed as dist
     from avid_hip.parallel import TrainStep
+    if per_layer:           # the per-layer autograd path (what a hooked / partly frozen model falls back to): deferred weight
+        from avid_hip import plan     # gradients report their buckets with the TRAILING stream current
+        plan.ENABLED = False
     dev = torch.device("cuda", 0)
     m = _model(dev)
     if rank == 1:                                    # ranks start DIFFERENT: the construction broadcast must fix it
@@ -139,8 +142,21 @@ def _train_job(rank, world, out):
         res["banks"].append((crit.nce_average.view1_mem.clone().cpu(), crit.nce_average.view2_mem.clone().cpu()))
         res["updates"].append(rec.calls)
     res["params_final"] = eng.flat.flat.clone().cpu()
+    from avid_hip import streams
+    res["stream_sets"] = len(streams._PLACED)
+    # an evaluation forward (per-layer path, AV_Wrapper.forward re-seats its buffers) must not orphan the tensor that
+    # sync_buffers() broadcasts: ONE owner of the BatchNorm statistics
+    m.eval()
+    with torch.no_grad():
+        m(v, a)
+    m.train()
+    res["bn_mean_before_sync"] = m.video_model.conv1[1].running_mean.clone().cpu()
     eng.sync_buffers()
     res["bn_mean_synced"] = m.video_model.conv1[1].running_mean.clone().cpu()
+    res["bn_all_synced"] = torch.cat([b.detach().flatten().float().cpu() for n, b in m.named_buffers()
+                                      if b.is_floating_point() and n != "_bn_flat"])
+    res["one_owner"] = all(b.untyped_storage().data_ptr() == eng.flat_buffers.flat.untyped_storage().data_ptr()
+                           for n, b in m.named_buffers() if b.is_floating_point())
     res["audio_bn_after_init"] = None
     from avid_hip import ops
     ops.check_device_errors(dev)
@@ -181,7 +197,11 @@ def _ddp_job(rank, world, out):
     crit.criterion.avg_exp_score.fill_(float(os.environ["TWO_RANK_Z"]))
     from avid_hip import ops
     ops.FUSED_CRITERION = False          # compared bit for bit with _single(), which runs the unfused criterion ops
+    if rank == 1:                                    # ranks start with DIFFERENT statistics: DDP's construction-time
+        with torch.no_grad():                        # _sync_module_states must install rank 0's (through _bn_flat)
+            m.audio_model.conv1[1].running_mean.fill_(3.0)
     ddp = DDP(m, device_ids=[0])
+    flat_at_wrap = m._bn_flat.clone().cpu()
     video, audio = _inputs()
     v = video[rank * BS:(rank + 1) * BS].to(dev)
     a = audio[rank * BS:(rank + 1) * BS].to(dev)
@@ -195,18 +215,27 @@ def _ddp_job(rank, world, out):
     # ONE tensor (models.AV_Wrapper._bn_flat) of which the BatchNorm modules' own buffers are views
     own_stats = {n: b.clone().cpu() for n, b in m.named_buffers() if n.endswith("running_var")}
     n_bcast = sum(1 for n, _ in m.named_buffers() if n not in ddp.parameters_to_ignore)
+    # second forward: the broadcast in front of it installs rank 0's statistics on every rank.  The training-mode forward
+    # then updates them again from each rank's own shard, so what the broadcast installed is read where it is visible: in
+    # a forward pre-hook of the wrapped module (DDP broadcasts before it calls module.forward)
+    seen = {}
+    hook = m.register_forward_pre_hook(lambda mod, args: seen.setdefault("flat", mod._bn_flat.clone().cpu()))
     with torch.no_grad():
-        ddp(v, a)                                    # second forward: the broadcast in front of it carries rank 0's statistics
+        ddp(v, a)
+    hook.remove()
     torch.cuda.synchronize()
-    # (the training-mode forward has updated them once more on every rank from ITS shard: compare what the broadcast
-    #  installed through a module the forward does not touch ... every BatchNorm is touched, so: undo one EMA step)
     return {"loss": float(loss), "overlap": bool(m.overlap_towers), "grads": grads, "stats_after_step0": own_stats,
-            "broadcast_tensors": n_bcast,
+            "broadcast_tensors": n_bcast, "flat_after_broadcast": seen["flat"],
+            "flat_at_wrap": flat_at_wrap,
             "views": all(b.untyped_storage().data_ptr() == m._bn_flat.untyped_storage().data_ptr()
                          for n, b in m.named_buffers() if b.is_floating_point())}
 
 
-_JOBS = {"train": _train_job, "cma": _cma_job, "ddp": _ddp_job}
+def _train_job_per_layer(rank, world, out):
+    return _train_job(rank, world, out, per_layer=True)
+
+
+_JOBS = {"train": _train_job, "train_pl": _train_job_per_layer, "cma": _cma_job, "ddp": _ddp_job}
 
 
 def _worker(rank, world, port, out, job):
@@ -317,6 +346,19 @@ def test_two_rank_training_step(tmp_path, gpu_device):
     assert not torch.equal(r[0]["params_final"], r[0]["params0"])
     assert torch.equal(r[0]["bn_mean_synced"], r[0]["bn_mean"][-1])                   # rank 0's statistics win
     assert torch.equal(r[1]["bn_mean_synced"], r[0]["bn_mean"][-1])
+    # ... although an evaluation forward ran on both ranks before sync_buffers(): the buffers and the tensor that is
+    # broadcast have ONE owner (every statistic of rank 1 equals rank 0's afterwards, not only the probed one)
+    assert not torch.equal(r[1]["bn_mean_before_sync"], r[0]["bn_mean_before_sync"])
+    assert torch.equal(r[0]["bn_all_synced"], r[1]["bn_all_synced"]) and r[0]["one_owner"] and r[1]["one_owner"]
+    assert r[0]["stream_sets"] == 1 and r[1]["stream_sets"] == 1
+    # ---- the same job on the per-layer path (deferred weight gradients report their buckets from the trailing stream):
+    #      one StreamSet, every bucket on its one comm stream, the same all-reduced gradients and parameters bit for bit
+    rp = _run2("train_pl", tmp_path)
+    for rank in range(2):
+        assert rp[rank]["stream_sets"] == 1
+        assert torch.equal(rp[rank]["grad0"], r[rank]["grad0"])
+        assert torch.equal(rp[rank]["params_final"], r[rank]["params_final"])
+        assert rp[rank]["loss"] == r[rank]["loss"]
     # ---- all-gathered records arrive in rank order on both ranks; duplicate id 77 (global positions 1 and 2):
     #      the highest global position — rank 1's sample — owns the row (criterions/avid.py:108-129)
     for rank in range(2):
@@ -337,6 +379,12 @@ def test_two_rank_training_step(tmp_path, gpu_device):
     assert d[0]["broadcast_tensors"] == 1 and d[0]["views"] and d[1]["views"]
     k0 = next(iter(d[0]["stats_after_step0"]))
     assert not torch.equal(d[0]["stats_after_step0"][k0], d[1]["stats_after_step0"][k0])
+    # ... the wrap installed rank 0's statistics on rank 1 (which had been set to something else), and the broadcast in
+    # front of the second forward installed rank 0's step-0 statistics on rank 1
+    assert torch.equal(d[0]["flat_at_wrap"], d[1]["flat_at_wrap"]) and float(d[1]["flat_at_wrap"].abs().max()) > 0
+    assert float(d[1]["flat_at_wrap"].max()) < 3.0
+    assert torch.equal(d[0]["flat_after_broadcast"], d[1]["flat_after_broadcast"])
+    assert not torch.equal(d[0]["flat_after_broadcast"], d[0]["flat_at_wrap"])
     eng = s1["eng"]
     for i, p in enumerate(eng.flat.params):
         name = next(n for n, q in s1["model"].named_parameters() if q is p)
