@@ -84,6 +84,7 @@ struct ConvArgs {
   // (avid_wt_desc mode 5 / 6): base of the first live tap's chunks, bytes addressable from it, bytes between two k-tiles
   const void* wsp;
   int wsp_nrec, wsp_kstep;
+  int stats_rows;  // tconv64_kernel: rows of `stats` the caller will fold (avid_conv_fwd_stats_rows / avid_conv_dgrad_bn_rows)
 };
 
 constexpr int BK = 32;
@@ -1109,6 +1110,260 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   }
   write_stats();
   PK_STAMP(31);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tconv64_kernel<MODE, EPI> — the (3,1,1) stride-1 pad-1 layers of conv2x (models/network_blocks.py:37,42 at 64 -> 64
+// channels, 8 frames): forward (MODE 0) and input gradient (MODE 1), split-bf16 products.  (round 5)
+//
+// igemm_pk_kernel stages one A tile per (tap, 32-channel block): a temporal layer's input rows travel HBM/L2 -> registers
+// -> LDS three times, once per tap, and a k-tile holds 24 matrix instructions per wave — too few to cover the round trip
+// (58 us without the global loads, 83 with).  Here a tile is 32 POSITIONS x ALL 8 FRAMES (256 GEMM rows,
+// wave w = output frame w): a 32-channel block of it is staged ONCE and serves the three taps as LDS rows shifted by a
+// frame (tap d of output frame t reads frame t + d - 1 forward, t + 1 - d for the input gradient; a frame outside the
+// clip is the zero padding: the wave skips that tap), and the 72 KB of pre-split weights (avid_wt_desc mode 5 / 6: six
+// PK_BCH chunks) sit in LDS for the whole kernel.  Per staged block and wave: 72 matrix instructions, 4 global loads and
+// 4 LDS stores per thread, ONE barrier — a third of the loads / stores / barriers per product, no weight traffic, and
+// every input row is read by exactly one workgroup (HBM traffic = the algorithmic bytes).
+// One persistent workgroup of 8 waves per CU (147 KB of LDS), tiles slot, slot + G, ...; the loader runs two
+// blocks ahead through registers, across tile boundaries.
+// Epilogues as igemm_pk_kernel's direct ones: BatchNorm partial sums of the output (forward, p.stats), addend, the
+// BatchNorm-backward sums of the gradient being written (input gradient, EPI 8 / 9).
+// ------------------------------------------------------------------------------------------------
+constexpr int TC_P = 32;                      // positions per tile
+constexpr int TC_T = 8;                       // frames (= waves)
+constexpr int TC_ROWS = TC_P * TC_T;
+constexpr int TC_B_BYTES = 6 * PK_BCH;        // 3 taps x 2 channel blocks
+constexpr int TC_STAGE = TC_ROWS * LDK;       // floats per A stage (one 32-channel block)
+constexpr size_t TC_LDS = TC_B_BYTES + (2 * TC_STAGE + TC_P * LDK) * sizeof(float);     // weights | two A stages | a frame of zeros
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void tconv64_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* Bs = reinterpret_cast<char*>(smem);
+  float* As = smem + TC_B_BYTES / 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+  const int G = gridDim.x;
+  const int slot = __builtin_amdgcn_readfirstlane((int)xcd_remap(blockIdx.x, G));
+  const int HW = p.Hs * p.Ws;
+  const int NP = p.B * HW;                                  // positions
+  const int ntiles = (NP + TC_P - 1) / TC_P;
+  const int nmine = slot < ntiles ? (ntiles - slot + G - 1) / G : 0;
+  const int nitems = 2 * nmine;                             // (tile, channel block) items of this workgroup
+  const int frame_bytes = HW * 256;                         // one frame of 64-channel fp32 rows
+
+  float cs[2][2], cq[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) cs[j][0] = cs[j][1] = cq[j][0] = cq[j][1] = 0.f;
+  auto write_stats = [&]() {                                // one partial row [2][64] per workgroup + zero rows up to the promise
+    if (!p.stats) return;
+    float* red = As;                                        // [2][8 waves][64]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a0 = cs[j][0] + cs[j][1], b0 = cq[j][0] + cq[j][1];
+      const float a = a0 + __shfl_xor(a0, 32, 64), b = b0 + __shfl_xor(b0, 32, 64);
+      if (h == 0) {
+        red[wave * 64 + j * 32 + l31] = a;
+        red[512 + wave * 64 + j * 32 + l31] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid & 63, which = tid >> 6;
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += red[which * 512 + w * 64 + c];
+      p.stats[(long long)slot * 128 + which * 64 + c] = a;
+      for (int r = slot + G; r < p.stats_rows; r += G) p.stats[(long long)r * 128 + which * 64 + c] = 0.f;
+    }
+  };
+  if (nitems == 0) {
+    write_stats();
+    return;
+  }
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.src, 0, (int)((long long)p.M * 256), 0x00020000);
+  // ---- loader: item li = (tile slot + (li >> 1) G, channel block li & 1); 4 rows per thread: frames (lrow >> 5) + 2 i
+  unsigned ld_voff = OOB;
+  auto ld_tile = [&](int li) {                              // this thread's row offset in the loader's tile
+    const int tile = slot + (li >> 1) * G;
+    const unsigned pg = (unsigned)(tile * TC_P + (lrow & 31));
+    const unsigned b = magic_div(pg, p.mgW, p.shW);         // position -> clip (division by HW)
+    const unsigned hw = pg - b * HW;
+    ld_voff = pg < (unsigned)NP ? (unsigned)(((b * TC_T + (lrow >> 5)) * HW + hw) * 256 + lcol * 4) : OOB;
+  };
+  floatx4 va[4];
+  auto issue_loads = [&](int li) {
+    const int c128 = (li & 1) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      va[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                              rsA, ld_voff, __builtin_amdgcn_readfirstlane(c128 + 2 * i * frame_bytes), 0));
+  };
+  auto store_stage = [&](float* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<floatx4*>(&st[(lrow + 64 * i) * LDK + lcol]) = va[i];
+  };
+
+  // ---- prologue: the weights -> LDS (72 KB, once), item 0 -> stage 0, item 1 -> registers
+  {
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wsp), 0, TC_B_BYTES, 0x00020000);
+    pk_uintx4 wv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      wv[i] = __builtin_bit_cast(pk_uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (tid + 512 * i) * 16, 0, 0));
+    ld_tile(0);
+    issue_loads(0);
+    for (int i = tid; i < TC_P * LDK; i += 512) As[2 * TC_STAGE + i] = 0.f;       // the padding frame
+#pragma unroll
+    for (int i = 0; i < 9; ++i) *reinterpret_cast<pk_uintx4*>(Bs + (tid + 512 * i) * 16) = wv[i];
+    store_stage(As);
+    if (nitems > 1) issue_loads(1);
+  }
+  __syncthreads();
+
+  floatx16 acc[2];
+  const int row_bytes = 256;                                // Cd = 64
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst, 0, (int)((long long)p.M * row_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.addend ? p.addend : p.dst), 0, (int)((long long)p.M * row_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsXb = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.bnb_x ? p.bnb_x : p.dst), 0, (int)((long long)p.M * row_bytes), 0x00020000);
+  constexpr bool HAS_ADD = (EPI & 1) != 0, BNB = (EPI & 8) != 0;
+  float bsc[2] = {0.f, 0.f}, bsh[2] = {0.f, 0.f}, bmu[2] = {0.f, 0.f}, bis[2] = {0.f, 0.f};
+  if (BNB) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = j * 32 + l31;
+      bsc[j] = p.bnb_scale[col]; bsh[j] = p.bnb_shift[col]; bmu[j] = p.bnb_mean[col]; bis[j] = p.bnb_invstd[col];
+    }
+  }
+
+  // products of one staged block: six steps s = (tap d = s >> 1, k-step st = s & 1) of 12 matrix instructions each,
+  // software-pipelined inside the wave: the fragments of step s + 2 are requested from LDS and the input rows of step s + 1
+  // are split while step s is multiplied.  Source frame of tap d: wave + d - 1 (forward) / wave + 1 - d (input gradient);
+  // a frame outside the clip reads the ZERO block (the padding in time), so every wave runs the same straight-line steps —
+  // the barrier at the end of the block waits for the slowest SIMD anyway.
+  const float* Alane = As + l31 * LDK + h * 8;              // this lane's fragment position inside a frame of a stage
+  auto products = [&](int stage_off, int cb) {
+    int aoff[3];                                            // frame of tap d, as a scalar offset from As (floats)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int f = MODE == 0 ? wave + d - 1 : wave + 1 - d;
+      aoff[d] = __builtin_amdgcn_readfirstlane((f < 0 || f >= TC_T) ? 2 * TC_STAGE : stage_off + f * TC_P * LDK);
+    }
+    const float* Af[3] = {Alane + aoff[0], Alane + aoff[1], Alane + aoff[2]};
+    const char* Bc = Bs + cb * PK_BCH + lane * 16;
+    floatx4 ar[2][2];
+    pk_bf16x8 bf[2][6], sp[2][3];
+    auto request = [&](int s_, int buf) {
+      const int d = s_ >> 1, st = s_ & 1;
+      ar[buf][0] = *reinterpret_cast<const floatx4*>(Af[d] + st * 16);
+      ar[buf][1] = *reinterpret_cast<const floatx4*>(Af[d] + st * 16 + 4);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          bf[buf][j * 3 + t] = *reinterpret_cast<const pk_bf16x8*>(Bc + d * 2 * PK_BCH + ((j * 2 + st) * 3 + t) * 1024);
+    };
+    request(0, 0);
+    request(1, 1);
+    pk_split8(ar[0][0], ar[0][1], sp[0][0], sp[0][1], sp[0][2]);
+#pragma unroll
+    for (int s_ = 0; s_ < 6; ++s_) {
+      const int b = s_ & 1;
+      const pk_bf16x8 ah = sp[b][0], am = sp[b][1], al = sp[b][2];
+      pk_bf16x8 bq[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) bq[q] = bf[b][q];
+      if (s_ + 1 < 6) pk_split8(ar[b ^ 1][0], ar[b ^ 1][1], sp[b ^ 1][0], sp[b ^ 1][1], sp[b ^ 1][2]);
+      if (s_ + 2 < 6) request(s_ + 2, b);
+      // (the two accumulators alternate: no matrix instruction waits for the one issued just before it)
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[2], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[5], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bq[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bq[3], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bq[1], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bq[4], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[1], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[4], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bq[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bq[3], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[3], acc[1], 0, 0, 0);
+    }
+  };
+
+  for (int it = 0; it < nitems; ++it) {
+    const int cb = it & 1;
+    const int cur = (it & 1) * TC_STAGE;
+    float* nxt = As + ((it + 1) & 1) * TC_STAGE;
+    if (cb == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    }
+    // the registers hold item it + 1: into the other stage (every wave left it at the last barrier), then item it + 2's loads
+    if (it + 1 < nitems) store_stage(nxt);
+    if (it + 2 < nitems) {
+      if (cb == 0) ld_tile(it + 2);
+      issue_loads(it + 2);
+    }
+    products(cur, cb);
+    if (cb == 1) {
+      // ---- epilogue of the tile: wave = frame, accumulator register r of lane (l31, h) = position (r & 3) + 8 (r >> 2) + 4 h,
+      // column j * 32 + l31.  Destination row of (position pg, frame w): pg + (7 b + w) HW, b = pg / HW — a tile crosses at
+      // most one clip boundary.
+      const int tile = slot + (it >> 1) * G;
+      const unsigned p0 = (unsigned)(tile * TC_P);
+      const unsigned b0 = magic_div(p0, p.mgW, p.shW);
+      const unsigned pb = (b0 + 1) * HW;                    // first position of the next clip
+      const unsigned base = (p0 + (7 * b0 + wave) * HW) * 256u + l31 * 4 + h * 4 * 256;
+      const unsigned step_b = 7u * HW * 256u;
+      unsigned voff[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned pr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const unsigned pg = p0 + pr;
+        const unsigned o = base + ((r & 3) + 8 * (r >> 2)) * 256u + (pg >= pb ? step_b : 0u);
+        voff[r] = pg < (unsigned)NP ? o : OOB;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float ad[16], xb[16];
+        if (HAS_ADD) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, voff[r], j * 128, 0));
+        }
+        if (BNB) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            xb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsXb, voff[r], j * 128, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[j][r];
+          if (HAS_ADD) v += ad[r];
+          if (MODE == 0) { cs[j][r & 1] += v; cq[j][r & 1] = fmaf(v, v, cq[j][r & 1]); }   // rows past the end are exact zeros
+          if (BNB) {
+            const float dm = (!p.bnb_relu || fmaf(xb[r], bsc[j], bsh[j]) > 0.f) ? v : 0.f;
+            cs[j][r & 1] += dm;
+            cq[j][r & 1] = fmaf(dm, (xb[r] - bmu[j]) * bis[j], cq[j][r & 1]);
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff[r], j * 128, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  write_stats();
 }
 
 // dst = sum_s part[s] (+ bias)(+ addend)(relu) — fixed summation order
@@ -2346,6 +2601,59 @@ static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
 }
 
 
+// ---- tconv64_kernel: which launches take it, and the launch
+static int g_tconv_mode = -1;     // -1: AVID_TCONV from the environment (default 1); 0 off; 1 layers with >= 3 rounds of tiles; 2 whenever it can
+static int tconv_mode() {
+  if (g_tconv_mode < 0) {
+    const char* e = getenv("AVID_TCONV");
+    g_tconv_mode = e ? atoi(e) : 1;
+    if (g_tconv_mode < 0 || g_tconv_mode > 2) g_tconv_mode = 1;
+  }
+  return g_tconv_mode;
+}
+static int tconv_grid(const ConvArgs& a) {
+  const long long ntiles = ((long long)a.B * a.Hs * a.Ws + TC_P - 1) / TC_P;
+  return (int)(ntiles < device_cus() ? ntiles : device_cus());
+}
+static bool tconv_takes(const ConvArgs& a, int mode) {
+  if (!PK_SPLIT || !tconv_mode() || !a.wsp) return false;
+  if (a.kt != 3 || a.kh != 1 || a.kw != 1 || a.st != 1 || a.sh != 1 || a.sw != 1 || a.pt != 1 || a.ph != 0 || a.pw != 0) return false;
+  if (a.Cs != 64 || a.Cd != 64 || a.Ts != TC_T || a.Td != TC_T || a.Hs != a.Hd || a.Ws != a.Wd) return false;
+  if (a.bias || a.relu || a.epi_op || a.add_s[0] * a.add_s[1] * a.add_s[2] != 1) return false;
+  if (mode == 0 && a.bnb_x) return false;
+  if ((long long)a.M * 256 >= (1ll << 31) || a.wsp_nrec < TC_B_BYTES) return false;
+  const long long ntiles = ((long long)a.B * a.Hs * a.Ws + TC_P - 1) / TC_P;
+  return tconv_mode() == 2 || ntiles >= 3ll * device_cus();
+}
+
+template <int MODE, int EPI>
+static void launch_tconv_e(const ConvArgs& a, int grid, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = tconv64_kernel<MODE, EPI>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TC_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), TC_LDS, s, a);
+}
+
+template <int MODE>
+static int launch_tconv(ConvArgs& a, hipStream_t s) {
+  magic_for(a.Hs * a.Ws, a.mgW, a.shW);       // position -> clip
+  const int grid = tconv_grid(a);
+  const double K = 3.0 * 64;
+  ScopedTimer t(s, MODE == 0 ? "tconv64_kernel<0>" : "tconv64_kernel<1>", 2.0 * a.M * 64 * K,
+                4.0 * ((double)a.M * 64 + 64 * K + (double)a.M * 64 * (1 + (a.addend ? 1 : 0) + (a.bnb_x ? 1 : 0))));
+  const int epi = (a.addend ? 1 : 0) | ((MODE == 1 && a.bnb_x) ? 8 : 0);
+  switch (epi) {
+    case 0: launch_tconv_e<MODE, 0>(a, grid, s); break;
+    case 1: launch_tconv_e<MODE, 1>(a, grid, s); break;
+    case 8: launch_tconv_e<MODE, MODE == 1 ? 8 : 0>(a, grid, s); break;
+    default: launch_tconv_e<MODE, MODE == 1 ? 9 : 1>(a, grid, s); break;
+  }
+  return check_launch("tconv64");
+}
+
 // Parity-class table of a strided dgrad (strides are 1 or 2 per axis).
 static void build_classes(ConvArgs& a, int BM) {
   const int S[3] = {a.st, a.sh, a.sw}, P[3] = {a.pt, a.ph, a.pw}, Kd[3] = {a.kt, a.kh, a.kw}, D[3] = {a.Td, a.Hd, a.Wd};
@@ -2566,6 +2874,15 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
   // Everything dense goes to the persistent kernel (whole rounds + K-split tail in one launch).
   {
     PkPlan pk = plan_pk(a.M, a.Cd, nk_total, MODE);
+    if (tconv_takes(a, MODE)) {   // conv2x's temporal layers: taps staged once, weights resident in LDS
+      const int rows = pk.grid + (pk.f > 1 ? (int)ceil_div(a.M - pk.tail_row0, stats_rpb(a.M - pk.tail_row0, a.Cd)) : 0);
+      if (!(a.stats && (MODE == 0 || a.bnb_x)) || rows >= tconv_grid(a)) {
+        ConvArgs k = a;
+        k.stats = (MODE == 0 || a.bnb_x) ? a.stats : nullptr;
+        k.stats_rows = rows;       // (the rows avid_conv_fwd_stats_rows / avid_conv_dgrad_bn_rows promised: the kernel zero-fills beyond its own)
+        return launch_tconv<MODE>(k, s);
+      }
+    }
     if (pk.f > 1 && (ws == nullptr || ws_bytes < sizeof(float) * pk.ws_floats)) {   // no scratch: unsplit
       AVID_REQUIRE(!a.stats, AVID_E_BADARG, "conv: BatchNorm partials need the planned workspace");
       pk.tail_units /= pk.f;
@@ -2701,6 +3018,7 @@ static void fill_common(ConvArgs& a, const avid_conv_desc* d) {
   a.add_n[0] = a.add_n[1] = a.add_n[2] = 0;
   a.wsp = nullptr;
   a.wsp_nrec = a.wsp_kstep = 0;
+  a.stats_rows = 0;
 }
 
 // C[M][N] = A[M][K] . Bq[N][K]^T, optionally combined with Cin by min / max — the similarity GEMMs of
@@ -2728,6 +3046,7 @@ int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin,
   a.add_n[0] = a.add_n[1] = a.add_n[2] = 0;
   a.wsp = nullptr;
   a.wsp_nrec = a.wsp_kstep = 0;
+  a.stats_rows = 0;
   // persistent kernel, no K-split (K = 128: 4 k-tiles per tile, thousands of tiles): 54 -> ~90 TFLOP/s
   return dispatch_igemm<0>(a, nullptr, 0, s);
 }
@@ -2755,6 +3074,11 @@ static bool conv_takes_split(const avid_conv_desc* d, int which) {
 }
 
 extern "C" long long avid_debug_presplit_launches(void) { return g_presplit_launches; }
+
+extern "C" int avid_tconv_configure(int mode) {
+  g_tconv_mode = (mode >= 0 && mode <= 2) ? mode : -1;
+  return tconv_mode();
+}
 
 extern "C" int avid_conv_uses_split(const avid_conv_desc* d, int which) {
   if (!d || validate(d) || which < 0 || which > 1) return 0;
@@ -3368,6 +3692,16 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
     static const char* kPk[] = {"2,2,2,2", "4,1,1,2", "4,2,2,2", "4,2,2,1", "2,1,2,2"};
     snprintf(buf, len, "igemm_pk_kernel<%s,%d> full=%d tail_units=%d f=%d", kPk[pk.tile], mode, pk.full, pk.tail_units, pk.f);
   };
+  // conv2x's temporal layers (given their pre-split weights): tconv64_kernel — the descriptor-level form of tconv_takes
+  const long long tc_tiles = ((long long)d->B * d->Hi * d->Wi + TC_P - 1) / TC_P;
+  const bool tc = PK_SPLIT && tconv_mode() && vec && which < 2 && d->kt == 3 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 &&
+                  d->sw == 1 && d->pt == 1 && d->ph == 0 && d->pw == 0 && d->Cin == 64 && d->Cout == 64 && d->Ti == TC_T &&
+                  d->To == TC_T && (long long)d->B * d->Ti * d->Hi * d->Wi * 256 < (1ll << 31) &&
+                  (tconv_mode() == 2 || tc_tiles >= 3ll * device_cus());
+  if (tc) {
+    snprintf(buf, len, "tconv64_kernel<%d> grid=%d", which, (int)(tc_tiles < device_cus() ? tc_tiles : device_cus()));
+    return AVID_OK;
+  }
   if (which == 0) {
     const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
     if (!vec) {

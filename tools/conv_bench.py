@@ -89,10 +89,14 @@ for name, cin, cout, k, st, pd, (T, H, W) in L:
                 t += v["ms"]; names.append(n)
         return t / reps * 1e3, [n for n in names if n.startswith(("wino_kernel", "wino2_kernel", "winot_kernel"))]
     f_us, fn = pick(res["fwd"], "igemm_", 0)
+    tf_us, tfn = pick(res["fwd"], "tconv64_kernel<0>")
+    f_us += tf_us; fn += tfn
     wf_us, wfn = pick_w(res["fwd"], 0)
     f_us += wf_us; fn += wfn
     fr_us, _ = pick(res["fwd"], "splitk")
     d_us, dn = pick(res["bwd"], "igemm_", 1)
+    td_us, tdn = pick(res["bwd"], "tconv64_kernel<1>")
+    d_us += td_us; dn += tdn
     wd_us, wdn = pick_w(res["bwd"], 1)
     d_us += wd_us; dn += wdn
     dr_us, _ = pick(res["bwd"], "splitk"); dt_us, _ = pick(res["bwd"], "weight_tr")

@@ -20,6 +20,8 @@ def short_name(name):
         strided = False
         if short == "igemm_pk_kernel" and len(args) >= 7:          # <WM,WN,TM,TN,MODE,STRIDED,EPI>
             strided, args = args[5] == "true", args[:5]
+        elif short == "tconv64_kernel" and len(args) >= 2:                # <MODE,EPI>: the timers pool the epilogue variants
+            args = args[:1]
         elif short.startswith(("igemm", "stem")) and args[-1] in ("true", "false"):   # trailing bool = STRIDED
             strided, args = args[-1] == "true", args[:-1]
         elif short in ("xmodal_fused_kernel", "xmodal_finish_kernel") and args[-1] in ("true", "false"):   # <CMA>: the timers' names
