@@ -1145,9 +1145,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+  const int lcol = (tid & 7) * 4;
   const int G = gridDim.x;
   const int slot = __builtin_amdgcn_readfirstlane((int)xcd_remap(blockIdx.x, G));
+  PK_STAMP(0);
   const int HW = p.Hs * p.Ws;
   const int NP = p.B * HW;                                  // positions
   const int ntiles = (NP + TC_P - 1) / TC_P;
@@ -1188,40 +1189,53 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.src, 0, (int)((long long)p.M * 256), 0x00020000);
-  // ---- loader: item li = (tile slot + (li >> 1) G, channel block li & 1); 4 rows per thread: frames (lrow >> 5) + 2 i
+  // ---- roles.  What the time stamps say (tools/tconv_trace.py, -DAVID_PK_TRACE): a SIMD executes its two waves' instructions
+  // as ONE serial stream — the older wave (0-3) runs its 72 products + 216 split instructions in 1.75 us, the younger one
+  // (4-7) gets the pipe when the older has finished (another 1.45-1.75 us); nothing of one wave hides under the matrix
+  // instructions of the other, and a tile's time is the SUM of everything both waves issue (288 matrix instructions at
+  // 17 ns = 4.9 us + ~860 split instructions at 2.7 ns + the rest = 7.5 us).  So the arrangement only decides who idles at
+  // the barriers: the younger waves do everything that is not a product while the older multiply — they alone stage (global
+  // -> registers -> LDS, all 256 rows) and they write their tile's output one item late, at the start of the next tile; the
+  // older waves go straight into their products and write their output right after a tile's last product, while the
+  // younger ones still multiply.  (60.5 -> 59.2 us; what would move it is fewer instructions: the split once per input
+  // row instead of once per tap — needs the rows in LDS as bf16 planes, 6 B per element: 16-channel stages — DESIGN.md 8g.)
+  const bool lead = wave < 4;
+  const int trow = (tid & 255) >> 3;                        // trailing waves: position of this thread's staged rows (frames 0..7)
+  // ---- loader (trailing waves): item li = (tile slot + (li >> 1) G, channel block li & 1); 8 rows per thread, one per frame
   unsigned ld_voff = OOB;
   auto ld_tile = [&](int li) {                              // this thread's row offset in the loader's tile
     const int tile = slot + (li >> 1) * G;
-    const unsigned pg = (unsigned)(tile * TC_P + (lrow & 31));
+    const unsigned pg = (unsigned)(tile * TC_P + trow);
     const unsigned b = magic_div(pg, p.mgW, p.shW);         // position -> clip (division by HW)
     const unsigned hw = pg - b * HW;
-    ld_voff = pg < (unsigned)NP ? (unsigned)(((b * TC_T + (lrow >> 5)) * HW + hw) * 256 + lcol * 4) : OOB;
+    ld_voff = pg < (unsigned)NP ? (unsigned)((b * TC_T * HW + hw) * 256 + lcol * 4) : OOB;
   };
-  floatx4 va[4];
+  floatx4 va[8];
   auto issue_loads = [&](int li) {
     const int c128 = (li & 1) * 128;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
       va[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
-                                              rsA, ld_voff, __builtin_amdgcn_readfirstlane(c128 + 2 * i * frame_bytes), 0));
+                                              rsA, ld_voff, __builtin_amdgcn_readfirstlane(c128 + i * frame_bytes), 0));
   };
   auto store_stage = [&](float* st) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<floatx4*>(&st[(lrow + 64 * i) * LDK + lcol]) = va[i];
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<floatx4*>(&st[(trow + 32 * i) * LDK + lcol]) = va[i];
   };
 
-  // ---- prologue: the weights -> LDS (72 KB, once), item 0 -> stage 0, item 1 -> registers
-  {
+  // ---- prologue: the weights -> LDS (72 KB, once; the older waves), item 0 -> stage 0, item 1 -> registers (the younger)
+  if (lead) {
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wsp), 0, TC_B_BYTES, 0x00020000);
-    pk_uintx4 wv[9];
+    pk_uintx4 wv[18];
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
-      wv[i] = __builtin_bit_cast(pk_uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (tid + 512 * i) * 16, 0, 0));
+    for (int i = 0; i < 18; ++i)
+      wv[i] = __builtin_bit_cast(pk_uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (tid + 256 * i) * 16, 0, 0));
+    for (int i = tid; i < TC_P * LDK; i += 256) As[2 * TC_STAGE + i] = 0.f;       // the padding frame
+#pragma unroll
+    for (int i = 0; i < 18; ++i) *reinterpret_cast<pk_uintx4*>(Bs + (tid + 256 * i) * 16) = wv[i];
+  } else {
     ld_tile(0);
     issue_loads(0);
-    for (int i = tid; i < TC_P * LDK; i += 512) As[2 * TC_STAGE + i] = 0.f;       // the padding frame
-#pragma unroll
-    for (int i = 0; i < 9; ++i) *reinterpret_cast<pk_uintx4*>(Bs + (tid + 512 * i) * 16) = wv[i];
     store_stage(As);
     if (nitems > 1) issue_loads(1);
   }
@@ -1250,7 +1264,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // a frame outside the clip reads the ZERO block (the padding in time), so every wave runs the same straight-line steps —
   // the barrier at the end of the block waits for the slowest SIMD anyway.
   const float* Alane = As + l31 * LDK + h * 8;              // this lane's fragment position inside a frame of a stage
-  auto products = [&](int stage_off, int cb) {
+  // products of one staged block: six steps s = (tap d = s >> 1, k-step st = s & 1) of 12 matrix instructions each,
+  // software-pipelined inside the wave: the fragments of step s + 2 are requested from LDS and the input rows of step s + 1
+  // are split while step s is multiplied.  Source frame of tap d: wave + d - 1 (forward) / wave + 1 - d (input gradient);
+  // a frame outside the clip reads the ZERO block (the padding in time), so every wave runs the same straight-line steps —
+  // the barrier at the end of the block waits for the slowest SIMD anyway.
+  auto products = [&](int stage_off, auto CB) {
+    constexpr int cb = decltype(CB)::value;
     int aoff[3];                                            // frame of tap d, as a scalar offset from As (floats)
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -1259,8 +1279,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const float* Af[3] = {Alane + aoff[0], Alane + aoff[1], Alane + aoff[2]};
     const char* Bc = Bs + cb * PK_BCH + lane * 16;
-    floatx4 ar[2][2];
-    pk_bf16x8 bf[2][6], sp[2][3];
+    floatx4 ar[3][2];
+    pk_bf16x8 bf[3][6], sp[2][3];
     auto request = [&](int s_, int buf) {
       const int d = s_ >> 1, st = s_ & 1;
       ar[buf][0] = *reinterpret_cast<const floatx4*>(Af[d] + st * 16);
@@ -1274,95 +1294,138 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     request(0, 0);
     request(1, 1);
     pk_split8(ar[0][0], ar[0][1], sp[0][0], sp[0][1], sp[0][2]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s_ = 0; s_ < 6; ++s_) {
-      const int b = s_ & 1;
-      const pk_bf16x8 ah = sp[b][0], am = sp[b][1], al = sp[b][2];
-      pk_bf16x8 bq[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) bq[q] = bf[b][q];
-      if (s_ + 1 < 6) pk_split8(ar[b ^ 1][0], ar[b ^ 1][1], sp[b ^ 1][0], sp[b ^ 1][1], sp[b ^ 1][2]);
-      if (s_ + 2 < 6) request(s_ + 2, b);
+      const int b = s_ % 3, q2 = s_ & 1;
+      if (s_ + 2 < 6) request(s_ + 2, (s_ + 2) % 3);      // lands under this step's and the next step's products
+      if (s_ + 1 < 6) pk_split8(ar[(s_ + 1) % 3][0], ar[(s_ + 1) % 3][1], sp[q2 ^ 1][0], sp[q2 ^ 1][1], sp[q2 ^ 1][2]);
+      const pk_bf16x8 ah = sp[q2][0], am = sp[q2][1], al = sp[q2][2];
       // (the two accumulators alternate: no matrix instruction waits for the one issued just before it)
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[2], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[5], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bq[0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bq[3], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bq[1], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bq[4], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[1], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[4], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bq[0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bq[3], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[3], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[b][2], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[b][5], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bf[b][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bf[b][3], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf[b][1], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf[b][4], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[b][1], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[b][4], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf[b][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf[b][3], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[b][0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[b][3], acc[1], 0, 0, 0);
+      // issue order of the step: the LDS requests first, then the next step's split spread under the matrix instructions
+      if (s_ + 2 < 6) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (s_ + 1 < 6) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  for (int it = 0; it < nitems; ++it) {
-    const int cb = it & 1;
-    const int cur = (it & 1) * TC_STAGE;
-    float* nxt = As + ((it + 1) & 1) * TC_STAGE;
-    if (cb == 0) {
+  // Epilogue of a tile: wave = frame, accumulator register r of lane (l31, h) = position (r & 3) + 8 (r >> 2) + 4 h, column
+  // j * 32 + l31.  Destination row of (position pg, frame w): pg + (7 b + w) HW, b = pg / HW.  A tile that lies inside one
+  // clip and inside the tensor (all but one in ~25) has ONE vector offset per lane, the 32 row / column steps ride in the
+  // scalar offset: no address arithmetic per element (it was 9 vector instructions per row, all waves of the CU at once,
+  // nothing for the matrix pipe to do meanwhile: 1.05 of a tile's 8.3 us).  SPLIT: the general form — a clip boundary or the
+  // end of the tensor inside the tile.
+  auto emit = [&](int tile, const floatx16 (&res)[2], auto SPLIT) {
+    const unsigned p0 = (unsigned)(tile * TC_P);
+    const unsigned b0 = magic_div(p0, p.mgW, p.shW);
+    const unsigned pb = (b0 + 1) * HW;                      // first position of the next clip
+    const unsigned base = (p0 + (7 * b0 + wave) * HW) * 256u + l31 * 4 + h * 4 * 256;
+    const unsigned step_b = 7u * HW * 256u;
+    unsigned voff[16];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      voff[r] = base;
+      if (decltype(SPLIT)::value) {
+        const unsigned pg = p0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        voff[r] = pg < (unsigned)NP ? base + (pg >= pb ? step_b : 0u) : OOB;
+      }
     }
-    // the registers hold item it + 1: into the other stage (every wave left it at the last barrier), then item it + 2's loads
-    if (it + 1 < nitems) store_stage(nxt);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float ad[16], xb[16];
+      if (HAS_ADD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, voff[r], ((r & 3) + 8 * (r >> 2)) * 256 + j * 128, 0));
+      }
+      if (BNB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          xb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsXb, voff[r], ((r & 3) + 8 * (r >> 2)) * 256 + j * 128, 0));
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = res[j][r];
+        if (HAS_ADD) v += ad[r];
+        if (MODE == 0) { cs[j][r & 1] += v; cq[j][r & 1] = fmaf(v, v, cq[j][r & 1]); }   // rows past the end are exact zeros
+        if (BNB) {
+          const float dm = (!p.bnb_relu || fmaf(xb[r], bsc[j], bsh[j]) > 0.f) ? v : 0.f;
+          cs[j][r & 1] += dm;
+          cq[j][r & 1] = fmaf(dm, (xb[r] - bmu[j]) * bis[j], cq[j][r & 1]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff[r], ((r & 3) + 8 * (r >> 2)) * 256 + j * 128, 0);
+      }
+    }
+  };
+  auto epilogue = [&](int tile, const floatx16 (&res)[2]) {
+    const unsigned p0 = (unsigned)(tile * TC_P);
+    const unsigned pb = (magic_div(p0, p.mgW, p.shW) + 1) * HW;
+    if (p0 + TC_P <= pb && p0 + TC_P <= (unsigned)NP) emit(tile, res, std::false_type{});
+    else emit(tile, res, std::true_type{});
+  };
+  // one item (trailing waves): the registers hold item it + 1 -> the other stage (every wave left it at the last barrier),
+  // item it + 2's loads go out; then, all waves, the products of item it from its stage; one barrier per item
+  auto stage_next = [&](int it, int cb) {
+    if (it + 1 < nitems) store_stage(As + (cb ^ 1) * TC_STAGE);
     if (it + 2 < nitems) {
       if (cb == 0) ld_tile(it + 2);
       issue_loads(it + 2);
     }
-    products(cur, cb);
-    if (cb == 1) {
-      // ---- epilogue of the tile: wave = frame, accumulator register r of lane (l31, h) = position (r & 3) + 8 (r >> 2) + 4 h,
-      // column j * 32 + l31.  Destination row of (position pg, frame w): pg + (7 b + w) HW, b = pg / HW — a tile crosses at
-      // most one clip boundary.
-      const int tile = slot + (it >> 1) * G;
-      const unsigned p0 = (unsigned)(tile * TC_P);
-      const unsigned b0 = magic_div(p0, p.mgW, p.shW);
-      const unsigned pb = (b0 + 1) * HW;                    // first position of the next clip
-      const unsigned base = (p0 + (7 * b0 + wave) * HW) * 256u + l31 * 4 + h * 4 * 256;
-      const unsigned step_b = 7u * HW * 256u;
-      unsigned voff[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned pr = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const unsigned pg = p0 + pr;
-        const unsigned o = base + ((r & 3) + 8 * (r >> 2)) * 256u + (pg >= pb ? step_b : 0u);
-        voff[r] = pg < (unsigned)NP ? o : OOB;
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float ad[16], xb[16];
-        if (HAS_ADD) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            ad[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, voff[r], j * 128, 0));
-        }
-        if (BNB) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            xb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsXb, voff[r], j * 128, 0));
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[j][r];
-          if (HAS_ADD) v += ad[r];
-          if (MODE == 0) { cs[j][r & 1] += v; cq[j][r & 1] = fmaf(v, v, cq[j][r & 1]); }   // rows past the end are exact zeros
-          if (BNB) {
-            const float dm = (!p.bnb_relu || fmaf(xb[r], bsc[j], bsh[j]) > 0.f) ? v : 0.f;
-            cs[j][r & 1] += dm;
-            cq[j][r & 1] = fmaf(dm, (xb[r] - bmu[j]) * bis[j], cq[j][r & 1]);
-          }
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, voff[r], j * 128, 0);
-        }
-      }
+  };
+  floatx16 out[2];                                          // trailing waves: the finished tile, written one item late
+  PK_STAMP(1);
+  for (int t = 0; t < nmine; ++t) {
+    PK_STAMP(2 + 7 * t);
+    if (!lead) {
+      stage_next(2 * t, 0);
+      if (t > 0) epilogue(slot + (t - 1) * G, out);
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    PK_STAMP(3 + 7 * t);
+#ifdef AVID_PK_TRACE   // tile 3: every wave's start and end of its products, in the rows of the (unused) workgroups 512...
+    if (t == 3 && lane == 0) g_pk_trace[(512 + blockIdx.x) * 64 + wave] = wall_clock64();
+#endif
+    products(0, std::integral_constant<int, 0>{});
+#ifdef AVID_PK_TRACE
+    if (t == 3 && lane == 0) g_pk_trace[(512 + blockIdx.x) * 64 + 8 + wave] = wall_clock64();
+#endif
+    PK_STAMP(4 + 7 * t);
     __syncthreads();
+    PK_STAMP(5 + 7 * t);
+    if (!lead) stage_next(2 * t + 1, 1);
+    products(TC_STAGE, std::integral_constant<int, 1>{});
+    PK_STAMP(6 + 7 * t);
+    if (lead) {
+      epilogue(slot + t * G, acc);
+    } else {
+      out[0] = acc[0];
+      out[1] = acc[1];
+    }
+    PK_STAMP(7 + 7 * t);
+    __syncthreads();
+    PK_STAMP(8 + 7 * t);
   }
+  if (!lead) epilogue(slot + (nmine - 1) * G, out);
+  PK_STAMP(31);
   write_stats();
 }
 
