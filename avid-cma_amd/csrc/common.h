@@ -106,11 +106,48 @@ constexpr bool W2_SPLIT = true;
 #endif
 
 // (x0, x1) -> three packed bf16 pairs h, m, l (element 0 in the low half) with x = h + m + l to fp32 accuracy: h = bf16(x),
-// m = bf16(x - h), l = bf16(x - h - m), round to nearest even.  Plain vector code on purpose — v_cvt_pk_bf16_f32, v_lshl /
-// v_and, v_add: as inline assembly the same instructions came out with a wait state behind every packed subtraction
-// and could not be moved by the scheduler (wino2_kernel: 160 -> 146 us on conv2x).
+// m = bf16(x - h), l = bf16(x - h - m), round to nearest even.
+//
+// Round 5: the residuals come from v_dot2c_f32_bf16 — r0 = x0 + (h0, h1) . (-1, 0), r1 = x1 + (h0, h1) . (0, -1): exact (a
+// bf16 times -1 or 0 and one fp32 subtraction whose result is representable), two instructions per pair where expanding h
+// to fp32 and subtracting took three (and / shift / packed subtract): SEVEN vector instructions per pair instead of nine.
+// (In every split-bf16 kernel the splits are as many instructions as everything else: profiles/r04_b counts 5.6-13 vector
+// instructions per matrix instruction, and a SIMD runs its waves largely as one serial stream — tools/tconv_trace.py,
+// DESIGN.md 8g.)  Bit-identical to the classic form for every finite input, denormals included
+// (tools/split_dot_check.hip: 2^25 random pairs); a non-finite element (or |x| > 3.39e38: h rounds to inf) now also turns
+// its PAIR-MATE's lower terms into NaN (0 x inf) — the neighbouring k index of the same fragment row, i.e. of the same
+// dot products, which the non-finite element has already made NaN (tests/test_gpu_precision.py).
+// Two traps, both found by that lab: the pair (-1, 0) = 0x0000bf80 has to come from a REGISTER — as a constant the compiler
+// and the assembler encode it as the inline constant -1.0, which the hardware reads as 0xbf800000 = (0, -1); and the
+// builtin, not inline assembly — a dot instruction reading a register the previous instruction wrote needs a wait state
+// that only the compiler's hazard recogniser inserts.  -DAVID_SPLIT_CLASSIC (every source file) builds the round-4 forms.
 typedef float floatx2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_bf16_dot(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  unsigned k10 = 0x0000bf80u;
+  asm volatile("" : "+s"(k10));
+  const bf16x2_t m10 = __builtin_bit_cast(bf16x2_t, k10), m01 = {(__bf16)0.0f, (__bf16)-1.0f};
+  const floatx2_t x = {x0, x1};
+  const bf16x2_t hb = __builtin_convertvector(x, bf16x2_t);
+  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(hb, m10, x0, false), r1 = __builtin_amdgcn_fdot2_f32_bf16(hb, m01, x1, false);
+  const floatx2_t r = {r0, r1};
+  const bf16x2_t mb = __builtin_convertvector(r, bf16x2_t);
+  const float t0 = __builtin_amdgcn_fdot2_f32_bf16(mb, m10, r0, false), t1 = __builtin_amdgcn_fdot2_f32_bf16(mb, m01, r1, false);
+  const floatx2_t t = {t0, t1};
+  const bf16x2_t lb = __builtin_convertvector(t, bf16x2_t);
+  h = __builtin_bit_cast(unsigned, hb);
+  m = __builtin_bit_cast(unsigned, mb);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+// Where it pays (same box, alternating library builds, ms per step): igemm_pk_kernel<4,1,1,2,0> 0.594 -> 0.557, <4,1,1,2,1>
+// 0.448 -> 0.42, wgrad_group_kernel 0.76 -> 0.74; where it does not: stem_fwd3_kernel 0.67 -> 0.73, wino2_kernel<1> 0.805 ->
+// 0.83, tconv64_kernel<0> 0.29 -> 0.31 (v_dot2c issues a little slower than a plain vector instruction — 23.3 against 27.1 ns
+// per pair for 7 against 9 instructions — and those kernels' own instruction interleave was tuned around the classic forms).
+// So it is a third form, chosen per kernel; -DAVID_SPLIT_CLASSIC (every source file) maps it back to split2_bf16.
+
+// The classic form.  Plain vector code on purpose — v_cvt_pk_bf16_f32, v_lshl /
+// v_and, v_add: as inline assembly the same instructions came out with a wait state behind every packed subtraction
+// and could not be moved by the scheduler (wino2_kernel: 160 -> 146 us on conv2x).
 __device__ __forceinline__ void split2_bf16(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
   const floatx2_t x = {x0, x1};
   const bf16x2_t hb = __builtin_convertvector(x, bf16x2_t);
@@ -133,6 +170,10 @@ __device__ __forceinline__ void split2_bf16_asm(float x0, float x1, unsigned& h,
   const float t0 = r0 - __uint_as_float(m << 16), t1 = r1 - __uint_as_float(m & 0xffff0000u);
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l) : "v"(t0), "v"(t1));
 }
+
+#ifdef AVID_SPLIT_CLASSIC
+#define split2_bf16_dot split2_bf16
+#endif
 
 // x = h + m + l to fp32 accuracy, each term a bf16 (round to nearest even): the scalar form of the packed splits in
 // conv.hip / stem.hip / wino.hip (same instruction, same roundings)

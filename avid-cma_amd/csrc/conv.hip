@@ -401,11 +401,17 @@ constexpr bool PK_SPLIT = true;
 #endif
 typedef __bf16 pk_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned pk_uintx4 __attribute__((ext_vector_type(4)));
+// DOT: the residuals from v_dot2c_f32_bf16 (common.h split2_bf16_dot: 7 instead of 9 instructions per pair; igemm_pk_kernel's
+// loops gain 6 %, tconv64_kernel's hand-ordered one loses 6 %)
+template <bool DOT = true>
 __device__ __forceinline__ void pk_split8(const floatx4& v0, const floatx4& v1, pk_bf16x8& fh, pk_bf16x8& fm, pk_bf16x8& fl) {
   const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
   unsigned h[4], m[4], l[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) split2_bf16(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+  for (int i = 0; i < 4; ++i) {
+    if (DOT) split2_bf16_dot(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+    else split2_bf16(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+  }
   fh = __builtin_bit_cast(pk_bf16x8, pk_uintx4{h[0], h[1], h[2], h[3]});
   fm = __builtin_bit_cast(pk_bf16x8, pk_uintx4{m[0], m[1], m[2], m[3]});
   fl = __builtin_bit_cast(pk_bf16x8, pk_uintx4{l[0], l[1], l[2], l[3]});
@@ -1293,13 +1299,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     request(0, 0);
     request(1, 1);
-    pk_split8(ar[0][0], ar[0][1], sp[0][0], sp[0][1], sp[0][2]);
+    pk_split8<false>(ar[0][0], ar[0][1], sp[0][0], sp[0][1], sp[0][2]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s_ = 0; s_ < 6; ++s_) {
       const int b = s_ % 3, q2 = s_ & 1;
       if (s_ + 2 < 6) request(s_ + 2, (s_ + 2) % 3);      // lands under this step's and the next step's products
-      if (s_ + 1 < 6) pk_split8(ar[(s_ + 1) % 3][0], ar[(s_ + 1) % 3][1], sp[q2 ^ 1][0], sp[q2 ^ 1][1], sp[q2 ^ 1][2]);
+      if (s_ + 1 < 6) pk_split8<false>(ar[(s_ + 1) % 3][0], ar[(s_ + 1) % 3][1], sp[q2 ^ 1][0], sp[q2 ^ 1][1], sp[q2 ^ 1][2]);
       const pk_bf16x8 ah = sp[q2][0], am = sp[q2][1], al = sp[q2][2];
       // (the two accumulators alternate: no matrix instruction waits for the one issued just before it)
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[b][2], acc[0], 0, 0, 0);
@@ -1828,7 +1834,7 @@ typedef unsigned wg_uintx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& fh, wg_bf16x8& fm, wg_bf16x8& fl) {
   unsigned h[4], m[4], l[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) split2_bf16_asm(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+  for (int i = 0; i < 4; ++i) split2_bf16_dot(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);      // (round 5: wgrad_group_kernel 0.76 -> 0.74 ms)
   fh = __builtin_bit_cast(wg_bf16x8, wg_uintx4{h[0], h[1], h[2], h[3]});
   fm = __builtin_bit_cast(wg_bf16x8, wg_uintx4{m[0], m[1], m[2], m[3]});
   fl = __builtin_bit_cast(wg_bf16x8, wg_uintx4{l[0], l[1], l[2], l[3]});
