@@ -87,6 +87,8 @@ __global__ void alias_draw_kernel(long long n, long long K, const float* __restr
 // wave keeps its 16 independent 512-B row reads in flight.
 // ---------------------------------------------------------------------------------------------
 constexpr int SC_ROWS_PER_BLOCK = 64;
+constexpr int XM_ROWS_DEFAULT = 64;      // xmodal_fused_kernel / cma_fused_kernel: rows per block, non-temporal row loads
+constexpr int XM_NT_DEFAULT = 0;
 
 template <int DPL>  // floats per lane: D = 64 * DPL
 __global__ __launch_bounds__(256) void bank_scores_fwd_kernel(const long long* __restrict__ idx,
@@ -385,9 +387,14 @@ struct XModalArgs {
 // CMA: four score sets per gathered row pair instead of two — inst-v2a / inst-a2v (self row positive, the K negatives) and
 // pos-v2v / pos-a2a (the P positives, each 1 / P of the positive term; the first Kw negatives): the same rows of both
 // banks, two more dot products per row, and both embeddings receive gradient from both banks.
-template <bool CMA>
+// RB rows (of both banks) per block: 64 = 16 per wave in flight (round 4), 128 = 32 per wave — the gather is a chain of two
+// dependent memory round trips (indices, rows) per block whatever its size, and what bounds it on the 2 M-row banks is how
+// many row requests the memory system holds at once (round 5).  NT: the rows with non-temporal loads (read
+// once per step; at 2 M rows nothing of them survives in L2 / MALL until the next step anyway).
+template <bool CMA, int RB, bool NT>
 __global__ __launch_bounds__(256) void xmodal_fused_kernel(const XModalArgs p) {
-  constexpr int D = 128, RPW = SC_ROWS_PER_BLOCK / 4, NU = RPW / 4, NL = CMA ? 4 : 2;
+  constexpr int D = 128, RPW = RB / 4, NU = RPW / 4, NL = CMA ? 4 : 2;
+  constexpr int SC_ROWS_PER_BLOCK = RB;
   __shared__ float sh_g[4][2][D];
   __shared__ double sh_l[4][NL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -445,8 +452,13 @@ __global__ __launch_bounds__(256) void xmodal_fused_kernel(const XModalArgs p) {
     const long long row = __shfl(mine, u * 4 + grp, 64);
     const float* pa = p.bank_a + row * D + sub * 8;
     const float* pv = p.bank_v + row * D + sub * 8;
-    ra[u][0] = *reinterpret_cast<const floatx4*>(pa); ra[u][1] = *reinterpret_cast<const floatx4*>(pa + 4);
-    rv[u][0] = *reinterpret_cast<const floatx4*>(pv); rv[u][1] = *reinterpret_cast<const floatx4*>(pv + 4);
+    if (NT) {
+      ra[u][0] = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(pa)); ra[u][1] = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(pa + 4));
+      rv[u][0] = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(pv)); rv[u][1] = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(pv + 4));
+    } else {
+      ra[u][0] = *reinterpret_cast<const floatx4*>(pa); ra[u][1] = *reinterpret_cast<const floatx4*>(pa + 4);
+      rv[u][0] = *reinterpret_cast<const floatx4*>(pv); rv[u][1] = *reinterpret_cast<const floatx4*>(pv + 4);
+    }
   }
   float gv[8], ga[8];                    // d L_v2a / d v_hat, d L_a2v / d a_hat (x T, unscaled): this group's rows
 #pragma unroll
@@ -816,8 +828,25 @@ extern "C" int avid_cma_negatives(int bs, int K, int P, int64_t N, const int32_t
   return check_launch("cma_negatives");
 }
 
+// rows per block / non-temporal row loads of the fused criterion kernels: AVID_XM_ROWS (64 | 128), AVID_XM_NT (0 | 1)
+static int xm_rows() {
+  static int v = 0;
+  if (!v) {
+    const char* e = getenv("AVID_XM_ROWS");
+    v = e && atoi(e) == 64 ? 64 : (e && atoi(e) == 128 ? 128 : XM_ROWS_DEFAULT);
+  }
+  return v;
+}
+static bool xm_nt() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AVID_XM_NT");
+    v = e ? (atoi(e) != 0) : XM_NT_DEFAULT;
+  }
+  return v != 0;
+}
 static size_t fused_ws_bytes(int bs, int rows, int nl) {
-  const size_t S = (size_t)ceil_div(rows, SC_ROWS_PER_BLOCK);
+  const size_t S = (size_t)ceil_div(rows, 64);      // (sized for the smaller block: either setting fits)
   return (size_t)bs * S * 2 * 128 * 4 + (size_t)bs * S * nl * 8 + (size_t)bs * nl * 8 + ((size_t)bs + 1) * 4 + (size_t)bs * 2 * 4 + 64;
 }
 extern "C" size_t avid_xmodal_fused_workspace_bytes(int bs, int K) { return fused_ws_bytes(bs, K + 1, 2); }
@@ -827,7 +856,8 @@ extern "C" size_t avid_cma_fused_workspace_bytes(int bs, int P, int K) { return 
 template <bool CMA>
 static int fused_launch(XModalArgs& a, int rows, void* ws, hipStream_t s) {
   constexpr int NL = CMA ? 4 : 2;
-  a.S = (int)ceil_div(rows, SC_ROWS_PER_BLOCK);
+  const int rb = xm_rows();
+  a.S = (int)ceil_div(rows, rb);
   char* w = static_cast<char*>(ws);                 // (zero-filled once by the caller: the tickets re-arm themselves)
   a.part_l = reinterpret_cast<double*>(w); w += (size_t)a.bs * a.S * NL * 8;
   a.samp_l = reinterpret_cast<double*>(w); w += (size_t)a.bs * NL * 8;
@@ -837,7 +867,14 @@ static int fused_launch(XModalArgs& a, int rows, void* ws, hipStream_t s) {
   // bytes: the gathered rows of both banks, read once
   ScopedTimer t(s, CMA ? "cma_fused_kernel" : "xmodal_fused_kernel", (CMA ? 2.0 : 1.0) * 2.0 * 2.0 * 2.0 * a.bs * rows * 128,
                 2.0 * 4.0 * a.bs * rows * 128.0);
-  hipLaunchKernelGGL(xmodal_fused_kernel<CMA>, dim3((unsigned)a.S, (unsigned)a.bs), dim3(256), 0, s, a);
+  const dim3 grid((unsigned)a.S, (unsigned)a.bs);
+  if (rb == 128) {
+    if (xm_nt()) hipLaunchKernelGGL((xmodal_fused_kernel<CMA, 128, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((xmodal_fused_kernel<CMA, 128, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (xm_nt()) hipLaunchKernelGGL((xmodal_fused_kernel<CMA, 64, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((xmodal_fused_kernel<CMA, 64, false>), grid, dim3(256), 0, s, a);
+  }
   int rc = check_launch(CMA ? "cma_fused" : "xmodal_fused");
   if (rc) return rc;
   hipLaunchKernelGGL(xmodal_finish_kernel<CMA>, dim3((unsigned)a.bs), dim3(256), 0, s, a);

@@ -1237,13 +1237,15 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
   }
   const int grid = wino_grid(d, mode);
   const double M = (double)d->B * d->Ti * d->Hi * d->Wi;
-  // flops: the multiply-adds the MFMAs of this kernel really execute (16 products of [tiles x Cr] x [Cr x Cn]), not
-  // the direct form's 2.25x larger count; bytes: source + destination (+ addend, + x of the BatchNorm-backward sums)
+  // flops: the multiply-adds of the in-image part of the tiles (M / 4 tiles of 16 products of [Cr] x [Cr x Cn]) — not the
+  // direct form's 2.25x larger count, and not the padding of the 2 x 2 tiles that hang over an odd extent (7 x 7 frames
+  // run 4 x 4 tiles: 31 % more matrix instructions than pixels / 4; round 4 counted those as achieved work);
+  // bytes: source + destination (+ addend, + x of the BatchNorm-backward sums)
   static const char* kNames[16] = {"wino_kernel<0>", "wino_kernel<1>", "wino_kernel<2>", "wino_kernel<3>",
                                    "wino_kernel<4>", "wino_kernel<5>", "wino_kernel<6>", "wino_kernel<7>",
                                    "wino2_kernel<0>", "wino2_kernel<1>", "wino2_kernel<2>", "wino2_kernel<3>",
                                    "wino2_kernel<4>", "wino2_kernel<5>", "wino2_kernel<6>", "wino2_kernel<7>"};
-  ScopedTimer t(s, kNames[(epi & 7) + 8 * a.v2], 2.0 * 16.0 * (double)a.ntiles * a.Cr * a.Cn,
+  ScopedTimer t(s, kNames[(epi & 7) + 8 * a.v2], 2.0 * 16.0 * (M / 4.0) * a.Cr * a.Cn,
                 4.0 * M * (a.Cr + a.Cn * (1 + (addend ? 1 : 0) + ((epi & 4) ? 1 : 0))));
   switch (epi) {
     case 0: wino_launch<0>(a, grid, s); break;
@@ -1322,8 +1324,9 @@ int wino_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* 
   }
   const double M = (double)d->B * d->Ti * d->Hi * d->Wi;
   {
-    // flops: the multiply-adds the MFMAs execute (16 per tile, channel pair); bytes: x + dy + dw once
-    ScopedTimer t(s, "wino_wgrad_kernel", 2.0 * 16.0 * (double)pl.ntiles * d->Cin * d->Cout,
+    // flops: the multiply-adds of the in-image part of the tiles (16 per tile and channel pair, M / 4 tiles: the tiles that
+    // hang over an odd extent are executed, not counted); bytes: x + dy + dw once
+    ScopedTimer t(s, "wino_wgrad_kernel", 2.0 * 16.0 * (M / 4.0) * d->Cin * d->Cout,
                   4.0 * (M * (d->Cin + d->Cout) + 9.0 * d->Cin * d->Cout));
     hipLaunchKernelGGL(wino_wgrad_kernel, dim3((unsigned)(pl.pairs * pl.nsplit)), dim3(512), lds, s, a);
   }

@@ -296,6 +296,9 @@ def forward_roofline(model, video, lib, reps=3):
     mf = {n: v for n, v in k.items() if v["flops"] > 0}
     ms = sum(v["ms"] for v in mf.values()) / reps
     executed = sum(v["flops"] for v in mf.values()) / reps
+    # the same executed flops against the peak of the instruction each kernel ISSUES (SURVEY 8(d)'s denominator): the time the
+    # kernels would need at their own peaks (fp32 MFMA 157.3 TF; split-bf16 products 2516.6 / 6 = 419.4 TF) over the time taken
+    ideal_ms = sum(v["flops"] / reps / (mfma_peak(n) * 1e12) * 1e3 for n, v in mf.items())
     direct = R2P1D_FWD_GFLOP_PER_CLIP * 1e9 * video.shape[0]
     all_ms = sum(v["ms"] for v in k.values()) / reps
     return {"mfma_kernels_ms": round(ms, 3), "all_kernels_ms": round(all_ms, 3),
@@ -304,8 +307,11 @@ def forward_roofline(model, video, lib, reps=3):
             "executed": {"gflop_per_clip": round(executed / video.shape[0] / 1e9, 3),
                          "achieved": round(executed / (ms * 1e-3) / 1e12, 2),
                          "frac": round(executed / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "frac_of_issued_peak": round(ideal_ms / ms, 4),
             "note": "frac of the 157.3 TFLOP/s fp32-MFMA peak over the video tower's forward MFMA kernels (stem, implicit "
-                    "GEMM, Winograd); direct_form prices every layer at 2*M*N*K, executed at the multiply-adds issued"}
+                    "GEMM, Winograd); direct_form prices every layer at 2*M*N*K, executed at the multiply-adds issued "
+                    "(in-image Winograd tiles only); frac_of_issued_peak: the executed flops of every kernel priced at the "
+                    "peak of the matrix instruction it issues (fp32 157.3 TF, split-bf16 419.4 TF fp32-equivalent)"}
 
 
 def launcher_command(gpus, argv, visible, env):

@@ -41,7 +41,7 @@ L = [
  ("g1152", 1152, 128, (1,1,1), (1,1,1), (0,0,0), (4,14,14)),
  ("r2.spt", 64, 64, (1,3,3), (1,1,1), (0,1,1), (8,56,56)),          # real-dataset shapes (224 x 224 input): run with B = 32
  ("r3.spt", 128, 128, (1,3,3), (1,1,1), (0,1,1), (4,28,28)),
- ("big128", 128, 128, (1,3,3), (1,1,1), (0,1,1), (8,28,28)),      # not a layer of the model: wide vs narrow tile at equal M (AVID_PK_ALT=3 / 2)
+ ("big128", 128, 128, (1,3,3), (1,1,1), (0,1,1), (8,28,28)),      # not a layer of the model: wide vs narrow tile at equal M
 ]
 print(f"{'layer':10s} {'M':>8s} {'K':>5s} {'N':>4s} | {'fwd us':>8s} {'TF':>6s} | {'dgrad us':>8s} {'TF':>6s} | {'wgrad us':>8s} {'TF':>6s}  kernels")
 for name, cin, cout, k, st, pd, (T, H, W) in L:
