@@ -434,17 +434,30 @@ __global__ __launch_bounds__(256) void xmodal_fused_kernel(const XModalArgs p) {
   const float KZ = (float)p.K * p.Z[0];
   const float KZw = CMA ? (float)p.Kw * p.Z[0] : 0.f;
   const int PP = CMA ? p.P : 0;
-  const int j0 = split * SC_ROWS_PER_BLOCK, j1 = min(j0 + SC_ROWS_PER_BLOCK, R);
+  // Cross-modal form: the blocks split the K NEGATIVES (rows 1 .. K) and the sample's own row 0 rides as an extra unit in
+  // wave 0 of split 0 — K + 1 = 1025 rows cut into blocks of 64 were 17 blocks per sample, the 17th with one row: 1088 blocks
+  // for the 1024 that are resident at once (108 registers: four waves per SIMD), i.e. a second round for 64 one-row blocks
+  // behind the first one's whole latency chain (round 5).
+  const int j0 = (CMA ? 0 : 1) + split * SC_ROWS_PER_BLOCK, j1 = min(j0 + SC_ROWS_PER_BLOCK, R);
   const int jw = j0 + wave * RPW;
+  const bool extra = !CMA && split == 0 && wave == 0;      // (wave-uniform)
   // row j = 0 is the positive (the sample's own row y), [CMA: rows 1..P the positives pos[b][j - 1],] then the negatives
   long long mine = 0;
-  if (lane < RPW && jw + lane < j1) {
-    const int jj = jw + lane;
+  if ((lane < RPW && jw + lane < j1) || (extra && lane == RPW)) {
+    const int jj = lane == RPW ? 0 : jw + lane;
     mine = jj == 0 ? p.y[b] : (jj <= PP ? p.pos[(long long)b * PP + jj - 1] : p.idx[(long long)b * p.K + jj - 1 - PP]);
     if (mine < 0 || mine >= p.N) {
       if (p.err) atomicOr(p.err, AVID_DEVERR_BANK_INDEX);
       mine = mine < 0 ? 0 : p.N - 1;
     }
+  }
+  floatx4 xa[2] = {}, xv[2] = {};        // the extra unit's rows (row 0 of the sample)
+  if (extra) {
+    const long long row = __shfl(mine, RPW, 64);
+    const float* pa = p.bank_a + row * D + sub * 8;
+    const float* pv = p.bank_v + row * D + sub * 8;
+    xa[0] = *reinterpret_cast<const floatx4*>(pa); xa[1] = *reinterpret_cast<const floatx4*>(pa + 4);
+    xv[0] = *reinterpret_cast<const floatx4*>(pv); xv[1] = *reinterpret_cast<const floatx4*>(pv + 4);
   }
   floatx4 ra[NU][2], rv[NU][2];          // audio-bank rows (scored against the video embedding) and video-bank rows
 #pragma unroll
@@ -465,8 +478,73 @@ __global__ __launch_bounds__(256) void xmodal_fused_kernel(const XModalArgs p) {
   for (int k = 0; k < 8; ++k) gv[k] = ga[k] = 0.f;
   double lv = 0, la = 0, lw = 0, lx = 0;
   const float invP = CMA ? 1.f / (float)p.P : 0.f;
+  if (!CMA) {
+    // Cross-modal form: the exp / log / divide chain of a row runs ONCE — lane `sub` = u of a row group takes unit u's two
+    // scores, so the NU units' chains run side by side in NU lanes of every group instead of one after the other in all 16
+    // (round 5: the chain was 3/4 of the kernel's instructions; the kernel is bound by them, not by the gather — consecutive
+    // rows instead of random ones take the same time, tools/xmodal_bench.py XB_SEQ=1).
+    float ms1 = 0.f, ms2 = 0.f;
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
+    for (int u = 0; u < NU; ++u) {
+      float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d1 = fmaf(ra[u][0][k], ev[k], d1); d1 = fmaf(ra[u][1][k], ev[4 + k], d1);
+        d2 = fmaf(rv[u][0][k], ea[k], d2); d2 = fmaf(rv[u][1][k], ea[4 + k], d2);
+      }
+      const float s1 = group_sum(d1) * p.inv_T, s2 = group_sum(d2) * p.inv_T;
+      if (sub == u) { ms1 = s1; ms2 = s2; }
+    }
+    bool xlane = false;                          // this lane carries the extra unit (row 0): lane sub = NU of group 0
+    if (extra) {
+      float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d1 = fmaf(xa[0][k], ev[k], d1); d1 = fmaf(xa[1][k], ev[4 + k], d1);
+        d2 = fmaf(xv[0][k], ea[k], d2); d2 = fmaf(xv[1][k], ea[4 + k], d2);
+      }
+      const float s1 = group_sum(d1) * p.inv_T, s2 = group_sum(d2) * p.inv_T;
+      xlane = sub == NU && grp == 0;
+      if (xlane) { ms1 = s1; ms2 = s2; }
+    }
+    float g1m = 0.f, g2m = 0.f;
+    {
+      const int j = xlane ? 0 : jw + sub * 4 + grp;          // the row of unit `sub` of this group
+      if (xlane || (sub < NU && j < j1)) {
+        const float e1 = expf(ms1), e2 = expf(ms2);
+        if (j == 0) {            // -log(e / (e + KZ));  d / ds = -KZ / (e + KZ)
+          lv += (double)(-logf(e1 / (e1 + KZ))); la += (double)(-logf(e2 / (e2 + KZ)));
+          g1m = -(KZ / (e1 + KZ)); g2m = -(KZ / (e2 + KZ));
+        } else {                 // -log(KZ / (e + KZ));  d / ds = e / (e + KZ)
+          lv += (double)(-logf(KZ / (e1 + KZ))); la += (double)(-logf(KZ / (e2 + KZ)));
+          g1m = e1 / (e1 + KZ); g2m = e2 / (e2 + KZ);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const float g1 = __shfl(g1m, (lane & 48) | u, 64), g2 = __shfl(g2m, (lane & 48) | u, 64);   // 0 for rows past the end
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        gv[k] = fmaf(g1, ra[u][0][k], gv[k]); gv[4 + k] = fmaf(g1, ra[u][1][k], gv[4 + k]);
+        ga[k] = fmaf(g2, rv[u][0][k], ga[k]); ga[4 + k] = fmaf(g2, rv[u][1][k], ga[4 + k]);
+      }
+    }
+    if (extra) {
+      const float gx1 = __shfl(g1m, NU, 64), gx2 = __shfl(g2m, NU, 64);
+      const float g1 = grp == 0 ? gx1 : 0.f, g2 = grp == 0 ? gx2 : 0.f;      // (every group loaded the row: count it once)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        gv[k] = fmaf(g1, xa[0][k], gv[k]); gv[4 + k] = fmaf(g1, xa[1][k], gv[4 + k]);
+        ga[k] = fmaf(g2, xv[0][k], ga[k]); ga[4 + k] = fmaf(g2, xv[1][k], ga[4 + k]);
+      }
+    }
+    // the units' loss terms sit in lanes sub = 0 .. NU of a group: into lane sub = 0
+#pragma unroll
+    for (int o = 1; o < 2 * NU; o <<= 1) { lv += __shfl_xor(lv, o, 64); la += __shfl_xor(la, o, 64); }
+  }
+#pragma unroll
+  for (int u = 0; CMA && u < NU; ++u) {
     const int j = jw + u * 4 + grp;
     float d1 = 0.f, d2 = 0.f, d3 = 0.f, d4 = 0.f;
 #pragma unroll
@@ -857,7 +935,7 @@ template <bool CMA>
 static int fused_launch(XModalArgs& a, int rows, void* ws, hipStream_t s) {
   constexpr int NL = CMA ? 4 : 2;
   const int rb = xm_rows();
-  a.S = (int)ceil_div(rows, rb);
+  a.S = (int)ceil_div(CMA ? rows : rows - 1, rb);       // cross-modal: the negatives in blocks, row 0 rides in the first
   char* w = static_cast<char*>(ws);                 // (zero-filled once by the caller: the tickets re-arm themselves)
   a.part_l = reinterpret_cast<double*>(w); w += (size_t)a.bs * a.S * NL * 8;
   a.samp_l = reinterpret_cast<double*>(w); w += (size_t)a.bs * NL * 8;

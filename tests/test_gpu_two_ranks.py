@@ -219,7 +219,9 @@ def _ddp_job(rank, world, out):
     # then updates them again from each rank's own shard, so what the broadcast installed is read where it is visible: in
     # a forward pre-hook of the wrapped module (DDP broadcasts before it calls module.forward)
     seen = {}
-    hook = m.register_forward_pre_hook(lambda mod, args: seen.setdefault("flat", mod._bn_flat.clone().cpu()))
+    def see(mod, args):                              # (a pre-hook that returns something replaces the arguments)
+        seen.setdefault("flat", mod._bn_flat.clone().cpu())
+    hook = m.register_forward_pre_hook(see)
     with torch.no_grad():
         ddp(v, a)
     hook.remove()
