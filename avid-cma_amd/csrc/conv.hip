@@ -1136,6 +1136,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
 // Epilogues as igemm_pk_kernel's direct ones: BatchNorm partial sums of the output (forward, p.stats), addend, the
 // BatchNorm-backward sums of the gradient being written (input gradient, EPI 8 / 9).
 // ------------------------------------------------------------------------------------------------
+constexpr int WG_LD_C = 64 + 4;               // row pitch (floats) of a 64-channel LDS row read by columns (== WG_LD below)
 constexpr int TC_P = 32;                      // positions per tile
 constexpr int TC_T = 8;                       // frames (= waves)
 constexpr int TC_ROWS = TC_P * TC_T;
@@ -1433,6 +1434,149 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (!lead) epilogue(slot + (nmine - 1) * G, out);
   PK_STAMP(31);
   write_stats();
+}
+
+// ------------------------------------------------------------------------------------------------
+// twgrad64_kernel — the weight gradient of the same layers (conv2x's (3,1,1) stride-1 convolutions, 64 -> 64 channels, 8
+// frames; backward of models/network_blocks.py:37,42): dw[n][dt][c] = sum over (clip, frame t, position) dy[t][n] x[t + dt - 1][c],
+// split-bf16 products.  (round 5)
+//
+// wgrad_tab_kernel<1,3> splits every fragment where it uses it: 13 vector instructions per matrix instruction, and a SIMD
+// runs them as one serial stream with its matrix instructions — the splits, not the products, are the kernel.
+// The contraction index is the pixel, so a fragment is a lane's COLUMN of 8 pixel rows (8 ds_read_b32 + the split) and
+// cannot be prepared once in LDS; what can be shared is the TAPS: a stage holds 16 positions x ALL 8 frames of dy and of x,
+// wave (n half jn, c half jc, frame half kh) walks its four frames t with the split dy[t] fragment and a rolling window of
+// the split x[t - 1], x[t], x[t + 1] fragments — one new dy and one new x fragment per 18 matrix instructions (4 vector
+// instructions per matrix instruction instead of 13), the three taps' 32 x 32 blocks of dw in 48 accumulation registers for
+// the whole kernel.  Persistent workgroups of 8 waves (136 KB of LDS: two stages), loads two stages ahead through
+// registers, one barrier per stage; at the end the two frame halves are summed through LDS and every workgroup leaves one
+// slab [64][3][64], which wgrad_reduce_kernel folds in fixed order.
+// ------------------------------------------------------------------------------------------------
+constexpr int TWG_P = 16;                          // positions per stage = one k-step
+constexpr int TWG_PLANE = TC_T * TWG_P * WG_LD_C;  // floats of one operand's stage: [8 frames][16 positions][64 + 4]
+constexpr size_t TWG_LDS = sizeof(float) * 2 * 2 * TWG_PLANE;
+
+struct TwgradArgs {
+  const float* x; const float* dy; float* part;    // part: [grid][64][3][64]
+  int B, HW;
+  unsigned mg; int sh;                             // multiply-shift division by HW
+};
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void twgrad64_kernel(const TwgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int jn = wave & 1, jc = (wave >> 1) & 1, kh = wave >> 2;
+  const int G = gridDim.x;
+  const int slot = __builtin_amdgcn_readfirstlane((int)xcd_remap(blockIdx.x, G));
+  const int HW = p.HW, NP = p.B * HW;
+  const int ntiles = (NP + TWG_P - 1) / TWG_P;
+  const int nmine = slot < ntiles ? (ntiles - slot + G - 1) / G : 0;
+  const int frame_bytes = HW * 256;
+  const long long total = (long long)NP * TC_T * 256;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)total, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)total, 0x00020000);
+  // ---- loader: 128 rows (8 frames x 16 positions) x 256 B of each operand per stage: thread (row trow + 32 i, 16 B at lcol)
+  const int trow = tid >> 4, lcol = (tid & 15) * 4;
+  unsigned ld_voff = OOB;
+  auto ld_tile = [&](int k) {
+    const unsigned pg = (unsigned)((slot + k * G) * TWG_P + (trow & 15));
+    const unsigned b = magic_div(pg, p.mg, p.sh);
+    const unsigned hw = pg - b * HW;
+    ld_voff = pg < (unsigned)NP ? (unsigned)(((b * TC_T + (trow >> 4)) * HW + hw) * 256 + lcol * 4) : OOB;
+  };
+  floatx4 vx[4], vy[4];
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int so = __builtin_amdgcn_readfirstlane(2 * i * frame_bytes);
+      vy[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsY, ld_voff, so, 0));
+      vx[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ld_voff, so, 0));
+    }
+  };
+  auto store_stage = [&](float* st) {                     // st: [dy plane | x plane]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<floatx4*>(&st[(trow + 32 * i) * WG_LD_C + lcol]) = vy[i];
+      *reinterpret_cast<floatx4*>(&st[TWG_PLANE + (trow + 32 * i) * WG_LD_C + lcol]) = vx[i];
+    }
+  };
+  floatx16 acc[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  if (nmine > 0) {
+    ld_tile(0);
+    issue_loads();
+    store_stage(smem);
+    if (nmine > 1) { ld_tile(1); issue_loads(); }
+  }
+  __syncthreads();
+  // a lane's fragment: its column (n or c = 32 j + l31) of the 8 pixel rows 8 h .. 8 h + 7 of a frame — 8 ds_read_b32
+  // (row pitch 68 floats: the 64 lanes of one read cover the 64 banks once), split into three bf16x8
+  auto frag = [&](const float* plane, int f, int col, pk_bf16x8& fh, pk_bf16x8& fm, pk_bf16x8& fl) {
+    const float* q = plane + (f * TWG_P + h * 8) * WG_LD_C + col;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = q[i * WG_LD_C];
+    pk_split8<true>(floatx4{v[0], v[1], v[2], v[3]}, floatx4{v[4], v[5], v[6], v[7]}, fh, fm, fl);
+  };
+  const int ncol = jn * 32 + l31, ccol = jc * 32 + l31;
+  const int t0 = kh * 4;
+  for (int k = 0; k < nmine; ++k) {
+    const float* cur = smem + (k & 1) * 2 * TWG_PLANE;
+    float* nxt = smem + ((k + 1) & 1) * 2 * TWG_PLANE;
+    if (k + 1 < nmine) store_stage(nxt);
+    if (k + 2 < nmine) { ld_tile(k + 2); issue_loads(); }
+    const float* Dp = cur;
+    const float* Xp = cur + TWG_PLANE;
+    pk_bf16x8 xw[3][3];                                   // rolling window of split x fragments: frames t - 1, t, t + 1
+    if (t0 > 0) frag(Xp, t0 - 1, ccol, xw[0][0], xw[0][1], xw[0][2]);
+    frag(Xp, t0, ccol, xw[1][0], xw[1][1], xw[1][2]);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int t = t0 + tt;
+      const int i0 = tt % 3, i1 = (tt + 1) % 3, i2 = (tt + 2) % 3;   // window slots of frames t - 1, t, t + 1
+      pk_bf16x8 ah, am, al;
+      frag(Dp, t, ncol, ah, am, al);
+      const bool has_next = t + 1 < TC_T;                   // (wave-uniform)
+      if (has_next) frag(Xp, t + 1, ccol, xw[i2][0], xw[i2][1], xw[i2][2]);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int sl = d == 0 ? i0 : (d == 1 ? i1 : i2);
+        if ((d == 0 && t == 0) || (d == 2 && !has_next)) continue;     // the zero padding in time
+        const pk_bf16x8 bh = xw[sl][0], bm = xw[sl][1], bl = xw[sl][2];
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[d], 0, 0, 0);
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[d], 0, 0, 0);
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[d], 0, 0, 0);
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[d], 0, 0, 0);
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[d], 0, 0, 0);
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[d], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- the two frame halves of a (jn, jc) pair: the upper half's sums through LDS, the lower half adds and writes the slab
+  float* xch = smem + (wave & 3) * (3 * 16 * 64);
+  if (kh == 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[(d * 16 + r) * 64 + lane] = acc[d][r];
+  }
+  __syncthreads();
+  if (kh == 0) {
+    float* slab = p.part + (long long)slot * (64 * 3 * 64);
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = jn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        slab[(n * 3 + d) * 64 + ccol] = acc[d][r] + xch[(d * 16 + r) * 64 + lane];
+      }
+  }
 }
 
 // dst = sum_s part[s] (+ bias)(+ addend)(relu) — fixed summation order
@@ -3483,6 +3627,23 @@ static void fill_wgrad_args(WgradArgs& a, const avid_conv_desc* d, const float* 
   fill_src_strides(d, a.ssB, a.ssT, a.ssH, a.ssW, a.ssC);
 }
 
+// ---- twgrad64_kernel: the layers it takes (the descriptor-level twin of tconv_takes; same switch: avid_tconv_configure)
+static bool twgrad_layer(const avid_conv_desc* d) {
+  return PK_SPLIT && wgrad_split() && !d->x_channel_first && d->kt == 3 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 &&
+         d->sw == 1 && d->pt == 1 && d->ph == 0 && d->pw == 0 && d->Cin == 64 && d->Cout == 64 && d->Ti == TC_T && d->To == TC_T &&
+         (long long)d->B * d->Ti * d->Hi * d->Wi * 256 < (1ll << 31);
+}
+static int twgrad_grid(const avid_conv_desc* d) {
+  const long long ntiles = ((long long)d->B * d->Hi * d->Wi + TWG_P - 1) / TWG_P;
+  return (int)(ntiles < device_cus() ? ntiles : device_cus());
+}
+static size_t twgrad_ws_bytes(const avid_conv_desc* d) { return sizeof(float) * (size_t)twgrad_grid(d) * 64 * 3 * 64; }
+static bool twgrad_takes(const avid_conv_desc* d) {
+  if (!tconv_mode() || !twgrad_layer(d)) return false;
+  const long long ntiles = ((long long)d->B * d->Hi * d->Wi + TWG_P - 1) / TWG_P;
+  return tconv_mode() == 2 || ntiles >= 6ll * device_cus();
+}
+
 extern "C" size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d) {
   if (!d || validate(d)) return 0;
   const Trim tr = trim_taps(d);      // (a trimmed layer always goes through slabs: the reduce scatters them into dw)
@@ -3490,6 +3651,7 @@ extern "C" size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d) {
   size_t nb = sizeof(float) * (size_t)pl.nsplit * d->Cout * tr.d.kt * d->kh * d->kw * d->Cin;
   if (stem_wgrad_supported(d) && stem_wgrad_ws_bytes(d) > nb) nb = stem_wgrad_ws_bytes(d);
   if (wino_wgrad_supported(d) && wino_wgrad_ws_bytes(d) > nb) nb = wino_wgrad_ws_bytes(d);
+  if (twgrad_layer(d) && twgrad_ws_bytes(d) > nb) nb = twgrad_ws_bytes(d);
   return nb;
 }
 
@@ -3509,6 +3671,30 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
     ScopedTimer t(s, "wgrad_reduce_kernel", 0.0, 4.0 * n * (nsplit + 1));
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(n, 128)), dim3(256), 0, s,
                        static_cast<const float*>(ws), dw, n, nsplit);
+    return check_launch("wgrad_reduce");
+  }
+  if (twgrad_takes(d) && ws && ws_bytes >= twgrad_ws_bytes(d)) {   // conv2x's temporal layers: the taps share their split fragments
+    hipStream_t s = (hipStream_t)stream;
+    TwgradArgs a;
+    a.x = x; a.dy = dy; a.part = static_cast<float*>(ws);
+    a.B = d->B; a.HW = d->Hi * d->Wi;
+    magic_for(a.HW, a.mg, a.sh);
+    const int grid = twgrad_grid(d);
+    static bool set = false;
+    if (!set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(twgrad64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TWG_LDS);
+      set = true;
+    }
+    const double M = (double)d->B * TC_T * a.HW, K = 3.0 * 64;
+    {
+      ScopedTimer t(s, "twgrad64_kernel", 2.0 * M * 64 * K, 4.0 * (M * 64 + M * 64 + 64 * K));
+      hipLaunchKernelGGL(twgrad64_kernel, dim3(grid), dim3(512), TWG_LDS, s, a);
+    }
+    rc = check_launch("twgrad64");
+    if (rc) return rc;
+    const long long n = 64ll * 3 * 64;
+    ScopedTimer t(s, "wgrad_reduce_kernel", 0.0, 4.0 * n * (grid + 1));
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(n, 128)), dim3(256), 0, s, static_cast<const float*>(ws), dw, n, grid);
     return check_launch("wgrad_reduce");
   }
   Trim tr = trim_taps(d);
@@ -3797,6 +3983,10 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
     }
   } else {
     WgradPlan pl = wgrad_plan(&tr.d);
+    if (twgrad_takes(d)) {
+      snprintf(buf, len, "twgrad64_kernel grid=%d", twgrad_grid(d));
+      return AVID_OK;
+    }
     if (wino_wgrad_supported(d))
       snprintf(buf, len, "wino_wgrad_kernel");
     else if (!pl.vec)

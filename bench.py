@@ -96,7 +96,7 @@ def split_kernel(name):
     (the bias / ReLU epilogues of the heads' linear layers stay on the fp32 instruction inside igemm_pk_kernel<4,1,1,2,0>)."""
     if name.startswith(("stem_fwd3", "stem_wgrad3", "igemm_pk_kernel<", "wino2_kernel", "tconv64_kernel")):
         return True
-    if name.startswith(("wgrad_tab_kernel", "wgrad_group_kernel")):
+    if name.startswith(("wgrad_tab_kernel", "wgrad_group_kernel", "twgrad64_kernel")):
         return os.environ.get("AVID_WGRAD_BF16X3", "1") != "0"
     return False
 

@@ -62,9 +62,10 @@ CASES = [
      ("igemm_pk_kernel<4,1,1,2,0>", "igemm_pk_kernel<4,1,1,2,1>s2", "wgrad_tab_kernel<2,2>")),
     ("pk_strided_128", 128, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), (16, 2, 14, 14), False, False,
      ("igemm_pk_kernel<4,1,1,2,0>", "igemm_pk_kernel<2,2,2,2,1>s2", "wgrad_tab_kernel<2,2>")),
-    # conv2x's temporal layers: tconv64_kernel (taps staged once, weights resident in LDS), forward and input gradient
+    # conv2x's temporal layers: tconv64_kernel (taps staged once, weights resident in LDS), forward and input gradient, and
+    # twgrad64_kernel (the taps share their split fragments), weight gradient
     ("tconv64", 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (5, 8, 27, 29), False, False,
-     ("tconv64_kernel<0>", "tconv64_kernel<1>", "wgrad_tab_kernel<1,3>")),
+     ("tconv64_kernel<0>", "tconv64_kernel<1>", "twgrad64_kernel")),
     # Winograd F(2x2,3x3) with split-bf16 products (wino2_kernel, forward and input gradient)
     ("wino2_64", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 8, 48, 48), False, True, ("wino2_kernel",)),
     ("wino2_128", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (9, 4, 27, 29), False, True, ("wino2_kernel",)),

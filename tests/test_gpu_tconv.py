@@ -1,4 +1,4 @@
-"""tconv64_kernel — conv2x's (3,1,1) stride-1 layers (models/network_blocks.py:37,42: 64 -> 64 channels, 8 frames) with
+"""tconv64_kernel / twgrad64_kernel — conv2x's (3,1,1) stride-1 layers (models/network_blocks.py:37,42: 64 -> 64 channels, 8 frames) with
 every input row staged once for its three taps and the pre-split weights resident in LDS — against float64 `F.conv3d`,
 against igemm_pk_kernel on the same layer, and through every epilogue it carries (BatchNorm partial sums, residual
 addend, BatchNorm-backward sums).  `avid_tconv_configure(2)` sends the small fixtures through it (the default rule asks for
@@ -68,14 +68,15 @@ def test_tconv_fwd_dgrad_vs_float64_and_igemm(shape, gpu_device, kernel_log, tco
         with kernel_log() as log:
             y = ops.conv_cl(xd, wd, stride, pad)
             y.backward(cl(gy).to(gpu_device))
-        n = log.launches("tconv64_kernel<0>"), log.launches("tconv64_kernel<1>")
-        assert n == ((1, 1) if mode == 2 else (0, 0)), (mode, sorted(log.report))
+        n = log.launches("tconv64_kernel<0>"), log.launches("tconv64_kernel<1>"), log.launches("twgrad64_kernel")
+        assert n == ((1, 1, 1) if mode == 2 else (0, 0, 0)), (mode, sorted(log.report))
         outs[mode] = (ncdhw(y.detach()).cpu(), ncdhw(xd.grad).cpu(), wd.grad.cpu())
         assert relerr(outs[mode][0], yr.detach()) < 2e-5
         assert relerr(outs[mode][1], xr.grad) < 2e-5
         assert relerr(outs[mode][2], wr.grad) < 5e-5
-    # same six-product arithmetic, another summation order over the taps / channel blocks
+    # same six-product arithmetic, another summation order over the taps / channel blocks (weight gradient: over the pixels)
     assert relerr(outs[2][0], outs[0][0]) < 2e-6 and relerr(outs[2][1], outs[0][1]) < 2e-6
+    assert relerr(outs[2][2], outs[0][2]) < 1e-5
 
 
 @pytest.mark.parametrize("shape", SHAPES[:3], ids=lambda s: "x".join(map(str, s)))

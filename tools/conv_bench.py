@@ -101,6 +101,8 @@ for name, cin, cout, k, st, pd, (T, H, W) in L:
     d_us += wd_us; dn += wdn
     dr_us, _ = pick(res["bwd"], "splitk"); dt_us, _ = pick(res["bwd"], "weight_tr")
     w_us, wn = pick(res["bwd"], "wgrad_tab")
+    tw_us, twn = pick(res["bwd"], "twgrad64")
+    w_us += tw_us; wn += twn
     ww_us, wwn = pick(res["bwd"], "wino_wgrad")
     w_us += ww_us; wn += wwn
     wr_us, _ = pick(res["bwd"], "wgrad_reduce")
