@@ -423,7 +423,7 @@ def main():
     for i in range(args.warmup):
         engine.step(video, audio, ids[i])
     sync()
-    if world > 1 and args.cu_reserve < 0:
+    if (world > 1 or os.environ.get("AVID_BENCH_CU_AB", "0") == "1") and use_dist and args.cu_reserve < 0:
         # RCCL's workgroups share the CUs with the persistent kernels, whose tile deal assumes every slot:
         # time three steps with every CU planned and three with one CU per XCD left free, keep the faster (max over ranks)
         def timed3():
