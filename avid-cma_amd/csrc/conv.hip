@@ -429,9 +429,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   constexpr int RPP = NT / 8;                   // rows staged per pass: 8 lanes x 16 B cover a 32-float row
   constexpr int PA = BM / RPP, PB = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
-  static_assert(!BS || (NT == 256 && BN == 64 && PK_SPLIT), "pre-split weights: the 128 x 64 tile of the split-bf16 build");
-  constexpr int PB3 = PK_BCH / (NT * 16);       // 16-byte items of a pre-split chunk per thread
-  constexpr int STAGE = BS ? BM * LDK + PK_BCH / 4 : (BM + BN) * LDK;
+  static_assert(!BS || (NT == 256 && (BN == 64 || BN == 128) && PK_SPLIT), "pre-split weights: the 4-wave tiles of the split-bf16 build");
+  constexpr int BCH = (BN / 64) * PK_BCH;       // bytes of a pre-split (k-tile, column block) chunk: one PK_BCH per 64 columns
+  constexpr int PB3 = BCH / (NT * 16);          // 16-byte items of a pre-split chunk per thread
+  constexpr int STAGE = BS ? BM * LDK + BCH / 4 : (BM + BN) * LDK;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)((n0 + lrow + RPP * i) * p.w_row + lcol) * 4;
-    if (BS) ld_bnt = __builtin_amdgcn_readfirstlane(nt * PK_BCH);
+    if (BS) ld_bnt = __builtin_amdgcn_readfirstlane(nt * BCH);
   };
   auto issue_loads = [&]() {   // k-tile (loader tile; tap, channel block) -> registers: PA + PB loads
     // The descriptor words and scalar offsets were prepared when they last changed (setup_tile / advance); here
@@ -2762,18 +2763,35 @@ static void launch_pk_eb(const ConvArgs& a, int grid, size_t lds, hipStream_t s)
 // pre-split weights (ConvArgs::wsp) are consumed by the 128 x 64 tile with the epilogues convolution layers use
 template <int WM, int WN, int TM, int TN, int EPI>
 constexpr bool pk_takes_split() {
-  return PK_SPLIT && WM == 4 && WN == 1 && TM == 1 && TN == 2 && (EPI == 0 || EPI == 1 || EPI == 8 || EPI == 9);
+  return PK_SPLIT && ((WM == 4 && WN == 1 && TM == 1 && TN == 2) || (WM == 2 && WN == 2 && TM == 2 && TN == 2)) &&
+         (EPI == 0 || EPI == 1 || EPI == 8 || EPI == 9);
 }
+// The 128 x 128 tile with pre-split weights (round 5): half the splits (8.1 -> ~5 vector instructions per matrix instruction), but
+// its stage grows from 36.9 to 43 KB — ONE workgroup per CU instead of two.  Measured per layer (tools/conv_bench.py 64, us
+// forward / input gradient): where a launch deals several tiles per CU the lost occupancy costs more than the splits save
+// (conv3x temporal 51.0 -> 56.1 / 56.2 -> 62.7, conv3x strided spatial forward 114.7 -> 132.7); where every workgroup has at
+// most one (tile, K piece) unit anyway it wins (conv4x strided spatial forward 85.9 -> 78.9, audio block 3 32.4 -> 29.9 / 40.4 ->
+// 36.4).  AVID_BS_WIDE: 1 (default) the second kind only — plans without a full round —, 2 every launch of the tile, 0 never.
+static int bs_wide_mode() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AVID_BS_WIDE");
+    v = e ? atoi(e) : 1;
+    if (v < 0 || v > 2) v = 1;
+  }
+  return v;
+}
+static bool bs_wide(const PkPlan& pk) { return pk.tile == 0 && (bs_wide_mode() == 2 || (bs_wide_mode() == 1 && pk.full == 0)); }
 
 static long long g_presplit_launches = 0;    // avid_debug_presplit_launches (tests: which instruction sequence a layer ran)
 
 template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED, int EPI>
 static void launch_pk_e(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-  if constexpr (pk_takes_split<WM, WN, TM, TN, EPI>()) {
+  if constexpr (pk_takes_split<WM, WN, TM, TN, EPI>() && !(STRIDED && WN == 2)) {
     if (a.wsp) {
       ++g_presplit_launches;
-      constexpr int BM = WM * TM * 32;
-      const size_t lds3 = sizeof(float) * 2 * (BM * LDK + PK_BCH / 4) + (STRIDED ? sizeof(int) * 2 * BM : 0);
+      constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+      const size_t lds3 = sizeof(float) * 2 * (BM * LDK + (BN / 64) * PK_BCH / 4) + (STRIDED ? sizeof(int) * 2 * BM : 0);
       launch_pk_eb<WM, WN, TM, TN, MODE, STRIDED, EPI, true>(a, grid, lds3, s);
       return;
     }
@@ -3278,12 +3296,14 @@ static bool conv_takes_split(const avid_conv_desc* d, int which) {
   if (which == 0) {
     if (d->Cin % 32 || d->Cout % 64 || wino_supported(d, 0)) return false;
     const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
-    return plan_pk(M, d->Cout, trim_taps(d).d.kt * d->kh * d->kw * (d->Cin / BK), 0).tile == 1;
+    const PkPlan pk = plan_pk(M, d->Cout, trim_taps(d).d.kt * d->kh * d->kw * (d->Cin / BK), 0);
+    return pk.tile == 1 || bs_wide(pk);
   }
   if (d->Cin % 64 || d->Cout % 32 || d->st > 2 || d->sh > 2 || d->sw > 2 || wino_supported(d, 1)) return false;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
   if (d->st > 1 || d->sh > 1 || d->sw > 1) return M * d->Cin * 4 < (1ll << 31) && d->Cin % 128 != 0;
-  return plan_pk(M, d->Cin, trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK), 1).tile == 1;
+  const PkPlan pk = plan_pk(M, d->Cin, trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK), 1);
+  return pk.tile == 1 || bs_wide(pk);
 }
 
 extern "C" long long avid_debug_presplit_launches(void) { return g_presplit_launches; }
