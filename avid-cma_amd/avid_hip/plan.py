@@ -849,8 +849,21 @@ def run(model, video, audio):
     overlap = (not timing) and os.environ.get("AVID_OVERLAP_TOWERS", "1") == "1" and (eng is None or model.overlap_towers)
     trailing = (not timing) and bool(ops.DEFER_WGRAD) and (eng is None or eng._defer_ok())
     video, audio = video.contiguous(), audio.contiguous()
+    # (what a compiled Plan froze besides shapes and switches — which parameters take gradients, their dtype, and
+    #  the identity of the BatchNorm buffers its slot table points at: parameters frozen after the first step, `.double()`,
+    #  `.cpu().cuda()` must not meet a stale program.  ~20 us per call for 141 parameters.)
+    mods = model.__dict__.get("_avid_param_list")
+    if mods is None:
+        mods = model.__dict__["_avid_param_list"] = list(model.parameters())
+    fp, dt_ok = 0, True
+    for p in mods:
+        fp = (fp << 1) | int(p.requires_grad)
+        dt_ok = dt_ok and p.dtype == torch.float32 and p.is_cuda
+    if not dt_ok:
+        return None
+    flat = getattr(model, "_bn_flat", None)
     key = (tuple(video.shape), tuple(audio.shape), video.device.index, overlap, trailing, bool(ops.GROUP_WGRAD),
-           ops.FUSE_BN_BWD, ops.wino_epoch())
+           ops.FUSE_BN_BWD, ops.wino_epoch(), fp, flat.data_ptr() if flat is not None else 0)
     plans = model.__dict__.setdefault("_avid_plans", {})
     pl = plans.get(key)
     if pl is not None and pl is not False and eng is not None and _engine_flat(eng, pl) is None:

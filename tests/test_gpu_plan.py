@@ -200,6 +200,45 @@ def test_hooked_or_eval_model_takes_the_per_layer_path(gpu_device):
     assert not type(v.grad_fn).__name__.startswith("NetFn")
 
 
+def test_a_stale_program_is_not_reused(gpu_device):
+    """What a compiled Plan froze besides shapes is part of its cache key: a parameter frozen AFTER the first
+    step sends the next call to the per-layer path (no gradient for the frozen parameter, every other gradient as before),
+    un-freezing it brings the program back; BatchNorm buffers re-created by `.cpu()` / `.cuda()` get a fresh program whose
+    running statistics keep updating."""
+    dev = gpu_device
+    video, audio, _ = _data(dev, bs=2, steps=1, hw=64)
+    m = _model(dev)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        v, a = m(video, audio)
+        (v.square().sum() + a.square().sum()).backward()
+        return v
+
+    v = step()
+    assert type(v.grad_fn).__name__.startswith("NetFn")
+    ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    w = m.video_model.conv3x[0].tmp_conv1.weight
+    w.requires_grad_(False)
+    v = step()
+    assert not type(v.grad_fn).__name__.startswith("NetFn") and w.grad is None
+    for n, p in m.named_parameters():
+        if p is not w:
+            assert float((p.grad - ref[n]).abs().max()) <= 1e-4 * float(ref[n].abs().max()) + 1e-12, n
+    w.requires_grad_(True)
+    v = step()
+    assert type(v.grad_fn).__name__.startswith("NetFn") and w.grad is not None
+    m.cpu()
+    m.to(dev)
+    bn = m.video_model.conv2x[0].spt_bn1
+    before = bn.running_mean.clone()
+    v = step()
+    torch.cuda.synchronize()
+    assert type(v.grad_fn).__name__.startswith("NetFn")
+    assert not torch.equal(bn.running_mean, before)         # the new buffers are the ones the program updates
+
+
 def test_backward_twice_raises(gpu_device):
     dev = gpu_device
     video, audio, _ = _data(dev, bs=2, steps=1, hw=64)
