@@ -2833,6 +2833,7 @@ static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
 
 
 // ---- tconv64_kernel: which launches take it, and the launch
+constexpr int TCONV_PARTS_DEFAULT = 5;      // forward + weight gradient (the input gradient: see tconv_parts)
 static int g_tconv_mode = -1;     // -1: AVID_TCONV from the environment (default 1); 0 off; 1 layers with >= 3 rounds of tiles; 2 whenever it can
 static int tconv_mode() {
   if (g_tconv_mode < 0) {
@@ -2842,12 +2843,40 @@ static int tconv_mode() {
   }
   return g_tconv_mode;
 }
+// Which of the three kernels the rule applies to: bit 0 forward, bit 1 input gradient, bit 2 weight gradient (AVID_TCONV_PARTS;
+// avid_tconv_configure(2) = tests: all three).  Default 5: the input gradient stays on igemm_pk_kernel IN THE STEP.  Layer
+// alone it is 90 -> 64 us; in the step it carries the BatchNorm-backward sums (86-93 us against ~96) and the whole step got
+// SLOWER with it: same box, alternating, ms per step / average shader clock — none 9.92 / 2.28 GHz, forward only 9.89 / 2.28,
+// weight gradient only 9.89 / 2.29, input gradient only 10.14 / 2.23, all three 10.08 / 2.20; second box: none 10.03 / 2.25,
+// forward + weight gradient 9.99 / 2.21, all three 10.10 / 2.17.  Every other matrix kernel of the step runs 3-7 % slower when
+// these kernels are in it — the chip answers their power draw (the lowest in-kernel clock of the step, 1.75 GHz) with a
+// lower clock all around, and most of what they save is given back (the step sits on an energy plateau).
+static int tconv_mode();
+static int tconv_parts() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AVID_TCONV_PARTS");
+    v = e ? atoi(e) & 7 : TCONV_PARTS_DEFAULT;
+  }
+  return tconv_mode() == 2 ? 7 : v;
+}
+// Grid of the persistent tile walkers: the fewest workgroups that need no more rounds than all CUs would (1568 tiles on 256
+// CUs are 7 rounds either way: 224 workgroups of exactly 7 tiles).  The CUs left over are not lost: in the step these kernels
+// run at the lowest clock of all (1.75 GHz) and the chip's power management answers a full-chip launch of them by lowering
+// the clock of every kernel around it — with tconv64_kernel<1> on all 256 CUs the whole step's average clock fell from 2.29 to
+// 2.25 GHz and every other matrix kernel ran 4-7 % slower (step 9.88 -> 9.95-10.05 ms although the kernel itself had got
+// faster); on 224 it does not.  AVID_TCONV_GRID1 caps the input gradient's grid further (experiments).
+static int balanced_grid(long long ntiles) {
+  const int cus = device_cus();
+  if (ntiles <= cus) return (int)ntiles;
+  const long long rounds = (ntiles + cus - 1) / cus;
+  return (int)((ntiles + rounds - 1) / rounds);
+}
 static int tconv_grid(const ConvArgs& a) {
-  const long long ntiles = ((long long)a.B * a.Hs * a.Ws + TC_P - 1) / TC_P;
-  return (int)(ntiles < device_cus() ? ntiles : device_cus());
+  return balanced_grid(((long long)a.B * a.Hs * a.Ws + TC_P - 1) / TC_P);
 }
 static bool tconv_takes(const ConvArgs& a, int mode) {
-  if (!PK_SPLIT || !tconv_mode() || !a.wsp) return false;
+  if (!PK_SPLIT || !tconv_mode() || !a.wsp || !(tconv_parts() & (1 << mode))) return false;
   if (a.kt != 3 || a.kh != 1 || a.kw != 1 || a.st != 1 || a.sh != 1 || a.sw != 1 || a.pt != 1 || a.ph != 0 || a.pw != 0) return false;
   if (a.Cs != 64 || a.Cd != 64 || a.Ts != TC_T || a.Td != TC_T || a.Hs != a.Hd || a.Ws != a.Wd) return false;
   if (a.bias || a.relu || a.epi_op || a.add_s[0] * a.add_s[1] * a.add_s[2] != 1) return false;
@@ -2871,7 +2900,12 @@ static void launch_tconv_e(const ConvArgs& a, int grid, hipStream_t s) {
 template <int MODE>
 static int launch_tconv(ConvArgs& a, hipStream_t s) {
   magic_for(a.Hs * a.Ws, a.mgW, a.shW);       // position -> clip
-  const int grid = tconv_grid(a);
+  int grid = tconv_grid(a);
+  {   // experiment: cap the input gradient's grid (AVID_TCONV_GRID1)
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("AVID_TCONV_GRID1"); cap = e ? atoi(e) : 0; }
+    if (MODE == 1 && cap > 0 && grid > cap) grid = cap;
+  }
   const double K = 3.0 * 64;
   ScopedTimer t(s, MODE == 0 ? "tconv64_kernel<0>" : "tconv64_kernel<1>", 2.0 * a.M * 64 * K,
                 4.0 * ((double)a.M * 64 + 64 * K + (double)a.M * 64 * (1 + (a.addend ? 1 : 0) + (a.bnb_x ? 1 : 0))));
@@ -3654,12 +3688,11 @@ static bool twgrad_layer(const avid_conv_desc* d) {
          (long long)d->B * d->Ti * d->Hi * d->Wi * 256 < (1ll << 31);
 }
 static int twgrad_grid(const avid_conv_desc* d) {
-  const long long ntiles = ((long long)d->B * d->Hi * d->Wi + TWG_P - 1) / TWG_P;
-  return (int)(ntiles < device_cus() ? ntiles : device_cus());
+  return balanced_grid(((long long)d->B * d->Hi * d->Wi + TWG_P - 1) / TWG_P);
 }
 static size_t twgrad_ws_bytes(const avid_conv_desc* d) { return sizeof(float) * (size_t)twgrad_grid(d) * 64 * 3 * 64; }
 static bool twgrad_takes(const avid_conv_desc* d) {
-  if (!tconv_mode() || !twgrad_layer(d)) return false;
+  if (!tconv_mode() || !(tconv_parts() & 4) || !twgrad_layer(d)) return false;
   const long long ntiles = ((long long)d->B * d->Hi * d->Wi + TWG_P - 1) / TWG_P;
   return tconv_mode() == 2 || ntiles >= 6ll * device_cus();
 }
@@ -3969,12 +4002,12 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
   };
   // conv2x's temporal layers (given their pre-split weights): tconv64_kernel — the descriptor-level form of tconv_takes
   const long long tc_tiles = ((long long)d->B * d->Hi * d->Wi + TC_P - 1) / TC_P;
-  const bool tc = PK_SPLIT && tconv_mode() && vec && which < 2 && d->kt == 3 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 &&
+  const bool tc = PK_SPLIT && tconv_mode() && vec && which < 2 && (tconv_parts() & (1 << which)) && d->kt == 3 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 &&
                   d->sw == 1 && d->pt == 1 && d->ph == 0 && d->pw == 0 && d->Cin == 64 && d->Cout == 64 && d->Ti == TC_T &&
                   d->To == TC_T && (long long)d->B * d->Ti * d->Hi * d->Wi * 256 < (1ll << 31) &&
                   (tconv_mode() == 2 || tc_tiles >= 3ll * device_cus());
   if (tc) {
-    snprintf(buf, len, "tconv64_kernel<%d> grid=%d", which, (int)(tc_tiles < device_cus() ? tc_tiles : device_cus()));
+    snprintf(buf, len, "tconv64_kernel<%d> grid=%d", which, balanced_grid(tc_tiles));
     return AVID_OK;
   }
   if (which == 0) {
