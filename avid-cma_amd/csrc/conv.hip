@@ -2849,8 +2849,8 @@ static int tconv_mode() {
 // SLOWER with it: same box, alternating, ms per step / average shader clock — none 9.92 / 2.28 GHz, forward only 9.89 / 2.28,
 // weight gradient only 9.89 / 2.29, input gradient only 10.14 / 2.23, all three 10.08 / 2.20; second box: none 10.03 / 2.25,
 // forward + weight gradient 9.99 / 2.21, all three 10.10 / 2.17.  Every other matrix kernel of the step runs 3-7 % slower when
-// these kernels are in it — the chip answers their power draw (the lowest in-kernel clock of the step, 1.75 GHz) with a
-// lower clock all around, and most of what they save is given back (the step sits on an energy plateau).
+// these kernels are in it — the clock the chip holds over the step falls with these kernels in it (they run at the lowest
+// in-kernel clock of the step, 1.75 GHz) although the package power falls too (tools/power_ab.py).
 static int tconv_mode();
 static int tconv_parts() {
   static int v = -1;
@@ -2862,7 +2862,7 @@ static int tconv_parts() {
 }
 // Grid of the persistent tile walkers: the fewest workgroups that need no more rounds than all CUs would (1568 tiles on 256
 // CUs are 7 rounds either way: 224 workgroups of exactly 7 tiles).  The CUs left over are not lost: in the step these kernels
-// run at the lowest clock of all (1.75 GHz) and the chip's power management answers a full-chip launch of them by lowering
+// run at the lowest clock of all (1.75 GHz) and the chip's frequency management answers a full-chip launch of them by lowering
 // the clock of every kernel around it — with tconv64_kernel<1> on all 256 CUs the whole step's average clock fell from 2.29 to
 // 2.25 GHz and every other matrix kernel ran 4-7 % slower (step 9.88 -> 9.95-10.05 ms although the kernel itself had got
 // faster); on 224 it does not.  AVID_TCONV_GRID1 caps the input gradient's grid further (experiments).
