@@ -753,15 +753,25 @@ __global__ __launch_bounds__(512) void stem_wgrad_kernel(const StemArgs p) {
 // dy rows are stored with their 32-column halves swapped on every second GROUP of 8 pixels (the two half-waves read groups
 // 8 pixels apart: disjoint banks).
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int KT>
+// PRE (round 5): dy is split ONCE, when its rows are committed to LDS, into the fragments the products read — DyF[k-step][n-tile]
+// [hi | mid | lo][lane][8 bf16], 6 KB per 16 pixels.  In the form above every wave splits the dy fragments it uses: the 2 n-tile
+// fragments of a k-step are split by 12 (wave, n-tile) users — 11 vector instructions per matrix instruction, the most of any
+// kernel in the step.  The transposition a pixel-contraction fragment needs (a lane = 8 consecutive pixels of ONE channel) is
+// done by the loader's thread mapping instead of by 16-bit LDS traffic: a thread fetches the same 4 channels of 8 CONSECUTIVE
+// pixels (8 row-coalesced 16-byte loads), i.e. the complete fragment content of 4 lanes — 16 pair splits and 12 ds_write_b128
+// per thread and tile; a product step then reads a dy fragment with 3 ds_read_b128 and no vector instruction.
+template <int CIN, int KT, bool PRE = false>
 __global__ __launch_bounds__(512, 1) void stem_wgrad3_kernel(const StemArgs p) {
   constexpr int KP = (CIN * KT * 49 + 31) / 32 * 32;   // k' columns of a slab (dense layout)
   constexpr int NKT_ALL = KP / 32, NKT = 3;
   static_assert(NKT_ALL == 14, "the two-role split is laid out for 14 k' tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ds = smem;                               // [256][WS_LD]
-  int* pixbase = reinterpret_cast<int*>(smem + STEM_TILE * WS_LD);   // [256]
-  float* P = smem + STEM_TILE * WS_LD + STEM_TILE;
+  // PRE: DyF takes (tile_px / 16) x 6 KB where Ds took 64 KB
+  const int dy_floats = PRE ? (p.tile_px / 16) * (S3_STEP_BYTES / 4) : STEM_TILE * WS_LD;
+  float* Ds = smem;                               // [256][WS_LD]   (PRE: DyF)
+  char* DyF = reinterpret_cast<char*>(smem);
+  int* pixbase = reinterpret_cast<int*>(smem + dy_floats);   // [256]
+  float* P = smem + dy_floats + STEM_TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, l31 = lane & 31;
   const int npix = p.Ho * p.Wo;
@@ -820,7 +830,8 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad3_kernel(const StemArgs p) {
         (void*)(p.dy + ((long long)t.frame * npix + t.p0) * 64), 0, (t.p1 - t.p0) * 256, 0x00020000);
 #pragma unroll
     for (int it = 0; it < STEM_TILE * 16 / 512; ++it) {
-      const int e = tid + it * 512;
+      // PRE: pixel 8 (tid >> 4) + it, channels 4 (tid & 15) ..: a thread holds 8 consecutive pixels of its 4 channels
+      const int e = PRE ? (((tid >> 4) * 8 + it) * 16 + (tid & 15)) : tid + it * 512;
       pre_d[it] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsD, (unsigned)e * 16u, 0, 0));
     }
   };
@@ -831,10 +842,27 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad3_kernel(const StemArgs p) {
       const int e = tid + it * 512;
       if (e < total) *reinterpret_cast<floatx4*>(P + 4 * e) = pre_p[it];
     }
+    if (PRE) {
+      const int pgrp = tid >> 4, ks = pgrp >> 1, gg = pgrp & 1;
+      if (ks < p.tile_px / 16) {
 #pragma unroll
-    for (int it = 0; it < STEM_TILE * 16 / 512; ++it) {
-      const int e = tid + it * 512;                  // pixel e >> 4, columns 4 (e & 15) ..: halves swapped on odd pixel groups
-      *reinterpret_cast<floatx4*>(&Ds[(e >> 4) * WS_LD + (((e & 15) * 4) ^ (((e >> 7) & 1) << 5))]) = pre_d[it];
+        for (int c = 0; c < 4; ++c) {
+          const int n = 4 * (tid & 15) + c;
+          unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s3_split2(pre_d[2 * i][c], pre_d[2 * i + 1][c], hh[i], mm[i], ll[i]);
+          char* q = DyF + ((ks * 2 + (n >> 5)) * 3) * 1024 + ((n & 31) + 32 * gg) * 16;
+          *reinterpret_cast<uintx4_t*>(q) = uintx4_t{hh[0], hh[1], hh[2], hh[3]};
+          *reinterpret_cast<uintx4_t*>(q + 1024) = uintx4_t{mm[0], mm[1], mm[2], mm[3]};
+          *reinterpret_cast<uintx4_t*>(q + 2048) = uintx4_t{ll[0], ll[1], ll[2], ll[3]};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < STEM_TILE * 16 / 512; ++it) {
+        const int e = tid + it * 512;                  // pixel e >> 4, columns 4 (e & 15) ..: halves swapped on odd pixel groups
+        *reinterpret_cast<floatx4*>(&Ds[(e >> 4) * WS_LD + (((e & 15) * 4) ^ (((e >> 7) & 1) << 5))]) = pre_d[it];
+      }
     }
   };
 
@@ -886,16 +914,28 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad3_kernel(const StemArgs p) {
         const int px = 16 * s + 8 * g;               // first pixel of this half-wave's group
         const int swz = (px >> 3 & 1) << 5;          // the group's column swizzle
         const float* dr = Ds + px * WS_LD;
-        float va[2][8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          va[0][e] = dr[e * WS_LD + (colA0 ^ swz)];
-          if (B_) va[1][e] = dr[e * WS_LD + (colA1 ^ swz)];
-        }
         const int pb = pixbase[px];
         bf16x8_t ah[2], am[2], al[2];
-        frag3(va[0], ah[0], am[0], al[0]);
-        if (B_) frag3(va[1], ah[1], am[1], al[1]);
+        if (PRE) {
+          const char* q0 = DyF + ((s * 2 + (B_ ? 0 : nsel)) * 3) * 1024 + lane * 16;
+          ah[0] = *reinterpret_cast<const bf16x8_t*>(q0);
+          am[0] = *reinterpret_cast<const bf16x8_t*>(q0 + 1024);
+          al[0] = *reinterpret_cast<const bf16x8_t*>(q0 + 2048);
+          if (B_) {
+            ah[1] = *reinterpret_cast<const bf16x8_t*>(q0 + 3072);
+            am[1] = *reinterpret_cast<const bf16x8_t*>(q0 + 4096);
+            al[1] = *reinterpret_cast<const bf16x8_t*>(q0 + 5120);
+          }
+        } else {
+          float va[2][8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            va[0][e] = dr[e * WS_LD + (colA0 ^ swz)];
+            if (B_) va[1][e] = dr[e * WS_LD + (colA1 ^ swz)];
+          }
+          frag3(va[0], ah[0], am[0], al[0]);
+          if (B_) frag3(va[1], ah[1], am[1], al[1]);
+        }
 #pragma unroll
         for (int j = 0; j < NBv; ++j) {
           float vb[8];
@@ -1096,13 +1136,21 @@ static int stem_wgrad_launch(const avid_conv_desc* d, const float* x, const floa
     if (!set3) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad3_kernel<3, 3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_wgrad3_kernel<3, 3, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       set3 = true;
     }
+    // dy pre-split into fragment order (PRE) where its 6 KB per 16 pixels fit beside the patch; AVID_STEM_WGRAD_PRE=0: never
+    static int pre_on = -1;
+    if (pre_on < 0) { const char* e = getenv("AVID_STEM_WGRAD_PRE"); pre_on = e ? atoi(e) != 0 : 1; }
+    const size_t lds_pre = (size_t)(a.tile_px / 16) * S3_STEP_BYTES + sizeof(float) * (STEM_TILE + stem_patch_floats(d, stem_wgrad_tile_px(d)));
+    const bool pre = pre_on && lds_pre <= 160 * 1024;
     const double M = (double)d->B * d->To * d->Ho * d->Wo, K = 3.0 * 3 * 49;
     {
       ScopedTimer t(s, "stem_wgrad3_kernel<3,3>", 2.0 * M * 64 * K,
                     4.0 * ((double)d->B * 3 * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
-      hipLaunchKernelGGL((stem_wgrad3_kernel<3, 3>), dim3(G), dim3(512), lds, s, a);
+      if (pre) hipLaunchKernelGGL((stem_wgrad3_kernel<3, 3, true>), dim3(G), dim3(512), lds_pre, s, a);
+      else hipLaunchKernelGGL((stem_wgrad3_kernel<3, 3>), dim3(G), dim3(512), lds, s, a);
     }
     int rc3 = check_launch("stem_wgrad3");
     if (rc3) return rc3;

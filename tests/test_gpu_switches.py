@@ -29,7 +29,8 @@ def default_run(gpu_device):
     return _probe({})
 
 
-IDENTICAL = [{"AVID_PLAN": "0"}, {"AVID_OVERLAP_TOWERS": "0"}, {"AVID_DEFER_WGRAD": "0"}, {"AVID_STREAM_PROBE": "0"},
+IDENTICAL = [{"AVID_PLAN": "0"}, {"AVID_STEM_WGRAD_PRE": "0"},    # (dy split at commit time or per use: the same split, the same sums)
+              {"AVID_OVERLAP_TOWERS": "0"}, {"AVID_DEFER_WGRAD": "0"}, {"AVID_STREAM_PROBE": "0"},
              {"AVID_FORCE_DIST": "1"}, {"AVID_FORCE_DIST": "1", "AVID_BUCKET_MB": "2"},
              {"AVID_HIP_LIB": os.path.join(os.path.dirname(HERE), "avid-cma_amd", "avid_hip", "libavid_hip.so")}]
 CLOSE = [{"AVID_GROUP_WGRAD": "0"}, {"AVID_WGRAD_BF16X3": "0"}, {"AVID_FUSE_BN_BWD": "0"}, {"AVID_FUSE_BN_STATS": "0"}, {"AVID_FUSE_RES": "0"},
