@@ -23,8 +23,28 @@ kernel needs the GPU.  BatchNorm statistics stay per-rank — the reference has 
 from __future__ import annotations
 
 import os
+import weakref
 import torch
 import torch.distributed as dist
+
+
+_FLAT_OF = {}           # id(parameter) -> weakref(FlatParams it is a view of)
+
+
+def flat_of(params):
+    """The FlatParams whose parameters are exactly ``params`` (any order), or None."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return None
+    ref = _FLAT_OF.get(id(params[0]))
+    flat = ref() if ref is not None else None
+    if flat is None or len(flat.params) != len(params):
+        return None
+    mine = {id(p) for p in flat.params}
+    if any(id(p) not in mine for p in params) or any(p.data_ptr() != flat.flat.data_ptr() + 4 * o
+                                                     for p, o in zip(flat.params, flat.offsets)):
+        return None
+    return flat
 
 
 def _dist_on():
@@ -39,8 +59,10 @@ def _dist_on():
 class FlatParams:
     """Re-seat ``module``'s parameters and gradients as views of two flat buffers."""
 
-    def __init__(self, module: torch.nn.Module):
-        params = [p for p in module.parameters() if p.requires_grad]
+    def __init__(self, module):
+        """``module``: an nn.Module, or the parameters themselves (an optimizer's: Adam below)."""
+        src = module.parameters() if isinstance(module, torch.nn.Module) else module
+        params = [p for p in src if p.requires_grad]
         self.params = list(reversed(params))            # backward produces gradients roughly in this order
         dev, dt = self.params[0].device, self.params[0].dtype
         self.offsets, off = [], 0
@@ -59,6 +81,14 @@ class FlatParams:
             p.data = view
             p.grad = self.grad[o:o + p.numel()].as_strided(p.shape, p.stride())
             self.grad_views.append(p.grad)
+            _FLAT_OF[id(p)] = weakref.ref(self)
+
+    def seat_grads(self):
+        """`.grad` of every parameter is its view of the flat gradient buffer again (after a zero_grad(set_to_none=True):
+        the kernels wrote the buffer, not the attribute)."""
+        for p, v in zip(self.params, self.grad_views):
+            if p.grad is not v:
+                p.grad = v
 
     def zero_grad(self):
         self.grad.zero_()
@@ -127,8 +157,12 @@ def lib_timing():
 class GradBuckets:
     """Bucketed, backward-overlapped gradient all-reduce over a ``FlatParams`` gradient buffer."""
 
-    def __init__(self, flat: FlatParams, bucket_bytes: int = 16 << 20):
+    def __init__(self, flat: FlatParams, bucket_bytes: int = 16 << 20, average: bool = False, hooks=None):
+        """``average``: the collective leaves the MEAN over ranks in the buffer (what torch's DDP hands the optimizer) instead
+        of the sum (TrainStep folds 1 / world into its Adam launch).  ``hooks``: autograd hooks on every parameter — default:
+        only where no kernel reports its gradients itself (CPU tensors)."""
         self.flat = flat
+        self.average = average
         self.world = dist.get_world_size() if _dist_on() else 1
         self.comm = _dist_on()
         self.bounds, self.bucket_of = [], []
@@ -149,12 +183,13 @@ class GradBuckets:
         self.comm_used = []           # every collectives' stream a bucket went out on this step (normally one)
         self.step_set = None          # the step's StreamSet, resolved once per step (first bucket)
         self.measure = False          # bench.py: event-time the compute stream's wait for the collectives in finish()
+        self.on_autograd = None       # called from every autograd hook (DistributedDataParallel: arm the end-of-backward callback)
         self.wait_events = []
         self.producers = [set() for _ in self.bounds]     # streams that issued gradients of each bucket
         # Autograd hooks only where the kernels do not report their gradients themselves (ops.GradSlots, the
         # CUDA path): 141 tensor hooks cost ~0.4 ms of backward per step on the single-rank check.  A gradient
         # that arrives through autograd anyway (a parameter used twice) is picked up by finish().
-        if self.comm and not flat.grad.is_cuda:
+        if (self.comm and not flat.grad.is_cuda) if hooks is None else hooks:
             for i, p in enumerate(flat.params):
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
@@ -175,7 +210,17 @@ class GradBuckets:
         return self.flat.grad.is_cuda and torch.cuda.is_current_stream_capturing()
 
     def _make_hook(self, i):
+        view = self.flat.grad_views[i]
+
         def hook(param):
+            # a gradient that came through autograd into a tensor of its own (`.grad` was None: zero_grad(set_to_none=True))
+            # belongs in the flat buffer the collectives and the optimizer read
+            g = param.grad
+            if g is not None and g.data_ptr() != view.data_ptr():
+                view.copy_(g)
+                param.grad = view
+            if self.on_autograd is not None:
+                self.on_autograd()
             self.ready(i)
         return hook
 
@@ -193,6 +238,7 @@ class GradBuckets:
         stalls both (the 6-8 ms a one-rank group used to add)."""
         s, e = self.bounds[b]
         if not self.flat.grad.is_cuda:
+            # (gloo has no AVG: the mean is taken in finish(), behind the wait)
             self.works.append(dist.all_reduce(self.flat.grad[s:e], async_op=True))
             return
         from . import lib, streams
@@ -207,8 +253,11 @@ class GradBuckets:
         cs = ss.comm
         for st in prod:
             lib.call("avid_stream_wait", cs.cuda_stream, st.cuda_stream)
+        native = self.average and dist.get_backend() == "nccl"       # (RCCL averages; gloo — the two-ranks-on-one-GPU tests — cannot)
         with torch.cuda.stream(cs):
-            dist.all_reduce(self.flat.grad[s:e])
+            dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.AVG if native else dist.ReduceOp.SUM)
+            if self.average and not native and self.world > 1:
+                self.flat.grad[s:e].div_(self.world)
         if all(cs is not c for c in self.comm_used):
             self.comm_used.append(cs)
 
@@ -234,7 +283,10 @@ class GradBuckets:
             dev = self.flat.grad.device
             cur = torch.cuda.current_stream(dev)
             cur.wait_stream(ops.side_stream(dev, 1))         # the audio tower's gradients
-            dist.all_reduce(self.flat.grad)
+            native = self.average and dist.get_backend() == "nccl"
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.AVG if native else dist.ReduceOp.SUM)
+            if self.average and not native and self.world > 1:
+                self.flat.grad.div_(self.world)
             self.launched = [True] * len(self.bounds)
         if self.comm:
             for b, left in enumerate(self.pending):
@@ -249,6 +301,8 @@ class GradBuckets:
                 e0.record()
             for w in self.works:
                 w.wait()                             # (CPU tensors: gloo)
+            if self.works and self.average and self.world > 1:
+                self.flat.grad.div_(self.world)
             for cs in self.comm_used:
                 torch.cuda.current_stream(self.flat.grad.device).wait_stream(cs)
             self.comm_used = []
@@ -271,7 +325,7 @@ class TrainStep:
     """
 
     def __init__(self, model, criterion, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5,
-                 bucket_bytes=16 << 20, broadcast_buffers="step"):
+                 bucket_bytes=16 << 20, broadcast_buffers="step", _wrapper=False):
         """``broadcast_buffers``: DistributedDataParallel broadcasts rank 0's BatchNorm buffers before EVERY
         forward (utils/main_utils.py:112, default ``broadcast_buffers=True``).  A training-mode forward never
         reads them (it normalises with the batch statistics), and rank 0's own buffers are never overwritten, so
@@ -298,9 +352,12 @@ class TrainStep:
             model.overlap_towers = True
         if os.environ.get("AVID_BUCKET_MB"):             # tuning knob: gradient all-reduce bucket size
             bucket_bytes = int(float(os.environ["AVID_BUCKET_MB"]) * (1 << 20))
-        self.buckets = GradBuckets(self.flat, bucket_bytes)
-        self.m = torch.zeros_like(self.flat.flat)
-        self.v = torch.zeros_like(self.flat.flat)
+        # (_wrapper: the engine inside DistributedDataParallel below — the optimizer is somebody else's, so the collectives
+        #  average, every parameter carries an autograd hook for gradients that do not come out of a launch program, and
+        #  there is no Adam state here)
+        self.buckets = GradBuckets(self.flat, bucket_bytes, average=_wrapper, hooks=True if _wrapper else None)
+        self.m = None if _wrapper else torch.zeros_like(self.flat.flat)
+        self.v = None if _wrapper else torch.zeros_like(self.flat.flat)
         self.t = 0
         self.t_dev = torch.zeros((), dtype=torch.int64, device=self.flat.flat.device) \
             if self.flat.flat.is_cuda else None
@@ -559,3 +616,159 @@ class TrainStep:
         if mult is not None:
             mult.offset += 1
         return self._sloss
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's OWN loop (main-avid.py:155-180: model(...); criterion(...); loss.item(); optimizer.zero_grad(); loss.backward();
+# optimizer.step()) on the engine's pieces: the two objects its factories build — utils/main_utils.py:112
+# `DistributedDataParallel(model, device_ids=[gpu])` and :250 `torch.optim.Adam(params, lr, weight_decay, betas)` — with the same
+# constructors and the same behaviour towards that loop.  Swapping the two names in main_utils.py is the whole change.
+class _WrapperEngine(TrainStep):
+    """TrainStep's flat buffers / buckets / launch-program hand-over without its criterion and optimizer: what runs under
+    `DistributedDataParallel.forward` and the `loss.backward()` the caller issues later."""
+
+    def __init__(self, model, bucket_bytes, broadcast_buffers):
+        super().__init__(model, None, bucket_bytes=bucket_bytes, broadcast_buffers="step" if broadcast_buffers else "off",
+                         _wrapper=True)
+        self._armed = False
+        self.buckets.on_autograd = self._arm
+
+    def _arm(self):
+        """Once per backward pass: when autograd has run every node, finish the collectives (the caller's stream waits for
+        them) and give every parameter its `.grad` — torch's reducer queues the same callback (reducer.cpp: finalize_backward)."""
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._after_backward)
+
+    def _after_backward(self):
+        self._armed = False
+        self.buckets.finish()
+        self.flat.seat_grads()
+
+    def _plan_backward(self, pl, fa, video, audio, dv, da):
+        self._arm()
+        super()._plan_backward(pl, fa, video, audio, dv, da)
+
+
+class DistributedDataParallel(torch.nn.Module):
+    """`torch.nn.parallel.DistributedDataParallel(module, device_ids=[gpu])` as utils/main_utils.py:112 builds it, for one
+    process per GPU: `.module`, `module.`-prefixed state_dict keys (main-avid.py:100, CheckpointManager), rank 0's parameters and
+    buffers broadcast at construction, rank 0's buffers before every training forward (`broadcast_buffers=True`: ONE 78 KB
+    collective), and after `loss.backward()` every `p.grad` holds the mean over ranks.  Underneath: the parameters and
+    gradients are views of flat buffers, the backward launch program writes the gradients in place, the buckets' all-reduces
+    (RCCL, mean) start under the rest of the backward pass on the collectives' stream — no per-parameter copy kernel in either
+    direction (torch's reducer: 141 `mul_out` + 141 copies back per step, 1.1 ms of the 12.3 ms step on one rank).
+
+    Not reproduced: `no_sync()` / gradient accumulation over several backward passes, `find_unused_parameters`, comm hooks —
+    the reference uses none of them; asking for one raises."""
+
+    def __init__(self, module, device_ids=None, output_device=None, dim=0, broadcast_buffers=True, process_group=None,
+                 bucket_cap_mb=None, find_unused_parameters=False, gradient_as_bucket_view=False, **unsupported):
+        super().__init__()
+        if unsupported or find_unused_parameters or process_group is not None:
+            raise NotImplementedError("avid_hip.parallel.DistributedDataParallel: unsupported argument(s) "
+                                      f"{sorted(unsupported) or ['find_unused_parameters / process_group']}")
+        if device_ids is not None and len(device_ids) != 1:
+            raise ValueError("one process per GPU: device_ids must name one device")
+        self.module = module
+        self.device_ids = device_ids
+        self.broadcast_buffers = bool(broadcast_buffers)
+        cap = int((bucket_cap_mb if bucket_cap_mb is not None else 16) * (1 << 20))
+        self._engine = _WrapperEngine(module, cap, self.broadcast_buffers)
+
+    def forward(self, *inputs, **kwargs):
+        if not (self.training and torch.is_grad_enabled()):
+            return self.module(*inputs, **kwargs)
+        from . import plan
+        eng = self._engine
+        if eng.broadcast_buffers == "step":
+            eng.sync_buffers()
+        with plan.engine(eng):
+            return self.module(*inputs, **kwargs)
+
+    def no_sync(self):
+        raise NotImplementedError("avid_hip.parallel.DistributedDataParallel: no_sync() (gradient accumulation) is not reproduced")
+
+
+class Adam(torch.optim.Optimizer):
+    """`torch.optim.Adam(params, lr, betas, eps, weight_decay)` (utils/main_utils.py:250-256; L2 weight decay, no amsgrad) whose
+    `step()` is ONE launch over the flat parameter / gradient / moment buffers.  A `torch.optim.Optimizer`: `param_groups`
+    (MultiStepLR writes `lr` there, utils/main_utils.py:258), `state_dict()` / `load_state_dict()` in torch.optim.Adam's own
+    format (`state[i] = {step, exp_avg, exp_avg_sq}`), so checkpoints written by either load into the other.
+
+    The parameters are used where they lie if they already are the views of one flat buffer (the model went through
+    `DistributedDataParallel` above or `TrainStep`), otherwise they are re-seated into one here.  One parameter group."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **unsupported):
+        if amsgrad or any(unsupported.get(k) for k in ("maximize", "capturable", "differentiable")):
+            raise NotImplementedError("avid_hip.parallel.Adam: amsgrad / maximize / capturable / differentiable")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False))
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("avid_hip.parallel.Adam: one parameter group")
+        ps = self.param_groups[0]["params"]
+        self.flat = flat_of(ps) or FlatParams(ps)
+        self.m = torch.zeros_like(self.flat.flat)
+        self.v = torch.zeros_like(self.flat.flat)
+        self._t = 0
+        self._step_t = torch.tensor(0.0)
+
+    def _views(self, i):
+        p, o = self.flat.params[i], self.flat.offsets[i]
+        return (self.m[o:o + p.numel()].as_strided(p.shape, p.stride()), self.v[o:o + p.numel()].as_strided(p.shape, p.stride()))
+
+    def _publish_state(self):
+        """`self.state` in torch.optim.Adam's shape: views of the flat moments, one shared step tensor."""
+        if self.state:
+            return
+        for i, p in enumerate(self.flat.params):
+            m, v = self._views(i)
+            self.state[p] = {"step": self._step_t, "exp_avg": m, "exp_avg_sq": v}
+
+    def zero_grad(self, set_to_none=True):
+        """One fill of the flat gradient buffer; `.grad` stays seated (a launch program writes the buffer, not the attribute)."""
+        self.flat.grad.zero_()
+        self.flat.seat_grads()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        from . import ops
+        g = self.param_groups[0]
+        p0 = self.flat.params[0]
+        if p0.data_ptr() != self.flat.flat.data_ptr() + 4 * self.flat.offsets[0]:
+            raise RuntimeError("avid_hip.parallel.Adam: the parameters were moved after the optimizer was built (model.cuda() / a "
+                               "wrapper constructed later): build the optimizer last, as main-avid.py:95-108 does")
+        self.flat.seat_grads()
+        self._t += 1
+        self._step_t.fill_(float(self._t))
+        ops.adam_flat(self.flat.flat, self.flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                      g["weight_decay"], self._t)
+        self._publish_state()
+        return loss
+
+    def state_dict(self):
+        if self._t > 0:
+            self._publish_state()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)              # (torch: casts, re-keys by parameter, replaces self.state)
+        self.m.zero_()
+        self.v.zero_()
+        step = 0
+        for i, p in enumerate(self.flat.params):
+            st = self.state.get(p)
+            if not st:
+                continue
+            m, v = self._views(i)
+            m.copy_(st["exp_avg"])
+            v.copy_(st["exp_avg_sq"])
+            step = max(step, int(float(st["step"])))
+        self._t = step
+        self._step_t = torch.tensor(float(step))
+        self.state.clear()
+        if step > 0:
+            self._publish_state()

@@ -758,6 +758,9 @@ class NetFn(torch.autograd.Function):
         ve, ae, fa = pl.forward(video, audio, gflat, zero_grad=gflat is not None)
         ctx.pl, ctx.fa, ctx.video, ctx.audio = pl, fa, video, audio
         ctx.in_engine = gflat is not None
+        # the engine of THIS forward pass: the reference's loop calls loss.backward() itself, outside any `with plan.engine`
+        # (parallel.DistributedDataParallel), and the gradients still have to land in the flat buffer this forward zeroed
+        ctx.eng = eng if gflat is not None else None
         ctx.versions = sum(p._version for p in params)
         ctx.params = params
         return ve, ae
@@ -771,8 +774,8 @@ class NetFn(torch.autograd.Function):
         if sum(p._version for p in params) != ctx.versions:
             raise RuntimeError("avid_hip.plan: a parameter was modified in place between the forward and the backward pass")
         dv, da = dv.contiguous(), da.contiguous()
-        eng = _ENGINE
-        gflat = _engine_flat(eng, pl) if (eng is not None and ctx.in_engine) else None
+        eng = ctx.eng
+        gflat = _engine_flat(eng, pl) if eng is not None else None
         if gflat is not None:
             eng._plan_backward(pl, ctx.fa, ctx.video, ctx.audio, dv, da)
             ctx.fa = None

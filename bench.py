@@ -235,12 +235,18 @@ def extra_configs(engine, model, video, audio, dev, lib, steps=10, warmup=3):
     return res
 
 
-def reference_loop(model, crit, video, audio, ids, dev, steps=10, warmup=4):
+def reference_loop(model, crit, video, audio, ids, dev, steps=30, warmup=6, dropin=False):
     """clips/s of the REFERENCE's loop shape on the same kernels (main-avid.py:155-180, utils/main_utils.py:112,250):
     torch DistributedDataParallel around the model (one-rank group), torch.optim.Adam, and the host synchronisation
     ``loss.item()`` between the criterion and ``zero_grad / backward / step`` — what a user of the unmodified driver gets,
-    against ``TrainStep`` (flat buffers, fused Adam, gradients written in place, helper streams, no host sync)."""
-    from torch.nn.parallel import DistributedDataParallel
+    against ``TrainStep`` (flat buffers, fused Adam, gradients written in place, helper streams, no host sync).
+    ``dropin``: the SAME loop with the two objects the reference's factories build swapped for this build's
+    (utils/main_utils.py:112 -> avid_hip.parallel.DistributedDataParallel, :250 -> avid_hip.parallel.Adam)."""
+    if dropin:
+        from avid_hip.parallel import DistributedDataParallel, Adam
+    else:
+        from torch.nn.parallel import DistributedDataParallel
+        Adam = torch.optim.Adam
     own_group = not dist.is_initialized()
     if own_group:
         import socket
@@ -251,9 +257,13 @@ def reference_loop(model, crit, video, audio, ids, dev, steps=10, warmup=4):
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     overlap, model.overlap_towers = model.overlap_towers, False      # (DDP's reducer knows one stream)
+    # like for like: torch's reducer all-reduces its buckets on a one-rank group too, so the drop-in is made to (AVID_FORCE_DIST)
+    force = os.environ.get("AVID_FORCE_DIST")
+    if dropin:
+        os.environ["AVID_FORCE_DIST"] = "1"
     try:
         ddp = DistributedDataParallel(model, device_ids=[dev.index])
-        opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-5)
+        opt = Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-5)
 
         def one(i):
             v, a = ddp(video, audio)
@@ -274,10 +284,16 @@ def reference_loop(model, crit, video, audio, ids, dev, steps=10, warmup=4):
         del ddp, opt
     finally:
         model.overlap_towers = overlap
+        if dropin:
+            os.environ.pop("AVID_FORCE_DIST", None)
+            if force is not None:
+                os.environ["AVID_FORCE_DIST"] = force
         if own_group:
             dist.destroy_process_group()
     return {"clips_s": round(video.shape[0] * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
-            "what": "torch DDP (1 rank) + torch.optim.Adam + loss.item() per step, same model / criterion kernels"}
+            "what": ("avid_hip.parallel.DistributedDataParallel (1 rank) + avid_hip.parallel.Adam + loss.item() per step: the "
+                     "reference's loop, its two factory lines swapped") if dropin else
+                    "torch DDP (1 rank) + torch.optim.Adam + loss.item() per step, same model / criterion kernels"}
 
 
 def forward_roofline(model, video, lib, reps=3):
@@ -650,6 +666,13 @@ def main():
             except Exception as e:                          # noqa: BLE001
                 ref = {"error": repr(e)[:300]}
             out["extra"]["reference_loop"] = ref
+            # (last: the wrapper re-seats the parameters in flat buffers of its own — `engine` is not used after this)
+            try:
+                ref = reference_loop(model, crit, video, audio, ids, dev, dropin=True)
+                ref["vs_trainstep"] = round(ref["clips_s"] / clips, 3)
+            except Exception as e:                          # noqa: BLE001
+                ref = {"error": repr(e)[:300]}
+            out["extra"]["reference_loop_dropin"] = ref
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

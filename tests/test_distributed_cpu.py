@@ -240,3 +240,70 @@ def test_optimizer_state_dict_indexes_all_parameters_like_torch_adam():
         i = {id(p): j for j, p in enumerate(eng2.flat.params)}[id(params[k])]
         assert torch.equal(eng2._slice(eng2.m, i), st["exp_avg"]) and torch.equal(eng2._slice(eng2.v, i), st["exp_avg_sq"])
     assert eng2.t == 1
+
+
+def _wrapper_job(rank, world):
+    """The reference's loop (main-avid.py:175-178: zero_grad, backward, step) on two ranks, once with torch's
+    DistributedDataParallel and once with avid_hip.parallel.DistributedDataParallel (utils/main_utils.py:112), torch.optim.SGD
+    either way; per-rank batches, ranks start from different weights."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avid-cma_amd"))
+    from avid_hip import parallel
+    out = {}
+    for name, wrap in (("torch", torch.nn.parallel.DistributedDataParallel),
+                       ("ours", lambda m: parallel.DistributedDataParallel(m, bucket_cap_mb=256 / (1 << 20)))):
+        torch.manual_seed(1000 + rank)
+        m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 16),
+                                torch.nn.ReLU(), torch.nn.Linear(16, 4))
+        m[1].running_mean.fill_(float(rank + 1))
+        net = wrap(m)
+        opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+        torch.manual_seed(100 + rank)
+        seated = []
+        for _ in range(3):
+            x = torch.randn(6, 8) * (1 + rank)
+            loss = net(x).pow(2).sum()
+            opt.zero_grad()                               # (set_to_none: `.grad` is None when the backward pass starts)
+            loss.backward()
+            seated.append(all(p.grad is not None for p in m.parameters()))
+            opt.step()
+        out[name] = ([p.detach().clone().numpy() for p in m.parameters()], m[1].running_mean.clone().numpy(),
+                     sorted(net.state_dict()), seated)
+        if name == "ours":
+            out["buckets"] = len(net._engine.buckets.bounds)
+            out["module_is"] = net.module is m
+    return out
+
+
+def test_dropin_ddp_equals_torch_ddp_on_two_ranks():
+    res = run2(_wrapper_job)
+    for rank in range(2):
+        r = res[rank]
+        assert r["buckets"] >= 3 and r["module_is"]
+        assert all(r["ours"][3]), "a parameter had no .grad after backward()"
+        assert r["ours"][2] == r["torch"][2] and all(k.startswith("module.") for k in r["ours"][2])
+        for a, b in zip(r["ours"][0], r["torch"][0]):
+            torch.testing.assert_close(torch.from_numpy(a), torch.from_numpy(b), rtol=1e-5, atol=1e-6)
+    for a, b in zip(res[0]["ours"][0], res[1]["ours"][0]):
+        assert (a == b).all()                               # the ranks stay in lock step
+    # buffers: rank 1 follows rank 0's running statistics (broadcast before every training forward), as under torch's
+    torch.testing.assert_close(torch.from_numpy(res[1]["ours"][1]), torch.from_numpy(res[1]["torch"][1]), rtol=1e-5, atol=1e-6)
+
+
+def test_dropin_ddp_refuses_what_it_does_not_reproduce():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avid-cma_amd"))
+    from avid_hip import parallel
+    m = _tiny_model()
+    with pytest.raises(NotImplementedError):
+        parallel.DistributedDataParallel(m, find_unused_parameters=True)
+    with pytest.raises(NotImplementedError):
+        parallel.DistributedDataParallel(m, static_graph=True)
+    net = parallel.DistributedDataParallel(m)
+    with pytest.raises(NotImplementedError):
+        net.no_sync()
+    assert net.module is m and not list(net._engine.buckets.works)
+    # eval / no_grad calls go straight to the module
+    net.eval()
+    with torch.no_grad():
+        assert net(torch.zeros(2, 8)).shape == (2, 4)

@@ -233,11 +233,54 @@ def _ddp_job(rank, world, out):
                          for n, b in m.named_buffers() if b.is_floating_point())}
 
 
+def _dropin_job(rank, world, out):
+    """main-avid.py:169-178 on two ranks with avid_hip.parallel.DistributedDataParallel + avid_hip.parallel.Adam (utils/main_utils.py:112,
+    :250), against TrainStep on the same two ranks: the wrapper leaves the MEAN in `.grad` (sum, then / world: exact for two
+    ranks) where the engine folds 1 / world into its Adam launch — the same numbers reach the same kernel."""
+    from avid_hip import parallel
+    dev = torch.device("cuda", 0)
+    video, audio = _inputs()
+    v = video[rank * BS:(rank + 1) * BS].to(dev)
+    a = audio[rank * BS:(rank + 1) * BS].to(dev)
+    res = {}
+    for which in ("engine", "dropin"):
+        m = _model(dev)
+        if rank == 1:
+            with torch.no_grad():
+                m.video_model.conv1[0].weight.add_(1.0)
+        crit = _criterion(dev, rank)
+        _set_banks(crit, rank)
+        losses = []
+        if which == "engine":
+            eng = parallel.TrainStep(m, crit, bucket_bytes=4 << 20)
+            for ids in IDS:
+                y = torch.tensor(ids[rank * BS:(rank + 1) * BS], dtype=torch.int64, device=dev)
+                losses.append(float(eng.step(v, a, y)))
+        else:
+            net = parallel.DistributedDataParallel(m, device_ids=[0], bucket_cap_mb=4)
+            opt = parallel.Adam(net.parameters(), lr=2e-4, weight_decay=1e-5, betas=[0.9, 0.999])
+            res["nbuckets"] = len(net._engine.buckets.bounds)
+            res["comm"] = bool(net._engine.buckets.comm)
+            for ids in IDS:
+                y = torch.tensor(ids[rank * BS:(rank + 1) * BS], dtype=torch.int64, device=dev)
+                ve, ae = net(v, a)
+                loss, _ = crit(ve, ae, y)
+                losses.append(loss.item())
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            res["program"] = bool([p for p in m.__dict__.get("_avid_plans", {}).values() if p])
+        torch.cuda.synchronize()
+        res[which] = (losses, {k: t.clone().cpu() for k, t in m.state_dict().items()},
+                      (crit.nce_average.view1_mem.clone().cpu(), crit.nce_average.view2_mem.clone().cpu()))
+    return res
+
+
 def _train_job_per_layer(rank, world, out):
     return _train_job(rank, world, out, per_layer=True)
 
 
-_JOBS = {"train": _train_job, "train_pl": _train_job_per_layer, "cma": _cma_job, "ddp": _ddp_job}
+_JOBS = {"train": _train_job, "train_pl": _train_job_per_layer, "cma": _cma_job, "ddp": _ddp_job, "dropin": _dropin_job}
 
 
 def _worker(rank, world, port, out, job):
@@ -412,3 +455,20 @@ def test_two_rank_cma_search_and_step(tmp_path, gpu_device):
     for b in range(2):
         assert torch.equal(r[0]["banks"][b], r[1]["banks"][b])
     assert not torch.equal(r[0]["banks"][0][17], _det_bank("twocma:v1", N)[17])
+
+
+def test_two_rank_reference_loop_with_the_dropin_objects(tmp_path, gpu_device):
+    """The reference's loop with its two factory lines swapped, on two ranks: losses, parameters, BatchNorm buffers and banks
+    of every rank equal TrainStep's on the same ranks bit for bit; the ranks' parameters stay equal to each other."""
+    r = _run2("dropin", tmp_path)
+    for rank in range(2):
+        assert r[rank]["comm"] and r[rank]["nbuckets"] >= 3 and r[rank]["program"]
+        le, sde, be = r[rank]["engine"]
+        ld, sdd, bd = r[rank]["dropin"]
+        assert ld == le
+        for k in sde:
+            assert torch.equal(sde[k], sdd[k]), (rank, k)
+        assert torch.equal(be[0], bd[0]) and torch.equal(be[1], bd[1])
+    names = [k for k, _ in r[0]["dropin"][1].items() if "running" not in k and "num_batches" not in k and k != "_bn_flat"]
+    for k in names:
+        assert torch.equal(r[0]["dropin"][1][k], r[1]["dropin"][1][k]), k
