@@ -441,6 +441,15 @@ __device__ __forceinline__ void w2_split8(const floatx4& v0, const floatx4& v1, 
   fm = __builtin_bit_cast(w2_bf16x8, w2_uintx4{m[0], m[1], m[2], m[3]});
   fl = __builtin_bit_cast(w2_bf16x8, w2_uintx4{l[0], l[1], l[2], l[3]});
 }
+typedef unsigned uintx2_t __attribute__((ext_vector_type(2)));
+// (the split of wino2p_kernel's transform threads; -DAVID_W2P_DOT: the v_dot2c form)
+__device__ __forceinline__ void w2p_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#ifdef AVID_W2P_DOT
+  split2_bf16_dot(x0, x1, h, m, l);
+#else
+  split2_bf16(x0, x1, h, m, l);
+#endif
+}
 constexpr int W2_STAGE = 16 * W2_TB * W2_CK;                 // floats per stage
 constexpr int W2_TAB_OFF = 2 * W2_STAGE;                     // three tile tables of 64 x int4
 constexpr int W2_LDS_FLOATS = W2_TAB_OFF + 3 * W2_TB * 4;
@@ -836,6 +845,394 @@ __global__ __launch_bounds__(256) void wino2_kernel(const WinoArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// wino2p_kernel (round 5): wino2_kernel with V split ONCE, by the thread that transforms it, and kept in LDS as the three bf16
+// planes the products read.  In wino2_kernel every wave splits the V fragment of every transform point it multiplies — the two
+// waves of a tile half split the same 8 values per lane: 36 vector instructions beside 6 matrix instructions, 16 times per chunk,
+// as long as the products themselves.  Here the transform thread (tile, 4 channels) splits its two channel pairs per
+// transform point (18 instructions, 288 per chunk instead of 576) and a product step reads its fragment with three ds_read_b128.
+//   LDS: V as bf16 planes is 6 B per element: a chunk (16 points x 64 tiles x 16 channels) takes 96 KB, two do not fit.  The
+//   stage is cut in HALVES of 8 transform points (48 KB) in a ring of three: while half g is multiplied the transform writes
+//   half g + 2 (the same half of the next chunk: rows 0-1 of the 4 x 4 transform with the first half, rows 2-3 with the second)
+//   into the third buffer; one barrier per half says "everybody is done reading g" (g + 3 will overwrite it) — reading g + 1,
+//   complete since the barrier before, may start in front of it, so the fragment prefetch runs across the barriers.
+//     half-stage [point 8][hi | mid | lo][tile 64][16 channels bf16 = 32 B], the two 16-byte halves of a row swapped on tiles
+//     with bit 3 set: the fragment reads (16 lanes = 16 tiles x 16 B, row pitch 32 B) and the transform's 8-byte stores
+//     (4 threads per tile) each cover the 64 banks once.
+//   Schedule of a chunk: column pass at point 0, ONE point transformed, split and stored per product step, the patch loads of
+//   the chunk after the next at points 2-7 (the raw rows are dead after the column pass); a unit's first chunk loads the next
+//   chunk's patch at points 0-3 and transforms two points per step in its second half, as wino2_kernel does.
+//   Output phase: the exchange buffer is the ring's dead buffer (48 KB; the other two hold the next unit's first chunk), so
+//   Y goes through it in two passes of two output pixels (8 KB per wave), the second pair waiting in registers.
+constexpr int W2P_HS = 8 * 3 * W2_TB * 32;                 // bytes of a half-stage
+constexpr int W2P_TAB_OFF = 3 * W2P_HS;                    // bytes: three tile tables of 64 x int4 behind the ring
+constexpr int W2P_LDS_BYTES = W2P_TAB_OFF + 3 * W2_TB * 16;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void wino2p_kernel(const WinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  char* smb = reinterpret_cast<char*>(sm);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int th = wave & 1, nh = wave >> 1;
+  const int H = p.H, W = p.W, TW = p.TW, TPF = p.TH * p.TW, Cr = p.Cr, Cn = p.Cn;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)((long long)p.F * H * W * Cr * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, 16 * Cn * Cr * 6, 0x00020000);
+  const int dbytes = (int)((long long)p.F * H * W * Cn * 4);
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst, 0, dbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI & 2) ? p.addend : p.src), 0, (EPI & 2) ? dbytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI & 4) ? p.bnb_x : p.src), 0, (EPI & 4) ? dbytes : 0, 0x00020000);
+  const int nchunks = Cr / W2_CK;
+  // unit order: see wino_kernel
+  const bool xl = p.xcd_local && gridDim.x % (8 * p.ncb) == 0;
+  const int lid = xl ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int cb = lid % p.ncb, q = lid / p.ncb, Gq = (int)gridDim.x / p.ncb;
+  const int nblk = p.units / p.ncb;
+  const int fullq = xl ? nblk / Gq * Gq : nblk;
+  const int qlast = fullq + (q % (Gq / 8)) * 8 + q / (Gq / 8);
+  auto blk_after = [&](int blk) {
+    if (blk >= fullq) return nblk;
+    const int nx = blk + Gq;
+    return nx < fullq ? nx : qlast;
+  };
+  const int blk0 = q < fullq ? q : (xl ? qlast : q);
+  int4* tabs = reinterpret_cast<int4*>(smb + W2P_TAB_OFF);
+  auto fill_tab = [&](int blk, int buf) {
+    if (tid < W2_TB) {
+      const long long t = (long long)blk * W2_TB + tid;
+      int4 e = {-1, 0, 0, 0};
+      if (blk < nblk && t < p.ntiles) {
+        const int f = (int)(t / TPF), rem = (int)(t - (long long)f * TPF);
+        e.x = f; e.y = rem / TW; e.z = rem - e.y * TW;
+      }
+      tabs[buf * W2_TB + tid] = e;
+    }
+  };
+  // ---- this thread's item of the input transform: tile tt, channels c4 .. c4 + 3 of the chunk
+  const int tt = tid >> 2, cq = tid & 3, c4 = cq * 4;
+  const unsigned px_b = (unsigned)Cr * 4u, row_b = (unsigned)W * px_b;
+  floatx4 raw[4][4];
+  unsigned ld_o11 = 0;
+  bool ld_oky[4] = {false, false, false, false}, ld_okx[4] = {false, true, false, false};
+  int ld_ck = 0, ld_buf = 0;
+  auto ld_unit = [&](int buf) {
+    const int4 e = tabs[buf * W2_TB + tt];
+    const bool t_ok = e.x >= 0;
+    const int y1 = 2 * e.y, x1 = 2 * e.z;
+    ld_o11 = (unsigned)(((e.x * H + y1) * W + x1) * Cr + c4) * 4u;
+    ld_oky[0] = t_ok && e.y > 0; ld_oky[1] = t_ok; ld_oky[2] = t_ok && y1 + 1 < H; ld_oky[3] = t_ok && y1 + 2 < H;
+    ld_okx[0] = e.z > 0; ld_okx[1] = true; ld_okx[2] = x1 + 1 < W; ld_okx[3] = x1 + 2 < W;
+  };
+  auto ld_issue = [&](int a, int b) {
+    const unsigned rowoff = ld_o11 + (unsigned)(a - 1) * row_b;
+    raw[a][b] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                rsX, (ld_oky[a] && ld_okx[b]) ? (b == 0 ? rowoff - px_b : rowoff) : 0x80000000u,
+                                                ld_ck * (W2_CK * 4) + (b == 0 ? 0 : (b - 1) * (int)px_b), 0));
+  };
+  auto ld_advance = [&]() {
+    if (++ld_ck == nchunks) {
+      ld_ck = 0;
+      ld_buf = ld_buf == 2 ? 0 : ld_buf + 1;
+      ld_unit(ld_buf);
+    }
+  };
+  floatx4 w_[4][4];
+  auto col_pass = [&]() {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      w_[0][b] = pk4_sub(raw[0][b], raw[2][b]);
+      w_[1][b] = pk4_add(raw[1][b], raw[2][b]);
+      w_[2][b] = pk4_sub(raw[2][b], raw[1][b]);
+      w_[3][b] = pk4_sub(raw[1][b], raw[3][b]);
+    }
+  };
+  // transform point xi (row a = xi >> 2 of the column pass, column j = xi & 3), split, three 8-byte stores
+  const int wr_off = tt * 32 + (((cq >> 1) ^ ((tt >> 3) & 1)) << 4) + ((cq & 1) << 3);
+  auto point = [&](char* Wb, int xi) {
+    const int a = xi >> 2, j = xi & 3;
+    const floatx4 v = j == 0 ? pk4_sub(w_[a][0], w_[a][2]) : j == 1 ? pk4_add(w_[a][1], w_[a][2])
+                    : j == 2 ? pk4_sub(w_[a][2], w_[a][1]) : pk4_sub(w_[a][1], w_[a][3]);
+    unsigned h0, m0, l0, h1, m1, l1;
+    w2p_split2(v[0], v[1], h0, m0, l0);
+    w2p_split2(v[2], v[3], h1, m1, l1);
+    char* dst = Wb + wr_off + (xi & 7) * (3 * W2_TB * 32);
+    *reinterpret_cast<uintx2_t*>(dst) = uintx2_t{h0, h1};
+    *reinterpret_cast<uintx2_t*>(dst + W2_TB * 32) = uintx2_t{m0, m1};
+    *reinterpret_cast<uintx2_t*>(dst + 2 * W2_TB * 32) = uintx2_t{l0, l1};
+  };
+  // ---- products: operands
+  const int ptile = 32 * th + l31;
+  const int rd_off = ptile * 32 + ((h ^ ((ptile >> 3) & 1)) << 4);
+  const unsigned u_voff = (unsigned)(lane * 16);
+  const int u_xi = Cn * Cr * 6;
+  const int u_ck = 3 * 1024;
+  const int u_base = __builtin_amdgcn_readfirstlane((cb * 2 + nh) * nchunks * u_ck);
+  floatx4 bv[4][3];
+  auto load_u = [&](int slot, int xi, int ck) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      bv[slot][q] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsU, u_voff + 1024u * q, u_base + xi * u_xi + ck * u_ck, 0));
+  };
+  w2_bf16x8 vs[2][3];
+  auto read_v = [&](const char* Vb, int slot, int xi8) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      vs[slot][t] = *reinterpret_cast<const w2_bf16x8*>(Vb + rd_off + (xi8 * 3 + t) * (W2_TB * 32));
+  };
+  floatx16 acc[16];
+
+#if AVID_W2_STAGGER
+  {
+    int mine = 0;
+    for (int b = blk0; b < nblk; b = blk_after(b)) ++mine;
+    const int most = (nblk + Gq - 1) / Gq;
+    if (mine < most) {
+      const int steps = ((lid * 5) & 7) * nchunks / 8 * AVID_W2_STAGGER;
+      for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
+#endif
+  // ---- prologue: the first unit's first chunk into ring buffers 0 and 1
+  fill_tab(blk0, 0);
+  fill_tab(blk_after(blk0), 1);
+  __syncthreads();
+  ld_unit(0);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) ld_issue(a, b);
+  ld_advance();
+  col_pass();
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) point(smb + (xi >> 3) * W2P_HS, xi);
+  load_u(0, 0, 0);
+  load_u(1, 1, 0);
+  load_u(2, 2, 0);
+  int rb = 0;                                     // ring buffer of the current chunk's first half
+
+  auto chunk = [&](auto first_tag, int ck) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int ck_n = ck + 1 < nchunks ? ck + 1 : 0;
+    const bool last = !FIRST && ck + 1 == nchunks;
+    const int b1 = rb == 2 ? 0 : rb + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+    const char* R0 = smb + rb * W2P_HS;           // halves of this chunk
+    const char* R1 = smb + b1 * W2P_HS;
+    char* W0 = smb + b2 * W2P_HS;                 // halves of the next chunk: the free buffer, then this chunk's first half
+    char* W1 = smb + rb * W2P_HS;
+    if (FIRST) read_v(R0, 0, 0);                  // (otherwise the previous chunk's last step has asked for it)
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+      if (!(W2_DBG & 4)) { if (xi + 3 < 16) load_u((xi + 3) & 3, xi + 3, ck); else load_u((xi + 3) & 3, xi + 3 - 16, ck_n); }
+      // the fragment of the next point: this chunk's, or — complete since the barrier in the middle of this chunk — the next chunk's
+      // first (not across the output phase)
+      if (!(W2_DBG & 16)) {
+        if (xi + 1 < 16) read_v(xi + 1 < 8 ? R0 : R1, (xi + 1) & 1, (xi + 1) & 7);
+        else if (!last) read_v(W0, 0, 0);
+      }
+      if (FIRST) {
+        if (xi < 4 && !(W2_DBG & 2)) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) ld_issue(xi, b);
+          if (xi == 3) ld_advance();
+        }
+        if (xi == 8 && !(W2_DBG & 1)) col_pass();
+        if (xi >= 8 && !(W2_DBG & 1)) {
+          point(xi < 12 ? W0 : W1, 2 * (xi - 8));
+          point(xi < 12 ? W0 : W1, 2 * (xi - 8) + 1);
+        }
+        if (xi >= 10 && !(W2_DBG & 2)) {
+          const int j = xi - 10;                 // 3, 3, 3, 3, 2, 2 loads
+          const int n = j < 4 ? 3 : 2, base = j < 4 ? j * 3 : 12 + (j - 4) * 2;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (k < n) ld_issue((base + k) >> 2, (base + k) & 3);
+          if (j == 5) ld_advance();
+        }
+      } else {
+        if (xi == 0 && !(W2_DBG & 1)) col_pass();
+        if (!(W2_DBG & 1)) point(xi < 8 ? W0 : W1, xi);
+        if (xi >= 2 && xi < 8 && !last && !(W2_DBG & 2)) {
+          const int j = xi - 2;
+          const int n = j < 4 ? 3 : 2, base = j < 4 ? j * 3 : 12 + (j - 4) * 2;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (k < n) ld_issue((base + k) >> 2, (base + k) & 3);
+          if (j == 5) ld_advance();
+        }
+      }
+      const w2_bf16x8 uh = __builtin_bit_cast(w2_bf16x8, bv[xi & 3][0]), um = __builtin_bit_cast(w2_bf16x8, bv[xi & 3][1]),
+                      ul = __builtin_bit_cast(w2_bf16x8, bv[xi & 3][2]);
+      const w2_bf16x8 vh = vs[xi & 1][0], vm = vs[xi & 1][1], vl = vs[xi & 1][2];
+      if (FIRST) {
+        const floatx16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vl, z16, 0, 0, 0);
+      } else {
+        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vl, acc[xi], 0, 0, 0);
+      }
+      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, vh, acc[xi], 0, 0, 0);
+      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vm, acc[xi], 0, 0, 0);
+      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vm, acc[xi], 0, 0, 0);
+      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(um, vh, acc[xi], 0, 0, 0);
+      acc[xi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, vh, acc[xi], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if ((xi == 7 || xi == 15) && !(W2_DBG & 32)) __syncthreads();    // everybody is done reading this half: the next half's transform writes over it
+    }
+    rb = b2;
+  };
+
+  // ---- output phase (see wino2_kernel), the exchange buffer in the ring's dead buffer, two output pixels per pass
+  const int xw_row = l31 * 32, xw_sw = l31 & 7;
+  const int t8 = lane >> 3, slot = lane & 7;
+  const int xr_off = t8 * 32 + ((slot ^ t8) << 2);
+  const int ccol = cb * 64 + nh * 32 + 4 * slot;
+  floatx4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, bis = bsc;
+  if (EPI & 4) {
+    bsc = *reinterpret_cast<const floatx4*>(p.bnb_scale + ccol); bsh = *reinterpret_cast<const floatx4*>(p.bnb_shift + ccol);
+    bmu = *reinterpret_cast<const floatx4*>(p.bnb_mean + ccol); bis = *reinterpret_cast<const floatx4*>(p.bnb_invstd + ccol);
+  }
+  floatx4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  const int pix_b[4] = {0, Cn * 4, W * Cn * 4, (W + 1) * Cn * 4};
+
+  int ubuf = 0;
+  for (int blk = blk0; blk < nblk; blk = blk_after(blk)) {
+    __syncthreads();
+    fill_tab(blk_after(blk_after(blk)), ubuf == 0 ? 2 : ubuf - 1);
+    chunk(std::true_type{}, 0);
+    for (int ck = 1; ck < nchunks; ++ck) chunk(std::false_type{}, ck);
+    // (the barrier behind the last half: every wave is done with it — rb now names the buffer the NEXT chunk's first half sits in,
+    //  the one before it in the ring is the dead one)
+    float* xch = reinterpret_cast<float*>(smb + (rb == 0 ? 2 : rb - 1) * W2P_HS) + wave * 2048;
+    unsigned voff[4];
+    int okm = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int4 te = tabs[ubuf * W2_TB + 32 * th + 8 * k + t8];
+      const int y0 = 2 * te.y, x0 = 2 * te.z;
+      const bool tok = te.x >= 0, okx = x0 + 1 < W, oky = y0 + 1 < H;
+      voff[k] = (unsigned)((((te.x * H + y0) * W + x0) * Cn + ccol) * 4);
+      okm |= ((tok ? 1 : 0) | (tok && okx ? 2 : 0) | (tok && oky ? 4 : 0) | (tok && okx && oky ? 8 : 0)) << (4 * k);
+    }
+    ubuf = ubuf == 2 ? 0 : ubuf + 1;
+    if (W2_DBG & 8) {                 // (timing experiment: no output transform, every accumulator stored once)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const floatx4 v = floatx4{acc[x][4 * (x & 3)], acc[x][4 * (x & 3) + 1], acc[x][4 * (x & 3) + 2], acc[x][4 * (x & 3) + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, v), rsD, (okm & 1) ? voff[0] : 0x80000000u, (x & 3) * 32, 0);
+        asm volatile("s_nop 1" : : "v"(v));
+      }
+      continue;
+    }
+    // the epilogue's inputs (BatchNorm input of the backward sums, addend), two output pixels at a time like the exchange: the
+    // first pair is requested before / behind the output transform, the second pair as the first pair's registers come free
+    floatx4 xb[2][4], ad[2][4];
+    auto epi_off = [&](int k, int pq) { return ((okm >> (4 * k + pq)) & 1) ? voff[k] : 0x80000000u; };
+    auto load_xb = [&](int pq) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        xb[pq & 1][k] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, epi_off(k, pq), pix_b[pq], 0));
+    };
+    auto load_ad = [&](int pq) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        ad[pq & 1][k] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, epi_off(k, pq), pix_b[pq], 0));
+    };
+    if (EPI & 4) { load_xb(0); load_xb(1); }
+    floatx4 low[4][2];                 // output row 1 (pixels 2, 3) of every channel group: the second pass
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      floatx4 T[4][2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        floatx4 M[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float t_;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t_) : "a"(acc[4 * a + b][4 * g + i]));
+            M[b][i] = t_;
+          }
+        T[a][0] = pk4_add(pk4_add(M[0], M[1]), M[2]);
+        T[a][1] = pk4_sub(pk4_sub(M[1], M[2]), M[3]);
+      }
+      float* wp = xch + xw_row + (((2 * g + h) ^ xw_sw) << 2);
+#pragma unroll
+      for (int qo = 0; qo < 2; ++qo) {
+        *reinterpret_cast<floatx4*>(wp + qo * 1024) = pk4_add(pk4_add(T[0][qo], T[1][qo]), T[2][qo]);
+        low[g][qo] = pk4_sub(pk4_sub(T[1][qo], T[2][qo]), T[3][qo]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (EPI & 2) { load_ad(0); load_ad(1); }
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+      if (pq == 2) {      // second pass (a wave's LDS operations execute in order: its loads of the first pass are behind it)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float* wp = xch + xw_row + (((2 * g + h) ^ xw_sw) << 2);
+          *reinterpret_cast<floatx4*>(wp) = low[g][0];
+          *reinterpret_cast<floatx4*>(wp + 1024) = low[g][1];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        floatx4 v = *reinterpret_cast<const floatx4*>(xch + ((pq & 1) * 32 + 8 * k) * 32 + xr_off);
+        if (EPI & 2) v = pk4_add(v, ad[pq & 1][k]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, v), rsD, epi_off(k, pq), pix_b[pq], 0);
+        asm volatile("s_nop 1" : : "v"(v));      // (see wino2_kernel: the store's data registers are read over several cycles)
+        if (EPI & 5) {
+          const bool okv = (okm >> (4 * k + pq)) & 1;
+          const floatx4 t0 = okv ? v : floatx4{0.f, 0.f, 0.f, 0.f};
+          if (EPI & 1) {
+            s0 += t0;
+            s1 += t0 * t0;
+          } else {
+            const floatx4 x_ = xb[pq & 1][k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float t = (!p.bnb_relu || fmaf(x_[i], bsc[i], bsh[i]) > 0.f) ? t0[i] : 0.f;
+              s0[i] += t;
+              s1[i] += t * ((x_[i] - bmu[i]) * bis[i]);
+            }
+          }
+        }
+      }
+      if (pq < 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (EPI & 4) load_xb(pq + 2);
+        if (EPI & 2) load_ad(pq + 2);
+      }
+    }
+  }
+  if ((EPI & 5) && p.stats) {
+    __syncthreads();
+    float* red = sm;            // [2 terms][4 waves][32]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = s0[i], b = s1[i];
+      a += __shfl_xor(a, 8, 64); b += __shfl_xor(b, 8, 64);
+      a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+      if (lane < 8) {
+        red[wave * 32 + 4 * lane + i] = a;
+        red[128 + wave * 32 + 4 * lane + i] = b;
+      }
+    }
+    __syncthreads();
+    float* row = p.stats + (long long)blockIdx.x * 2 * Cn;
+    for (int c = tid; c < Cn; c += 256) {
+      float a = 0.f, b = 0.f;
+      if (c / 64 == cb) {
+        const int cc = c % 64, w0 = (cc >> 5) * 2, c32 = cc & 31;
+        a = red[w0 * 32 + c32] + red[(w0 + 1) * 32 + c32];
+        b = red[128 + w0 * 32 + c32] + red[128 + (w0 + 1) * 32 + c32];
+      }
+      row[c] = a;
+      row[Cn + c] = b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same layers through the Winograd identity (backward of models/network_blocks.py:35,40):
 //     dU[xi][n][c] = sum over tiles of (A dY A^T)[xi][tile][n] * (B^T d B)[xi][tile][c],     dw = G^T dU G
 // 16 instead of 36 multiply-adds per (tile, n, c) — the 2.25x of the forward.  One workgroup = 8 waves = one
@@ -1158,6 +1555,9 @@ int wino_variant(const avid_conv_desc* d, int mode) { return wino_use_v2(d, mode
 
 int wino_grid(const avid_conv_desc* d, int mode) {
   const int Cn = mode ? d->Cin : d->Cout, ncb = Cn / 64;
+  // (the fewest workgroups with the same number of rounds — 224 instead of 256 for conv2x at batch 64 — was measured in round 5:
+  //  every workgroup then has the full count, the start stagger of wino2_kernel has nobody to delay, the chip loads and stores in
+  //  lockstep: layer alone 136 -> 142 us, the step unchanged (10.07 vs 10.06 ms).  Not kept.)
   if (wino_use_v2(d, mode)) return wino_cus() / ncb * ncb;
   int g = 2 * wino_cus();
   g = g / ncb * ncb;
@@ -1167,8 +1567,28 @@ int wino_grid(const avid_conv_desc* d, int mode) {
   return g;
 }
 
+// AVID_WINO2_PRE (default 1): wino2p_kernel — V split once, by the transform (split-bf16 builds only)
+static int g_wino2_pre_override = -1;   // avid_wino2_pre_configure
+static bool wino2_pre() {
+  static int on = -1;
+  if (on < 0) on = wino_env("AVID_WINO2_PRE", 1) != 0;
+  return W2_SPLIT && (g_wino2_pre_override >= 0 ? g_wino2_pre_override != 0 : on != 0);
+}
+
 template <int EPI>
 static void wino2_launch(const WinoArgs& a, int grid, hipStream_t s) {
+  if (wino2_pre()) {
+    auto kp = wino2p_kernel<EPI>;
+    static bool setp[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!setp[dev]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, W2P_LDS_BYTES);
+      setp[dev] = true;
+    }
+    hipLaunchKernelGGL(kp, dim3(grid), dim3(256), W2P_LDS_BYTES, s, a);
+    return;
+  }
   auto kern = wino2_kernel<EPI>;
   const size_t lds = sizeof(float) * W2_LDS_FLOATS;
   static bool set[64] = {false};
@@ -1335,6 +1755,11 @@ int wino_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* 
 }
 
 }  // namespace avid
+
+extern "C" int avid_wino2_pre_configure(int on) {
+  avid::g_wino2_pre_override = on < 0 ? -1 : (on ? 1 : 0);
+  return AVID_OK;
+}
 
 extern "C" int avid_wino2_configure(int min_rounds_x10) {
   avid::g_wino2_override = min_rounds_x10;

@@ -173,6 +173,12 @@ int avid_wino_configure(int enabled, int64_t min_pixels, int max_channels);
  * (default 15, environment AVID_WINO2_MIN_ROUNDS; AVID_WINO2=0: never), wino_kernel otherwise.  0 sends every Winograd
  * layer through wino2_kernel (tests), negative restores the environment / default. */
 int avid_wino2_configure(int min_rounds_x10);
+/* wino2_kernel's two forms: 1 (default; environment AVID_WINO2_PRE) = wino2p_kernel — the transformed input V is split into its
+ * three bf16 terms ONCE, by the thread that transforms it, and kept in LDS as the fragments the products read (a ring of three
+ * half-stages of 8 transform points); 0 = every product wave splits the fragments it multiplies.  Same split, same products,
+ * same order: bit-identical results (tests/test_gpu_ops.py::test_wino2_presplit_is_bit_identical).  Negative: environment /
+ * default.  Takes effect from the next launch. */
+int avid_wino2_pre_configure(int on);
 
 /* Which launches take tconv64_kernel — the (3,1,1) stride-1 pad-1 layers with 64 -> 64 channels and 8 frames
  * (models/network_blocks.py:37,42 in conv2x), forward and input gradient, when the layer's pre-split weights are passed

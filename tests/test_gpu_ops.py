@@ -915,3 +915,50 @@ def test_winograd_bn_backward_sums_random_shapes(gpu_device):
     finally:
         ops.wino_configure(-1, -1, -1)
         ops.wino2_configure(-1)
+
+
+@pytest.mark.parametrize("shape,cin,cout", [((6, 8, 27, 29), 64, 64), ((5, 4, 45, 47), 128, 128), ((8, 2, 21, 19), 256, 256),
+                                            ((64, 1, 10, 25), 64, 64), ((3, 8, 56, 56), 64, 128)])
+def test_wino2_presplit_is_bit_identical(shape, cin, cout, gpu_device, kernel_log):
+    """wino2p_kernel (V split once by the transform thread, three bf16 planes in a ring of half-stages; default) against
+    wino2_kernel (every product wave splits its fragments): the same split of the same values and the same six products in
+    the same order — output, BatchNorm partial sums (with and without the residual addend) and the input gradient with the
+    BatchNorm-backward sums out of its epilogue are bit-identical.  Odd extents, one to four column blocks, 4 to 16 chunks."""
+    from avid_hip import ops, lib
+    B, Ti, Hi, Wi = shape
+    x = T(detgen.det_normalish(f"w2p:{shape}:{cin}:x", (B, Ti, Hi, Wi, cin))).to(gpu_device)
+    w = ops.make_weight(cout, cin, 1, 3, 3)
+    w.copy_(T(detgen.det_param(f"w2p:{cout}:{cin}:w.weight", (cout, cin, 1, 3, 3))))
+    w = w.to(gpu_device)
+    add = T(detgen.det_uniform(f"w2p:{shape}:{cout}:add", (B, Ti, Hi, Wi, cout))).to(gpu_device)
+    gy = T(detgen.det_uniform(f"w2p:{shape}:{cout}:gy", (B, Ti, Hi, Wi, cout))).to(gpu_device)
+    gam = (T(detgen.det_uniform(f"w2p:{cin}:g", (cin,))) + 1.5).to(gpu_device)
+    bet = T(detgen.det_uniform(f"w2p:{cin}:b", (cin,))).to(gpu_device)
+    pre = lib.raw("avid_wino2_pre_configure")
+    ops.wino_configure(1, 1, 256)
+    ops.wino2_configure(0)
+    res = {}
+    try:
+        for on in (1, 0):
+            pre(on)
+            with kernel_log() as log:
+                out = [ops.conv_cl(x, w, (1, 1, 1), (0, 1, 1))]
+                out += list(ops.conv_cl(x, w, (1, 1, 1), (0, 1, 1), bn_stats=True))
+                out += list(ops.conv_cl(x, w, (1, 1, 1), (0, 1, 1), addend=add, bn_stats=True))
+                # BN + ReLU in front of the conv: its input gradient carries the BatchNorm-backward sums (EPI 4)
+                xx = x.clone().requires_grad_(True)
+                g_, b_ = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+                rm, rv = torch.zeros(cin, device=gpu_device), torch.ones(cin, device=gpu_device)
+                src = ops.BnSource(None, None, True)
+                hh = ops.batch_norm_cl(xx, g_, b_, rm, rv, True, relu=True, src=src)
+                y2 = ops.conv_cl(hh, w, (1, 1, 1), (0, 1, 1), bn_src=src)
+                (y2 * gy).sum().backward()
+                out += [y2.detach(), xx.grad, g_.grad, b_.grad]
+            assert log.launches("wino2_kernel") >= 5 and log.launches("wino_kernel") == 0, sorted(log.report)
+            res[on] = [t.clone() for t in out]
+    finally:
+        pre(-1)
+        ops.wino_configure(-1, -1, -1)
+        ops.wino2_configure(-1)
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(a, b)

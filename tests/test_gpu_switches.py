@@ -30,6 +30,7 @@ def default_run(gpu_device):
 
 
 IDENTICAL = [{"AVID_PLAN": "0"}, {"AVID_STEM_WGRAD_PRE": "0"},    # (dy split at commit time or per use: the same split, the same sums)
+             {"AVID_WINO2_PRE": "0"},                             # (V split by the transform or by every product wave: likewise)
               {"AVID_OVERLAP_TOWERS": "0"}, {"AVID_DEFER_WGRAD": "0"}, {"AVID_STREAM_PROBE": "0"},
              {"AVID_FORCE_DIST": "1"}, {"AVID_FORCE_DIST": "1", "AVID_BUCKET_MB": "2"},
              {"AVID_HIP_LIB": os.path.join(os.path.dirname(HERE), "avid-cma_amd", "avid_hip", "libavid_hip.so")}]
