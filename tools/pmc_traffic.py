@@ -15,6 +15,8 @@ def short_name(name):
     if not m:
         return None
     short = m.group(1)
+    if short == "wino2p_kernel":                  # wino2_kernel's default form (V split by the transform): the timers' name
+        short = "wino2_kernel"
     if m.group(2):
         args = [a.strip() for a in m.group(2).split(",")]
         strided = False
