@@ -608,6 +608,9 @@ def main():
                          "unit": "TFLOP/s", "frac": round(ach / mfma_peak(dom), 4), "traffic": traffic,
                          "traffic_source": dict({"file": "profiles/pmc_traffic.json"}, **(traffic_source or {})),
                          "shader_clock_ghz": clock_ghz,
+                         # ms_per_step x mean shader clock: the step in shader cycles.  Boxes of this pool hold 2.11 - 2.29 GHz under
+                         # this load and the step time follows the clock: this figure compares runs across boxes
+                         "mcycles_per_step": None if clock_ghz is None else round(ms * clock_ghz, 2),
                          "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                          "launches_per_step": d["launches"] / kern_steps,
                          "avg_launch_ms": round(d["ms"] / d["launches"], 4),
