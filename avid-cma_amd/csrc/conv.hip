@@ -432,7 +432,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   static_assert(!BS || (NT == 256 && (BN == 64 || BN == 128) && PK_SPLIT), "pre-split weights: the 4-wave tiles of the split-bf16 build");
   constexpr int BCH = (BN / 64) * PK_BCH;       // bytes of a pre-split (k-tile, column block) chunk: one PK_BCH per 64 columns
   constexpr int PB3 = BCH / (NT * 16);          // 16-byte items of a pre-split chunk per thread
-  constexpr int STAGE = BS ? BM * LDK + BCH / 4 : (BM + BN) * LDK;
+  // BS with the 128-column tile: the input stage unpadded (32 floats per row) with its 16-byte pieces XOR-swizzled by bits 1-3 of
+  // the row — 16 KB + 24 KB of weight fragments = 40 KB per stage, two stages = 80 KB: TWO workgroups in the CU's 160 KB (the padded
+  // rows made it 43 KB and one workgroup: round 5, first form).  A read phase (16 consecutive rows, one piece each) and a store
+  // pass (8 rows x 8 pieces per wave) both touch every bank once.
+  constexpr bool ASWZ = BS && BN == 128;
+  constexpr int ALD = ASWZ ? BK : LDK;
+  constexpr int STAGE = BS ? BM * ALD + BCH / 4 : (BM + BN) * LDK;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -733,11 +739,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   };
   auto store_stage = [&](float* st) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) *reinterpret_cast<floatx4*>(&st[(lrow + RPP * i) * LDK + lcol]) = va[i];
+    for (int i = 0; i < PA; ++i)   // (RPP is a multiple of 16: the swizzle key of a thread's rows is that of lrow)
+      *reinterpret_cast<floatx4*>(&st[(lrow + RPP * i) * ALD + (ASWZ ? (((tid & 7) ^ ((lrow >> 1) & 7)) << 2) : lcol)]) = va[i];
     if (BS) {
 #pragma unroll
       for (int i = 0; i < PB3; ++i)
-        *reinterpret_cast<pk_uintx4*>(reinterpret_cast<char*>(st + BM * LDK) + (tid + NT * i) * 16) = vb3[i];
+        *reinterpret_cast<pk_uintx4*>(reinterpret_cast<char*>(st + BM * ALD) + (tid + NT * i) * 16) = vb3[i];
       return;
     }
 #pragma unroll
@@ -788,17 +795,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     //  fragments 24 — measured: <4,1,1,2,0> 0.98 -> 1.06 ms per step, <2,2,2,2,0> 0.59 -> 0.52)
     if (BS) {
       // the weight fragments come whole from LDS; only this wave's input rows are split in registers
-      const float* As = Ab - h * 4 + h * 8;
-      const char* Bc = reinterpret_cast<const char*>(cur + BM * LDK) + lane * 16;
+      const float* As = ASWZ ? cur + (wm * TM * 32 + l31) * ALD : Ab - h * 4 + h * 8;
+      const int akey = (l31 >> 1) & 7;                 // ASWZ: piece c of this lane's rows sits at c ^ akey
+      const char* Bc = reinterpret_cast<const char*>(cur + BM * ALD) + lane * 16;
 #pragma unroll
       for (int st = 0; st < BK / 16; ++st) {
         if (decltype(ST)::value && st == 0) store_stage(nxt);
         if (decltype(LD)::value && st == 1) issue_loads();
         pk_bf16x8 ah[TM], am[TM], al[TM];
+        const int o0 = ASWZ ? (((st * 4 + h * 2) ^ akey) << 2) : st * 16;
+        const int o1 = ASWZ ? (((st * 4 + h * 2 + 1) ^ akey) << 2) : st * 16 + 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const floatx4 v0 = *reinterpret_cast<const floatx4*>(As + i * 32 * LDK + st * 16);
-          const floatx4 v1 = *reinterpret_cast<const floatx4*>(As + i * 32 * LDK + st * 16 + 4);
+          const floatx4 v0 = *reinterpret_cast<const floatx4*>(As + i * 32 * ALD + o0);
+          const floatx4 v1 = *reinterpret_cast<const floatx4*>(As + i * 32 * ALD + o1);
           pk_split8(v0, v1, ah[i], am[i], al[i]);
         }
 #pragma unroll
@@ -2210,6 +2220,231 @@ __device__ __forceinline__ void wgrad_tab_body(const WgradArgs& p, const unsigne
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad_pre_body: the 128 x 128 dw tile of wgrad_tab_body<2, 2, SPLIT> with every operand fragment split ONCE, by the thread that
+// stages it (round 5, late; DESIGN 8g "split once at the LDS write where the loader can do the transposition").  The contraction
+// index of a weight gradient is the PIXEL, so a fragment lane holds 8 consecutive pixels of one channel — across the channels-last
+// rows.  In wgrad_tab_body each of the two waves that share a fragment gathers it with eight ds_read_b32 and splits it itself
+// (7 vector instructions per matrix instruction).  Here a stage is ONE k-step of 16 pixel rows; wave w stages sub-tile w
+// (0 / 1: dy columns 0-63 / 64-127 of the tile, 2 / 3: the two (tap, 64-channel) x chunks), thread (o = lane >> 5, cp = lane & 31)
+// loads rows 8 o .. 8 o + 7 x columns 2 cp, 2 cp + 1 (eight 8-byte loads, a row = 256 contiguous bytes per half-wave), holds the
+// complete content of two fragment lanes, splits them (2 x 4 pair splits) and writes six 16-byte pieces into
+//     P[sub-tile 4][column half 2][hi | mid | lo][lane 64][8 bf16]            (24 KB per stage, two stages)
+// at lane slot o * 32 + i * 16 + (cp & 15): consecutive threads, consecutive slots (conflict-free), and a product step reads a
+// fragment with three ds_read_b128 and no vector instruction.  Slot s of a 32-column half therefore holds column
+// chan(s) = 2 (s & 15) + (s >> 4): the MFMA's row / column index is a permutation of the tile's channels, undone where the
+// accumulators are stored (same 128-byte segments per row).  Pixel rows map to the same (half-wave, element) positions as in
+// wgrad_tab_body and the six products are issued in the same order: bit-identical to it.
+// Loads run two stages ahead of the split (two register sets), the split one stage ahead of the products; one barrier per stage;
+// the row table covers 64 chunks (16 KB): 64 KB of LDS, two workgroups per CU as before.
+// ------------------------------------------------------------------------------------------------
+constexpr int WGP_TABC = 64;                       // chunks of 32 pixel rows per fill of the row table
+constexpr int WGP_STAGE = 4 * 2 * 3 * 1024;        // bytes
+constexpr size_t WGP_LDS = 2 * WGP_STAGE + sizeof(unsigned) * 2 * WGP_TABC * 32;
+
+__device__ __forceinline__ void wgrad_pre_body(const WgradArgs& p, const unsigned lid, float* smem) {
+  constexpr int NB = 2, KC = 2;
+  char* const sb = reinterpret_cast<char*>(smem);
+  // row table: the RESOLVED byte offset of every pixel row's x element for each of the tile's two (tap, 64-channel) chunks —
+  // OOB where the tap leaves the source or the row is past M — so that staging x costs what staging dy costs (two 16-byte
+  // table reads per stage, fetched one stage ahead, and one add per row): tabx[chunk j][row]
+  unsigned* tabx = reinterpret_cast<unsigned*>(sb + 2 * WGP_STAGE);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ntaps = p.kt * p.kh * p.kw;
+  const int K = ntaps * p.Cs;
+  const int cpt = p.Cs / 64, nchunks = ntaps * cpt;
+
+  const int bx = (int)(lid % (unsigned)p.tiles), by = (int)(lid / (unsigned)p.tiles);
+  const int ktile = bx % p.kt_tiles, ntile = bx / p.kt_tiles;
+  const int n0 = ntile * 64 * NB;
+  // loader role: sub-tile = wave, rows 8 o .. 8 o + 7 of the stage, columns 2 cp, 2 cp + 1 of the sub-tile
+  const int o = h, cp = l31;
+  int q_tap[KC], q_c0[KC];
+  bool q_ok[KC];
+#pragma unroll
+  for (int j = 0; j < KC; ++j) {
+    const int q = ktile * KC + j;
+    q_ok[j] = q < nchunks;
+    const int qq = q_ok[j] ? q : 0;
+    q_tap[j] = qq / cpt;
+    q_c0[j] = (qq - q_tap[j] * cpt) * 64;
+  }
+  // the two x chunks: offset from tap (0,0,0), required validity bits
+  unsigned xq_off[KC], xq_need[KC];
+#pragma unroll
+  for (int j = 0; j < KC; ++j) {
+    const int dw = q_tap[j] % p.kw, r = q_tap[j] / p.kw;
+    const int dh = r % p.kh, dt = r / p.kh;
+    xq_off[j] = (unsigned)(((dt * p.Hs + dh) * p.Ws + dw) * p.Cs + q_c0[j]) * 4;
+    xq_need[j] = q_ok[j] ? (1u << dt) | (1u << (8 + dh)) | (1u << (16 + dw)) : 0xffffffffu;
+  }
+
+  const int total_chunks = (p.M + 31) / 32;
+  const int chunk0 = by * p.chunks_per_split;
+  const int chunk1 = min(chunk0 + p.chunks_per_split, total_chunks);
+
+  const int pix_out = p.Td * p.Hd * p.Wd, pix_in = p.Ts * p.Hs * p.Ws;
+  int b_lo = (chunk0 * 32) / pix_out;
+  if (b_lo >= p.B) b_lo = p.B - 1;
+  const long long x_base = (long long)b_lo * pix_in * p.Cs;
+  long long x_bytes = ((long long)p.B * pix_in * p.Cs - x_base) * 4;
+  if (x_bytes > 0x7fffffffll) x_bytes = 0x7fffffffll;
+  const __amdgpu_buffer_rsrc_t rsX =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.src + x_base), 0, (int)x_bytes, 0x00020000);
+  const long long d_base = (long long)min(chunk0 * 32, p.M - 1) * p.Cd;
+  long long d_bytes = ((long long)p.M * p.Cd - d_base) * 4;     // exact: rows >= M read as zeros
+  if (d_bytes > 0x7fffffffll) d_bytes = 0x7fffffffll;
+  const __amdgpu_buffer_rsrc_t rsD =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + d_base), 0, (int)d_bytes, 0x00020000);
+  const int cs4 = p.Cs * 4, cd4 = p.Cd * 4;
+  const unsigned dvoff = (unsigned)((8 * o) * p.Cd + n0 + wave * 64 + 2 * cp) * 4;   // waves 0, 1
+
+  int cb = chunk0;                                  // first chunk covered by the row table
+  auto fill_table = [&](int nrows) {
+    for (int r = tid; r < nrows; r += 256) {
+      const int m = cb * 32 + r;
+      const bool ok = m < p.M;
+      const unsigned mm = ok ? (unsigned)m : 0u;
+      const unsigned q1 = magic_div(mm, p.mgW, p.shW);
+      const int wd = mm - q1 * p.Wd;
+      const unsigned q2 = magic_div(q1, p.mgH, p.shH);
+      const int hd = q1 - q2 * p.Hd;
+      const int b = magic_div(q2, p.mgT, p.shT);
+      const int td = q2 - b * p.Td;
+      const int t0 = td * p.st - p.pt, h0 = hd * p.sh - p.ph, w0 = wd * p.sw - p.pw;
+      unsigned mt = 0, mh = 0, mw = 0;
+      for (int d = 0; d < p.kt; ++d) mt |= ((unsigned)(t0 + d) < (unsigned)p.Ts ? 1u : 0u) << d;
+      for (int d = 0; d < p.kh; ++d) mh |= ((unsigned)(h0 + d) < (unsigned)p.Hs ? 1u : 0u) << d;
+      for (int d = 0; d < p.kw; ++d) mw |= ((unsigned)(w0 + d) < (unsigned)p.Ws ? 1u : 0u) << d;
+      const unsigned off = (unsigned)((((b - b_lo) * p.Ts + t0) * p.Hs + h0) * p.Ws + w0) * cs4;
+      const unsigned bits = ok ? (mt | (mh << 8) | (mw << 16)) : 0u;
+#pragma unroll
+      for (int j = 0; j < KC; ++j) tabx[j * (WGP_TABC * 32) + r] = (bits & xq_need[j]) == xq_need[j] ? off + xq_off[j] : OOB;
+    }
+  };
+  // x role: the eight row offsets of the NEXT stage this wave loads (stages are loaded in order), read behind the current loads
+  uint4 xo[2];
+  const unsigned* const my_tab = tabx + (wave & 1) * (WGP_TABC * 32) + 8 * o;
+  auto fetch_offsets = [&](int hs) {
+    const int r = min(hs - 2 * cb, 2 * WGP_TABC - 1) * 16;          // (the stage past the window's last: any valid entry)
+    xo[0] = *reinterpret_cast<const uint4*>(my_tab + r);
+    xo[1] = *reinterpret_cast<const uint4*>(my_tab + r + 4);
+  };
+  // stage hs (a half chunk: 16 pixel rows) -> the register set R
+  const bool dy_role = __builtin_amdgcn_readfirstlane(wave) < 2;
+  auto load_stage = [&](floatx2_t (&R)[8], int hs) {
+    if (dy_role) {
+      const int soff = __builtin_amdgcn_readfirstlane((hs - 2 * chunk0) * 16 * cd4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        R[e] = __builtin_bit_cast(floatx2_t, __builtin_amdgcn_raw_buffer_load_b64(rsD, dvoff, soff + e * cd4, 0));
+    } else {
+      // (OOB + 8 cp is still beyond num_records)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        R[e] = __builtin_bit_cast(floatx2_t, __builtin_amdgcn_raw_buffer_load_b64(rsX, xo[e >> 2][e & 3] + 8u * cp, 0, 0));
+      fetch_offsets(hs + 1);
+    }
+  };
+  // the register set R, split, -> LDS stage `buf`
+  char* const st_base = sb + (((wave * 2 + (cp >> 4)) * 3) * 64 + o * 32 + (cp & 15)) * 16;
+  auto store_stage = [&](const floatx2_t (&R)[8], int buf) {
+    char* d = st_base + buf * WGP_STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float v[8] = {R[0][i], R[1][i], R[2][i], R[3][i], R[4][i], R[5][i], R[6][i], R[7][i]};
+      wg_bf16x8 fh, fm, fl;
+      wg_split8(v, fh, fm, fl);
+      *reinterpret_cast<wg_bf16x8*>(d + i * 256) = fh;
+      *reinterpret_cast<wg_bf16x8*>(d + i * 256 + 1024) = fm;
+      *reinterpret_cast<wg_bf16x8*>(d + i * 256 + 2048) = fl;
+    }
+  };
+
+  floatx16 acc[NB][KC];
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+
+  const char* const a_base = sb + ((wm * 2) * 3 * 64 + lane) * 16;            // + t * 3072 + plane * 1024
+  const char* const b_base = sb + (((2 * 2) + wn) * 3 * 64 + lane) * 16;      // + j * 6144 + plane * 1024
+  auto products = [&](int buf) {
+    const char* A = a_base + buf * WGP_STAGE;
+    const char* B = b_base + buf * WGP_STAGE;
+    wg_bf16x8 ah[NB], am[NB], al[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      ah[t] = *reinterpret_cast<const wg_bf16x8*>(A + t * 3072);
+      am[t] = *reinterpret_cast<const wg_bf16x8*>(A + t * 3072 + 1024);
+      al[t] = *reinterpret_cast<const wg_bf16x8*>(A + t * 3072 + 2048);
+    }
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      const wg_bf16x8 bh = *reinterpret_cast<const wg_bf16x8*>(B + j * 6144);
+      const wg_bf16x8 bm = *reinterpret_cast<const wg_bf16x8*>(B + j * 6144 + 1024);
+      const wg_bf16x8 bl = *reinterpret_cast<const wg_bf16x8*>(B + j * 6144 + 2048);
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl, acc[t][j], 0, 0, 0);
+        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, acc[t][j], 0, 0, 0);
+        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], bm, acc[t][j], 0, 0, 0);
+        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bm, acc[t][j], 0, 0, 0);
+        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t], bh, acc[t][j], 0, 0, 0);
+        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh, acc[t][j], 0, 0, 0);
+      }
+    }
+  };
+
+  floatx2_t R0[8], R1[8];
+  for (; cb < chunk1; cb += WGP_TABC) {
+    const int ce = min(cb + WGP_TABC, chunk1);
+    const int s0 = 2 * cb, s1 = 2 * ce;             // stages of this table window (always an even number, >= 2)
+    __syncthreads();                                // the previous window's table and stage reads are done
+    fill_table((ce - cb) * 32);
+    __syncthreads();
+    if (!dy_role) fetch_offsets(s0);
+    load_stage(R0, s0);
+    load_stage(R1, s0 + 1);
+    store_stage(R0, 0);
+    if (s0 + 2 < s1) load_stage(R0, s0 + 2);
+    __syncthreads();
+    // stage s is multiplied from buffer (s - s0) & 1; its successor is split into the other buffer first, then the loads of
+    // stage s + 3 go into the register set that has just been written out
+    for (int s = s0; s < s1; s += 2) {
+      store_stage(R1, 1);                           // stage s + 1 (exists: the window has an even number of stages)
+      if (s + 3 < s1) load_stage(R1, s + 3);
+      products(0);
+      __syncthreads();
+      if (s + 2 < s1) store_stage(R0, 0);
+      if (s + 4 < s1) load_stage(R0, s + 4);
+      products(1);
+      __syncthreads();
+    }
+  }
+
+  const int ld = p.out_ld ? p.out_ld : K;
+  float* op = p.out + (long long)by * (p.out_split ? p.out_split : (long long)p.Cd * K) + p.out_koff;
+  const int ccol = 2 * (l31 & 15) + (l31 >> 4);     // the channel this lane's fragment slot holds
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      if (!q_ok[j]) continue;
+      const int kcol = q_tap[j] * p.Cs + q_c0[j] + wn * 32 + ccol;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;                       // MFMA row = fragment slot of the dy operand
+        const int n = n0 + wm * 32 * NB + t * 32 + 2 * (i & 15) + (i >> 4);
+        op[(long long)n * ld + kcol] = acc[t][j][r];
+      }
+    }
+}
+
 template <int NB, int KC, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void wgrad_tab_kernel(const WgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2233,7 +2468,7 @@ struct WgradGroupArgs {
   unsigned run;                      // consecutive items that stay on one XCD
 };
 
-template <bool SPLIT>
+template <bool SPLIT, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const WgradGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int total = g.item0[g.n];
@@ -2251,7 +2486,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const WgradGroupArg
   for (int item = (int)first; item < total; item += (int)G) {
     int l = 0;
     while (l + 1 < g.n && item >= g.item0[l + 1]) ++l;
-    wgrad_tab_body<2, 2, SPLIT>(g.layer[l], (unsigned)(item - g.item0[l]), smem);
+    if (PRE) wgrad_pre_body(g.layer[l], (unsigned)(item - g.item0[l]), smem);
+    else wgrad_tab_body<2, 2, SPLIT>(g.layer[l], (unsigned)(item - g.item0[l]), smem);
     __syncthreads();                 // the next item refills the row table and both stages
   }
 }
@@ -2771,13 +3007,16 @@ constexpr bool pk_takes_split() {
 // forward / input gradient): where a launch deals several tiles per CU the lost occupancy costs more than the splits save
 // (conv3x temporal 51.0 -> 56.1 / 56.2 -> 62.7, conv3x strided spatial forward 114.7 -> 132.7); where every workgroup has at
 // most one (tile, K piece) unit anyway it wins (conv4x strided spatial forward 85.9 -> 78.9, audio block 3 32.4 -> 29.9 / 40.4 ->
-// 36.4).  AVID_BS_WIDE: 1 (default) the second kind only — plans without a full round —, 2 every launch of the tile, 0 never.
+// 36.4).  Round 5, second form: the input stage unpadded and XOR-swizzled (igemm_pk_kernel's ASWZ): 40 KB per stage, two workgroups per
+// CU again — conv3x temporal 49.2 -> 45.2 / 54.5 -> 51.0, conv3x strided spatial forward 109.7 -> 104.5, `<2,2,2,2,*>` 0.78 -> 0.74 ms
+// per step, the step 9.782 -> 9.746 ms (three alternating pairs of 300 steps, one box).
+// AVID_BS_WIDE: 2 (default) every launch of the tile, 1 only plans without a full round of tiles, 0 never.
 static int bs_wide_mode() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("AVID_BS_WIDE");
-    v = e ? atoi(e) : 1;
-    if (v < 0 || v > 2) v = 1;
+    v = e ? atoi(e) : 2;
+    if (v < 0 || v > 2) v = 2;
   }
   return v;
 }
@@ -2791,7 +3030,7 @@ static void launch_pk_e(const ConvArgs& a, int grid, size_t lds, hipStream_t s) 
     if (a.wsp) {
       ++g_presplit_launches;
       constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-      const size_t lds3 = sizeof(float) * 2 * (BM * LDK + (BN / 64) * PK_BCH / 4) + (STRIDED ? sizeof(int) * 2 * BM : 0);
+      const size_t lds3 = sizeof(float) * 2 * (BM * (BN == 128 ? BK : LDK) + (BN / 64) * PK_BCH / 4) + (STRIDED ? sizeof(int) * 2 * BM : 0);
       launch_pk_eb<WM, WN, TM, TN, MODE, STRIDED, EPI, true>(a, grid, lds3, s);
       return;
     }
@@ -3621,6 +3860,20 @@ static bool wgrad_split() {
   return on != 0;
 }
 
+// grouped weight gradients with the fragments split once at the LDS write (wgrad_pre_body); AVID_WGRAD_PRE=0: split per use
+static int g_wgrad_pre = -1;
+static bool wgrad_pre() {
+  if (g_wgrad_pre < 0) {
+    const char* e = getenv("AVID_WGRAD_PRE");
+    g_wgrad_pre = e ? (atoi(e) != 0 ? 1 : 0) : 1;
+  }
+  return g_wgrad_pre != 0 && wgrad_split();
+}
+extern "C" int avid_wgrad_pre_configure(int on) {
+  g_wgrad_pre = on < 0 ? -1 : (on ? 1 : 0);
+  return AVID_OK;
+}
+
 // ---- wgrad plan
 struct WgradPlan {
   bool vec;
@@ -3956,9 +4209,12 @@ extern "C" int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* 
     bytes += 4.0 * ((double)d->B * d->Ti * d->Hi * d->Wi * d->Cin + M * d->Cout + (double)d->Cout * Kp);
   }
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = sizeof(float) * 2 * 32 * (64 * 2 + 4 + 2 * WG_LD) + sizeof(uint2) * WG_TABC * 32;
+  const bool pre = wgrad_pre();
+  const size_t lds = pre ? WGP_LDS : sizeof(float) * 2 * 32 * (64 * 2 + 4 + 2 * WG_LD) + sizeof(uint2) * WG_TABC * 32;
   static bool set = false;
   if (!set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)WGP_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3970,7 +4226,8 @@ extern "C" int avid_conv_wgrad_group(int n, const avid_wgrad_item* items, void* 
   if (grid > grid_cap) grid = grid_cap;
   {
     ScopedTimer t(s, "wgrad_group_kernel", flops, bytes);
-    if (wgrad_split()) hipLaunchKernelGGL(wgrad_group_kernel<true>, dim3((unsigned)grid), dim3(256), lds, s, g);
+    if (pre) hipLaunchKernelGGL((wgrad_group_kernel<true, true>), dim3((unsigned)grid), dim3(256), lds, s, g);
+    else if (wgrad_split()) hipLaunchKernelGGL(wgrad_group_kernel<true>, dim3((unsigned)grid), dim3(256), lds, s, g);
     else hipLaunchKernelGGL(wgrad_group_kernel<false>, dim3((unsigned)grid), dim3(256), lds, s, g);
   }
   int rc = check_launch("wgrad_group");

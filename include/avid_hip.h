@@ -179,6 +179,12 @@ int avid_wino2_configure(int min_rounds_x10);
  * same order: bit-identical results (tests/test_gpu_ops.py::test_wino2_presplit_is_bit_identical).  Negative: environment /
  * default.  Takes effect from the next launch. */
 int avid_wino2_pre_configure(int on);
+/* wgrad_group_kernel's two forms (the grouped weight gradients of the 128-wide layers, backward of models/network_blocks.py:37-49,
+ * models/audio.py:27-30): 1 (default; environment AVID_WGRAD_PRE) = every dy / x fragment is split into its three bf16 terms ONCE, by
+ * the thread that stages it (one k-step of 16 pixel rows per LDS stage, fragments kept as three planes); 0 = each of the two waves
+ * that share a fragment gathers and splits it itself.  Same split, same products, same order: bit-identical results
+ * (tests/test_gpu_ops.py::test_grouped_weight_gradients_presplit_is_bit_identical).  Negative: environment / default. */
+int avid_wgrad_pre_configure(int on);
 
 /* Which launches take tconv64_kernel — the (3,1,1) stride-1 pad-1 layers with 64 -> 64 channels and 8 frames
  * (models/network_blocks.py:37,42 in conv2x), forward and input gradient, when the layer's pre-split weights are passed

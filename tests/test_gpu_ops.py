@@ -302,6 +302,44 @@ def test_grouped_weight_gradients(count, gpu_device):
             assert bool((o.cpu()[:, :, dead] == 0).all())
 
 
+def test_grouped_weight_gradients_presplit_is_bit_identical(gpu_device):
+    """wgrad_group_kernel with the fragments split once at the LDS write (wgrad_pre_body: k-step stages, three bf16 planes,
+    permuted fragment slots) against the form that gathers and splits per use: same split, same products, same order — every
+    layer of the twelve-layer table (strided, temporal, 1x1x1, dead taps, ragged pixel counts), slabs and direct writes."""
+    import ctypes as C
+    from avid_hip import lib, ops
+    count = len(GROUP_LAYERS[:12])
+    items = (lib.WgradItem * count)()
+    keep, outs = [], []
+    for i, (cin, cout, k, stride, pad, (B, Ti, Hi, Wi)) in enumerate(GROUP_LAYERS[:count]):
+        x = T(detgen.det_normalish(f"grp:{i}:x", (B, cin, Ti, Hi, Wi)))
+        To, Ho, Wo = [(n + 2 * p_ - k_) // s_ + 1 for n, p_, k_, s_ in zip((Ti, Hi, Wi), pad, k, stride)]
+        gy = T(detgen.det_uniform(f"grp:{i}:gy", (B, cout, To, Ho, Wo)))
+        xd, gyd = cl(x).to(gpu_device), cl(gy).to(gpu_device)
+        d, _, _, _, _ = ops._desc_cached((B, Ti, Hi, Wi), cin, cout, k, stride, pad, False)
+        dw = ops.make_weight(cout, cin, *k).to(gpu_device)
+        items[i].d = d
+        items[i].x, items[i].dy, items[i].dw = xd.data_ptr(), gyd.data_ptr(), dw.data_ptr()
+        keep += [xd, gyd]
+        outs.append(dw)
+    nb = lib.raw("avid_conv_wgrad_group_workspace_bytes")(count, items)
+    ws = torch.empty(max(int(nb), 16), dtype=torch.uint8, device=gpu_device)
+    pre = lib.raw("avid_wgrad_pre_configure")
+    res = {}
+    try:
+        for on in (1, 0):
+            pre(on)
+            for o in outs:
+                o.fill_(float("nan"))
+            lib.call("avid_conv_wgrad_group", count, items, ops._p(ws), ws.numel(), ops._stream())
+            res[on] = [o.clone() for o in outs]
+    finally:
+        pre(-1)
+    for i, (a, b) in enumerate(zip(res[1], res[0])):
+        assert bool(torch.isfinite(a).all()), i
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+
+
 def test_conv_transpose_detecting(gpu_device):
     """A = identity-like with ASYMMETRIC weights: catches a row<->col swap in the MFMA C-write."""
     from avid_hip import ops
