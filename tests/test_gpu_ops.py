@@ -302,16 +302,22 @@ def test_grouped_weight_gradients(count, gpu_device):
             assert bool((o.cpu()[:, :, dead] == 0).all())
 
 
-def test_grouped_weight_gradients_presplit_is_bit_identical(gpu_device):
+BIG_GROUP = [(128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (64, 4, 14, 14))] * 6 + \
+            [(128, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), (64, 4, 14, 14))] * 6
+
+
+@pytest.mark.parametrize("layers", [GROUP_LAYERS[:12], BIG_GROUP], ids=["small_layers", "conv3x_at_64_clips"])
+def test_grouped_weight_gradients_presplit_is_bit_identical(layers, gpu_device):
     """wgrad_group_kernel with the fragments split once at the LDS write (wgrad_pre_body: k-step stages, three bf16 planes,
     permuted fragment slots) against the form that gathers and splits per use: same split, same products, same order — every
-    layer of the twelve-layer table (strided, temporal, 1x1x1, dead taps, ragged pixel counts), slabs and direct writes."""
+    layer of the twelve-layer table (strided, temporal, 1x1x1, dead taps, ragged pixel counts), slabs and direct writes; and
+    twelve conv3x-sized layers at 64 clips, whose items are longer than one fill of the row table (64 chunks)."""
     import ctypes as C
     from avid_hip import lib, ops
-    count = len(GROUP_LAYERS[:12])
+    count = len(layers)
     items = (lib.WgradItem * count)()
     keep, outs = [], []
-    for i, (cin, cout, k, stride, pad, (B, Ti, Hi, Wi)) in enumerate(GROUP_LAYERS[:count]):
+    for i, (cin, cout, k, stride, pad, (B, Ti, Hi, Wi)) in enumerate(layers):
         x = T(detgen.det_normalish(f"grp:{i}:x", (B, cin, Ti, Hi, Wi)))
         To, Ho, Wo = [(n + 2 * p_ - k_) // s_ + 1 for n, p_, k_, s_ in zip((Ti, Hi, Wi), pad, k, stride)]
         gy = T(detgen.det_uniform(f"grp:{i}:gy", (B, cout, To, Ho, Wo)))
