@@ -129,6 +129,7 @@ SIGNATURES = {
     "avid_wino2_configure": (_i, [_i]),
     "avid_wino2_pre_configure": (_i, [_i]),
     "avid_wgrad_pre_configure": (_i, [_i]),
+    "avid_stem_fwd_pre_configure": (_i, [_i]),
     "avid_tconv_configure": (_i, [_i]),
     "avid_set_cu_budget": (_i, [_i]),
     "avid_cu_budget": (_i, []),

@@ -29,6 +29,7 @@ struct StemArgs {
   float* __restrict__ stats;      // forward: BatchNorm partial sums of y, one row [2][64] per workgroup, or null
   int B, Ti, Hi, Wi, Ho, Wo;
   int PW, rows_in_max, tiles_per_frame;
+  int patch_plane_bytes;        // stem_fwd3p_kernel: bytes of one bf16 plane of the patch
   int tile_px;                    // wgrad: output pixels per tile (whole rows when a row fits, <= STEM_TILE)
   int ntiles;                     // B*Ti*tiles_per_frame
   int xcd_local;                  // XCD-contiguous tile order
@@ -508,6 +509,251 @@ __global__ __launch_bounds__(512, 1) void stem_fwd3_kernel(const StemArgs p) {
           cq[j] = fmaf(v, v, cq[j]);
         }
       }
+  }
+  if (p.stats) {
+    float* red = smem;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a = cs[j] + __shfl_xor(cs[j], 32, 64), b = cq[j] + __shfl_xor(cq[j], 32, 64);
+      if (g == 0) {
+        red[wave * 64 + j * 32 + l31] = a;
+        red[WAVES * 64 + wave * 64 + j * 32 + l31] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid & 63, q = tid >> 6;
+      float tt = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) tt += red[q * WAVES * 64 + w * 64 + c];
+      p.stats[(long long)blockIdx.x * 128 + q * 64 + c] = tt;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem_fwd3p_kernel (round 5, late): stem_fwd3_kernel with the patch split ONCE, when it is committed to LDS, and a k-step laid
+// out so that a lane's fragment is CONTIGUOUS in the split planes.  stem_fwd3_kernel's lane takes the taps of its parity from two
+// rows (stride-2 gathers: fine for 4-byte elements, and the reason variant (a) above needed 24 ds_read_u16 per k-step); here the
+// half-wave g takes ROW 2s + g and its eight k are the eight consecutive patch columns 2 wo .. 2 wo + 7 of pixel wo = taps
+// dw = -1 .. 6, the first one a pad slot with zero weight (the window starts at an EVEN column: 4-byte aligned in a 2-byte
+// plane).  The patch lives in LDS as three bf16 planes [hi | mid | lo][(c, dt)][row][PW]; a fragment is 16 contiguous bytes per
+// plane = two ds_read2_b32, the term's operand register as it is: 6 LDS reads and NO vector instruction per k-step where
+// stem_fwd3_kernel has 4 reads + 44 vector instructions (1408 per tile and wave: the "tile overhead" that did not scale with the
+// number of products).  The commit splits: a thread's float4 item = two pair splits + three 8-byte stores (14 vector instructions
+// per item, 16 items per tile).  Every patch element used to be split by each of its ~12 users.  LDS: 6 bytes per patch element
+// (110 KB at 112 x 112 input) + the two 24 KB weight stages = 156 KB; larger inputs keep stem_fwd3_kernel.
+// Same products in the same order per (row, tap); the assignment of (row, tap) pairs to the matrix instruction's k index differs
+// from stem_fwd3_kernel's, so sums agree to rounding, not bit for bit.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned uintx2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// Wf[s][tile][plane][lane][e]: element e of lane (j = lane & 31, g = lane >> 5) = w[n = 32 tile + j][row 2s + g][dw = e - 1]  (e = 0: 0)
+template <int CIN, int KT>
+__global__ void stem_split_weights_rows_kernel(const float* __restrict__ w, uintx4_t* __restrict__ Wf) {
+  constexpr int R = CIN * KT * 7;
+  const int frag = blockIdx.x, lane = threadIdx.x;
+  const int s = frag >> 1, tile = frag & 1, n = 32 * tile + (lane & 31), g = lane >> 5;
+  const int r = 2 * s + g;
+  const int pl = r / 7, dh = r - pl * 7, dt = pl % KT, c = pl / KT;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (r < R && e > 0) ? w[(((n * KT + dt) * 7 + dh) * 7 + (e - 1)) * CIN + c] : 0.f;
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s3_split2(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+  uintx4_t* dst = Wf + ((size_t)frag * 3) * 64 + lane;
+  dst[0] = uintx4_t{h[0], h[1], h[2], h[3]};
+  dst[64] = uintx4_t{m[0], m[1], m[2], m[3]};
+  dst[128] = uintx4_t{l[0], l[1], l[2], l[3]};
+}
+
+// TM = 32-pixel row blocks per wave: 1 (default) = eight waves of 32 pixels (every wave reads all weight fragments: 6 KB of LDS
+// reads per 12 matrix instructions), 2 = FOUR waves of 64 pixels, one per SIMD: a weight fragment feeds two row blocks (6 KB per
+// 24), eight independent accumulation chains per wave.  Same products, same order per accumulator: the outputs are bit-identical;
+// measured slower (stem_fwd3p_tm below), kept as a switch.
+template <int CIN, int KT, int TM>
+__global__ __launch_bounds__(512 / TM, 1) void stem_fwd3p_kernel(const StemArgs p) {
+  constexpr int WAVES = 8 / TM, NT = WAVES * 64, TILE = 256;
+  constexpr int S3_Q = 4;                     // k-steps per weight chunk (24 KB: 3 b128 items per thread)
+  constexpr int S3_CHUNK = S3_Q * S3_STEP_BYTES;
+  constexpr int R = CIN * KT * 7, NS = (R + 1) / 2, NCH = (NS + S3_Q - 1) / S3_Q;
+  constexpr int PIT = TM == 1 ? 10 : 19;      // float4 patch items per thread: >= 4864 items = the 19 456 floats the host admits
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* Wl = reinterpret_cast<char*>(smem);                 // [2][S3_CHUNK]
+  char* P = Wl + 2 * S3_CHUNK;                              // patch: [hi | mid | lo][plane_bytes] of bf16
+  const int plane_bytes = p.patch_plane_bytes;              // 2 bytes per patch element, rounded up to 16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 5, l31 = lane & 31;
+  const int npix = p.Ho * p.Wo;
+  const int q4 = p.PW >> 2;
+  const long long item_floats = (long long)CIN * p.Ti * p.Hi * p.Wi;
+
+  struct TileGeo { int frame, to, b, p0, p1, ho_lo, nrows_in; };
+  auto geo = [&](int tile) {
+    TileGeo t;
+    const int tf = tile % p.tiles_per_frame;
+    t.frame = tile / p.tiles_per_frame;
+    t.to = t.frame % p.Ti;
+    t.b = t.frame / p.Ti;
+    t.p0 = tf * TILE;
+    t.p1 = min(t.p0 + TILE, npix);
+    t.ho_lo = t.p0 / p.Wo;
+    t.nrows_in = 2 * ((t.p1 - 1) / p.Wo - t.ho_lo) + 7;
+    return t;
+  };
+  floatx4 pre_p[PIT];
+  const unsigned mgq = 0xffffffffu / (unsigned)q4 + 1u;
+  auto prefetch = [&](const TileGeo& t) {
+    const int total = CIN * KT * t.nrows_in * q4;
+    const unsigned mgn = 0xffffffffu / (unsigned)t.nrows_in + 1u;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (long long)t.b * item_floats), 0, (int)(item_floats * 4), 0x00020000);
+    int t0 = tid;
+    asm volatile("" : "+v"(t0));
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int e = t0 + it * NT;
+      const int r = (int)__umulhi((unsigned)e, mgq), cq = e - r * q4;
+      const int pl = (int)__umulhi((unsigned)r, mgn), row = r - pl * t.nrows_in;
+      const int dt = pl % KT, c = pl / KT;
+      const int ti = t.to + dt - KT / 2, hi = 2 * t.ho_lo - 3 + row, wi = cq * 4 - 4;
+      const bool ok = (e < total) & ((unsigned)ti < (unsigned)p.Ti) & ((unsigned)hi < (unsigned)p.Hi) &
+                      ((unsigned)wi < (unsigned)p.Wi);
+      const unsigned off = (unsigned)(((c * p.Ti + ti) * p.Hi + hi) * p.Wi + wi) * 4u;
+      pre_p[it] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? off : 0xfffffff0u, 0, 0));
+    }
+  };
+  // item e = patch floats 4 e .. 4 e + 3 -> bytes 8 e .. 8 e + 7 of each plane
+  auto commit = [&](const TileGeo& t) {
+    const int total = CIN * KT * t.nrows_in * q4;
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int e = tid + it * NT;
+      if (e < total) {
+        unsigned h[2], m[2], l[2];
+        s3_split2(pre_p[it][0], pre_p[it][1], h[0], m[0], l[0]);
+        s3_split2(pre_p[it][2], pre_p[it][3], h[1], m[1], l[1]);
+        char* d = P + 8 * e;
+        *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
+        *reinterpret_cast<uint2*>(d + plane_bytes) = make_uint2(m[0], m[1]);
+        *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = make_uint2(l[0], l[1]);
+      }
+    }
+  };
+  constexpr int WIT = S3_CHUNK / 16 / NT;      // b128 items of a weight chunk per thread
+  uintx4_t wv[WIT];
+  const uintx4_t* Wf = reinterpret_cast<const uintx4_t*>(p.wt);
+  auto load_w = [&](int ch) {
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) wv[i] = Wf[(size_t)ch * (S3_CHUNK / 16) + tid + NT * i];
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WIT; ++i) *reinterpret_cast<uintx4_t*>(Wl + buf * S3_CHUNK + (tid + NT * i) * 16) = wv[i];
+  };
+
+  int tile = (int)xcd_remap(blockIdx.x, gridDim.x);
+  if (tile >= p.ntiles) return;
+  int u = 0;
+  float cs[2] = {0.f, 0.f}, cq[2] = {0.f, 0.f};
+  load_w(0);
+  prefetch(geo(tile));
+  store_w(0);
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const TileGeo t = geo(tile);
+    const int p0 = t.p0, p1 = t.p1, ho_lo = t.ho_lo;
+    __syncthreads();
+    commit(t);
+    __syncthreads();
+    if (tile + (int)gridDim.x < p.ntiles) prefetch(geo(tile + gridDim.x));
+
+    // this lane's windows of row offset 0: patch columns 2 wo .. 2 wo + 7 (taps dw = -1 .. 6), hi plane
+    const char* Pb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int pi = p0 + (wave * TM + i) * 32 + l31;
+      const bool pok = pi < p1;
+      const int ho = (pok ? pi : p0) / p.Wo, wo = (pok ? pi : p0) - ho * p.Wo;
+      Pb[i] = P + 2 * ((2 * (ho - ho_lo)) * p.PW + 2 * wo);
+    }
+    const int plane = t.nrows_in * p.PW;
+
+    floatx16 acc[TM][2], cor[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; cor[i][j][r] = 0.f; }
+
+    for (int ch = 0; ch < NCH; ++ch, u ^= 1) {
+      load_w(ch + 1 < NCH ? ch + 1 : 0);
+      const char* Wb = Wl + u * S3_CHUNK + lane * 16;
+#pragma unroll
+      for (int q = 0; q < S3_Q; ++q) {
+        const int s = ch * S3_Q + q;
+        if (s < NS) {
+          // rows 2s (g = 0), 2s + 1 (g = 1; the pad row past R reads row R - 1: its weights are zero, its data finite)
+          const int r0 = 2 * s, r1 = (2 * s + 1 < R) ? 2 * s + 1 : R - 1;
+          const int pl0 = r0 / 7, pl1 = r1 / 7;
+          const int o0 = pl0 * plane + (r0 - pl0 * 7) * p.PW, o1 = pl1 * plane + (r1 - pl1 * 7) * p.PW;
+          const int og = 2 * (g ? o1 : o0);
+          auto frag = [&](const char* a) {
+            const uintx2_a4 lo = *reinterpret_cast<const uintx2_a4*>(a);
+            const uintx2_a4 hi = *reinterpret_cast<const uintx2_a4*>(a + 8);
+            return __builtin_bit_cast(bf16x8_t, uintx4_t{lo[0], lo[1], hi[0], hi[1]});
+          };
+          bf16x8_t ah[TM], am[TM], al[TM];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const char* A = Pb[i] + og;
+            ah[i] = frag(A); am[i] = frag(A + plane_bytes); al[i] = frag(A + 2 * plane_bytes);
+          }
+          bf16x8_t bh[2], bm[2], bl[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const char* bp = Wb + ((q * 2 + j) * 3) * 1024;
+            bh[j] = *reinterpret_cast<const bf16x8_t*>(bp);
+            bm[j] = *reinterpret_cast<const bf16x8_t*>(bp + 1024);
+            bl[j] = *reinterpret_cast<const bf16x8_t*>(bp + 2048);
+          }
+          // six products per (row block, column tile); the five correction products go to their own accumulators (2 TM
+          // x 2 independent chains per wave), in the same order per accumulator as stem_fwd3_kernel
+#define S3P_ALL(DST, AF, BF)                                                                              \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)             \
+      DST[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[i], BF[j], DST[i][j], 0, 0, 0);
+          S3P_ALL(cor, ah, bl)
+          S3P_ALL(acc, ah, bh)
+          S3P_ALL(cor, al, bh)
+          S3P_ALL(cor, am, bm)
+          S3P_ALL(cor, ah, bm)
+          S3P_ALL(cor, am, bh)
+#undef S3P_ALL
+        }
+      }
+      store_w(u ^ 1);
+      __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int blk = p0 + (wave * TM + i) * 32;
+      const long long m_base = (long long)t.frame * npix + blk;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (blk + rr < p1) {
+            const float v = acc[i][j][r] + cor[i][j][r];
+            p.y[(m_base + rr) * 64 + j * 32 + l31] = v;
+            cs[j] += v;
+            cq[j] = fmaf(v, v, cq[j]);
+          }
+        }
+    }
   }
   if (p.stats) {
     float* red = smem;
@@ -1179,16 +1425,54 @@ static int stem_wgrad_launch(const avid_conv_desc* d, const float* x, const floa
   return check_launch("stem_wgrad_reduce");
 }
 
+// stem_fwd3p_kernel (the patch split once at commit time, three bf16 planes): where 6 bytes per patch element fit beside the weight
+// stages; AVID_STEM_FWD_PRE=0 / avid_stem_fwd_pre_configure(0): stem_fwd3_kernel everywhere
+static int g_stem_fwd_pre = -1;
+static size_t stem_patch_plane_bytes(const avid_conv_desc* d) { return (2 * stem_patch_floats(d, 256) + 15) / 16 * 16; }
+static size_t stem_fwd3p_lds(const avid_conv_desc* d) { return 2 * 4 * (size_t)S3_STEP_BYTES + 3 * stem_patch_plane_bytes(d); }
+static bool stem_fwd3p_ok(const avid_conv_desc* d) {
+  if (g_stem_fwd_pre < 0) {
+    const char* e = getenv("AVID_STEM_FWD_PRE");
+    g_stem_fwd_pre = e ? (atoi(e) != 0 ? 1 : 0) : 1;
+  }
+  return g_stem_fwd_pre != 0 && stem_fwd3_ok(d) && stem_fwd3p_lds(d) <= 160 * 1024 && d->Wi % 4 == 0 &&
+         stem_patch_floats(d, 256) <= 19 * 256 * 4;       // (the register prefetch of either wave shape: 10 x 512 / 19 x 256 items)
+}
+void stem_fwd_pre_configure(int on) { g_stem_fwd_pre = on < 0 ? -1 : (on ? 1 : 0); }
+// wave shape of stem_fwd3p_kernel: AVID_STEM_FWD_TM = 1 (default: eight waves of 32 pixels) or 2 (four waves of 64 pixels, one per
+// SIMD: half the weight-fragment reads and eight accumulation chains per wave — and 0.625-0.649 against 0.564-0.568 ms: with one
+// wave on a SIMD nothing runs while it waits for its fragments.  Same outputs bit for bit; the BatchNorm partial sums add the
+// pixels of a wave in another order)
+static int stem_fwd3p_tm() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AVID_STEM_FWD_TM");
+    v = e ? atoi(e) : 1;
+    if (v != 1 && v != 2) v = 1;
+  }
+  return v;
+}
+
 template <int CIN, int KT>
 static int stem_fwd3_launch(const avid_conv_desc* d, const float* x, const float* w, float* y, float* stats, void* ws,
                             hipStream_t s) {
   StemArgs a{};
   stem_geometry(d, a, 256);
   a.x = x; a.w = w; a.y = y; a.wt = static_cast<float*>(ws); a.stats = stats;
-  hipLaunchKernelGGL((stem_split_weights_kernel<CIN, KT>), dim3(stem_fwd3_steps(d) * 2), dim3(64), 0, s, w, static_cast<uintx4_t*>(ws));
+  const bool pre = stem_fwd3p_ok(d);
+  if (pre) {
+    a.patch_plane_bytes = (int)stem_patch_plane_bytes(d);
+    hipLaunchKernelGGL((stem_split_weights_rows_kernel<CIN, KT>), dim3(stem_fwd3_steps(d) * 2), dim3(64), 0, s, w, static_cast<uintx4_t*>(ws));
+  } else {
+    hipLaunchKernelGGL((stem_split_weights_kernel<CIN, KT>), dim3(stem_fwd3_steps(d) * 2), dim3(64), 0, s, w, static_cast<uintx4_t*>(ws));
+  }
   static bool set = false;
   if (!set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd3_kernel<CIN, KT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd3p_kernel<CIN, KT, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd3p_kernel<CIN, KT, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     set = true;
   }
@@ -1196,7 +1480,9 @@ static int stem_fwd3_launch(const avid_conv_desc* d, const float* x, const float
   ScopedTimer t(s, "stem_fwd3_kernel<3,3>", 2.0 * M * 64 * K,
                 4.0 * ((double)d->B * CIN * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
   const int grid = a.ntiles < device_cus() ? a.ntiles : device_cus();
-  hipLaunchKernelGGL((stem_fwd3_kernel<CIN, KT>), dim3(grid), dim3(512), stem_fwd3_lds(d), s, a);
+  if (pre && stem_fwd3p_tm() == 2) hipLaunchKernelGGL((stem_fwd3p_kernel<CIN, KT, 2>), dim3(grid), dim3(256), stem_fwd3p_lds(d), s, a);
+  else if (pre) hipLaunchKernelGGL((stem_fwd3p_kernel<CIN, KT, 1>), dim3(grid), dim3(512), stem_fwd3p_lds(d), s, a);
+  else hipLaunchKernelGGL((stem_fwd3_kernel<CIN, KT>), dim3(grid), dim3(512), stem_fwd3_lds(d), s, a);
   return check_launch("stem_fwd3");
 }
 
@@ -1228,3 +1514,8 @@ int stem_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* 
 }
 
 }  // namespace avid
+
+extern "C" int avid_stem_fwd_pre_configure(int on) {
+  avid::stem_fwd_pre_configure(on);
+  return AVID_OK;
+}

@@ -185,6 +185,13 @@ int avid_wino2_pre_configure(int on);
  * that share a fragment gathers and splits it itself.  Same split, same products, same order: bit-identical results
  * (tests/test_gpu_ops.py::test_grouped_weight_gradients_presplit_is_bit_identical).  Negative: environment / default. */
 int avid_wgrad_pre_configure(int on);
+/* The video stem's forward (models/video.py:20) in its split-bf16 form: 1 (default; environment AVID_STEM_FWD_PRE) =
+ * stem_fwd3p_kernel — the input patch is split into its three bf16 terms ONCE, when it is committed to LDS (three planes), and a
+ * lane's operand fragment is eight consecutive patch columns of one row, read as it is; 0 = stem_fwd3_kernel (fp32 patch, every lane
+ * gathers and splits its taps per k-step).  Same products per (row, tap), assigned to other k indices of the matrix instruction:
+ * results agree to rounding (tests/test_gpu_ops.py::test_stem_fwd_presplit_patch).  Inputs whose split patch does not fit in LDS
+ * (224 x 224) keep stem_fwd3_kernel.  Negative: environment / default. */
+int avid_stem_fwd_pre_configure(int on);
 
 /* Which launches take tconv64_kernel — the (3,1,1) stride-1 pad-1 layers with 64 -> 64 channels and 8 frames
  * (models/network_blocks.py:37,42 in conv2x), forward and input gradient, when the layer's pre-split weights are passed

@@ -387,6 +387,41 @@ def test_stem_conv(which, gpu_device):
     assert relerr(wd.grad, wr.grad) < 5e-5
 
 
+@pytest.mark.parametrize("shp", [(2, 3, 8, 112, 112), (5, 3, 2, 38, 44), (2, 3, 4, 24, 28), (1, 3, 1, 112, 112)],
+                         ids=["clips_112", "ragged_tiles", "small", "one_frame"])
+def test_stem_fwd_presplit_patch(shp, gpu_device, kernel_log):
+    """stem_fwd3p_kernel (the patch split once at commit time into three bf16 planes, a lane's fragment = eight consecutive
+    columns of one row) against float64 and against stem_fwd3_kernel (fp32 patch, taps gathered and split per k-step): the same
+    products per (row, tap) at other k positions of the matrix instruction — outputs agree to rounding, BatchNorm partial sums
+    are the sums of what was written; temporal padding (one frame: two dead planes), ragged last tiles, both image borders."""
+    from avid_hip import lib, ops
+    k, stride, pad = (3, 7, 7), (1, 2, 2), (1, 3, 3)
+    x = T(detgen.det_normalish(f"stemp:{shp}:x", shp))
+    w = T(detgen.det_param(f"stemp:{shp}:w.weight", (64, 3) + k))
+    yr = F.conv3d(x.double(), w.double(), stride=stride, padding=pad)
+    wd = ops.make_weight(64, 3, *k)
+    wd.copy_(w)
+    xd, wd = x.to(gpu_device), wd.to(gpu_device)
+    pre = lib.raw("avid_stem_fwd_pre_configure")
+    res = {}
+    try:
+        for on in (1, 0):
+            pre(on)
+            with kernel_log() as log:
+                y, part = ops.conv_cl(xd, wd, stride, pad, channel_first=True, bn_stats=True)
+            assert log.launches("stem_fwd3_kernel") == 1, sorted(log.report)
+            res[on] = (ncdhw(y).cpu(), part.clone())
+    finally:
+        pre(-1)
+    for on in (1, 0):
+        y, part = res[on]
+        e = float((y.double() - yr).pow(2).mean().sqrt() / yr.pow(2).mean().sqrt())
+        assert e <= 6e-7, (on, e)                                    # the precision tests' bar (a three-product kernel: 4e-6)
+        yd = y.double().permute(0, 2, 3, 4, 1).reshape(-1, 64)
+        assert relerr(part[:, 1].double().sum(0).cpu(), (yd * yd).sum(0)) < 1e-5
+    assert relerr(res[1][0], res[0][0]) < 2e-6
+
+
 @pytest.mark.parametrize("which", ["video", "audio", "video_ragged"])
 def test_stem_bn_partials(which, gpu_device):
     """BatchNorm partial sums from the LDS-patch stem kernel's epilogue (one row per workgroup; the pixels past a

@@ -17,6 +17,8 @@ def short_name(name):
     short = m.group(1)
     if short == "wino2p_kernel":                  # wino2_kernel's default form (V split by the transform): the timers' name
         short = "wino2_kernel"
+    if short == "stem_fwd3p_kernel":              # stem_fwd3_kernel's default form (patch split at commit time): likewise
+        short = "stem_fwd3_kernel"
     if m.group(2):
         args = [a.strip() for a in m.group(2).split(",")]
         strided = False
