@@ -2999,7 +2999,7 @@ static void launch_pk_eb(const ConvArgs& a, int grid, size_t lds, hipStream_t s)
 // pre-split weights (ConvArgs::wsp) are consumed by the 128 x 64 tile with the epilogues convolution layers use
 template <int WM, int WN, int TM, int TN, int EPI>
 constexpr bool pk_takes_split() {
-  return PK_SPLIT && ((WM == 4 && WN == 1 && TM == 1 && TN == 2) || (WM == 2 && WN == 2 && TM == 2 && TN == 2)) &&
+  return PK_SPLIT && ((WM == 4 && WN == 1 && TM == 1 && (TN == 2 || TN == 4)) || (WM == 2 && WN == 2 && TM == 2 && TN == 2)) &&
          (EPI == 0 || EPI == 1 || EPI == 8 || EPI == 9);
 }
 // The 128 x 128 tile with pre-split weights (round 5): half the splits (8.1 -> ~5 vector instructions per matrix instruction), but
@@ -3019,6 +3019,18 @@ static int bs_wide_mode() {
     if (v < 0 || v > 2) v = 2;
   }
   return v;
+}
+// The 128 x 128 tile with pre-split weights as FOUR waves of 32 rows x 128 columns (igemm_pk_kernel<4,1,1,4,*>) instead of 2 x 2
+// waves of 64 x 64: no input fragment is shared by two waves any more, so each is split once (one split per 24 matrix
+// instructions instead of two); every wave reads all four column blocks' weight fragments from LDS (12 instead of 6 reads per
+// k-step).  AVID_BS_ROWS = 1 / 0.  Same products in the same order per output element: the outputs are bit-identical.
+static bool bs_rows() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AVID_BS_ROWS");
+    v = e ? (atoi(e) != 0 ? 1 : 0) : 1;
+  }
+  return v != 0;
 }
 static bool bs_wide(const PkPlan& pk) { return pk.tile == 0 && (bs_wide_mode() == 2 || (bs_wide_mode() == 1 && pk.full == 0)); }
 
@@ -3043,7 +3055,9 @@ static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + (STRIDED ? sizeof(int) * 2 * BM : 0);
   static char name[64] = "";
-  if (!name[0]) snprintf(name, sizeof(name), "igemm_pk_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, MODE, STRIDED ? "s2" : "");
+  // (the 128 x 128 tile as four waves of 32 rows x 128 columns is the same tile of the same plan: the timers pool it with <2,2,2,2>)
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_pk_kernel<%d,%d,%d,%d,%d>%s", TN == 4 ? 2 : WM, TN == 4 ? 2 : WN, TN == 4 ? 2 : TM,
+                         TN == 4 ? 2 : TN, MODE, STRIDED ? "s2" : "");
   const double K = (double)a.kt * a.kh * a.kw * a.Cs;
   const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
   // algorithmic work = the multiply-adds of the FORWARD convolution this launch belongs to: 2 * (output pixels) *
@@ -3412,7 +3426,12 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     magic_for(k.Td, k.mgT, k.shT);
     int rc;
     switch (pk.tile) {
-      case 0: rc = launch_pk<2, 2, 2, 2, MODE>(k, pk.grid, s); break;
+      case 0: {
+        const int e = epi_code<MODE>(k);      // (the epilogues the pre-split form is instantiated for: pk_takes_split)
+        const bool rows = k.wsp && bs_rows() && (e == 0 || e == 1 || e == 8 || e == 9);
+        rc = rows ? launch_pk<4, 1, 1, 4, MODE>(k, pk.grid, s) : launch_pk<2, 2, 2, 2, MODE>(k, pk.grid, s);
+        break;
+      }
       default: rc = launch_pk<4, 1, 1, 2, MODE>(k, pk.grid, s); break;
     }
     if (rc || pk.f == 1) return rc;

@@ -42,7 +42,7 @@ CLOSE = [{"AVID_GROUP_WGRAD": "0"}, {"AVID_WGRAD_BF16X3": "0"}, {"AVID_FUSE_BN_B
          {"AVID_CU_RESERVE": "8"},
          # conv2x's temporal layers through tconv64_kernel / twgrad64_kernel at this small batch too (the default rule wants
          # three rounds of tiles), pre-split weights for every launch of the 128 x 128 tile, the criterion kernel's variants
-         {"AVID_TCONV": "2"}, {"AVID_TCONV": "0"}, {"AVID_BS_WIDE": "1"}, {"AVID_BS_WIDE": "0"}, {"AVID_XM_ROWS": "128"}, {"AVID_XM_NT": "1"}]
+         {"AVID_TCONV": "2"}, {"AVID_TCONV": "0"}, {"AVID_BS_WIDE": "1"}, {"AVID_BS_WIDE": "0"}, {"AVID_BS_ROWS": "0"}, {"AVID_XM_ROWS": "128"}, {"AVID_XM_NT": "1"}]
 
 
 @pytest.mark.parametrize("env", IDENTICAL, ids=lambda e: ",".join(f"{k}={v if len(v) < 9 else '...'}" for k, v in e.items()))
