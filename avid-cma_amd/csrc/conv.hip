@@ -798,25 +798,51 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       const float* As = ASWZ ? cur + (wm * TM * 32 + l31) * ALD : Ab - h * 4 + h * 8;
       const int akey = (l31 >> 1) & 7;                 // ASWZ: piece c of this lane's rows sits at c ^ akey
       const char* Bc = reinterpret_cast<const char*>(cur + BM * ALD) + lane * 16;
-#pragma unroll
-      for (int st = 0; st < BK / 16; ++st) {
-        if (decltype(ST)::value && st == 0) store_stage(nxt);
-        if (decltype(LD)::value && st == 1) issue_loads();
-        pk_bf16x8 ah[TM], am[TM], al[TM];
+      // (-DAVID_PK_PREFETCH: all fragments of k-step st + 1 requested before the products of k-step st are issued — the compiler
+      // places every fragment read right in front of the matrix instructions that use it, "two reads, wait, six products".
+      // Measured on the 128 x 64 tile (134 -> 181 registers): nothing — `<4,1,1,2,0>` 0.509-0.514 against 0.514-0.520 ms per step,
+      // `<4,1,1,2,1>` 0.754-0.761 / 0.755-0.762, conv4x temporal 32.2 / 32.1 us: the LDS round trip of the fragments is not what a
+      // k-tile waits for either)
+      floatx4 ar[2][TM][2];
+      pk_bf16x8 bq[2][TN][3];
+      auto fetch = [&](int st, int slot) {
         const int o0 = ASWZ ? (((st * 4 + h * 2) ^ akey) << 2) : st * 16;
         const int o1 = ASWZ ? (((st * 4 + h * 2 + 1) ^ akey) << 2) : st * 16 + 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const floatx4 v0 = *reinterpret_cast<const floatx4*>(As + i * 32 * ALD + o0);
-          const floatx4 v1 = *reinterpret_cast<const floatx4*>(As + i * 32 * ALD + o1);
-          pk_split8(v0, v1, ah[i], am[i], al[i]);
+          ar[slot][i][0] = *reinterpret_cast<const floatx4*>(As + i * 32 * ALD + o0);
+          ar[slot][i][1] = *reinterpret_cast<const floatx4*>(As + i * 32 * ALD + o1);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const char* Bj = Bc + (((wn * TN + j) * 2 + st) * 3) * 1024;
-          const pk_bf16x8 bh = *reinterpret_cast<const pk_bf16x8*>(Bj);
-          const pk_bf16x8 bm = *reinterpret_cast<const pk_bf16x8*>(Bj + 1024);
-          const pk_bf16x8 bl = *reinterpret_cast<const pk_bf16x8*>(Bj + 2048);
+          bq[slot][j][0] = *reinterpret_cast<const pk_bf16x8*>(Bj);
+          bq[slot][j][1] = *reinterpret_cast<const pk_bf16x8*>(Bj + 1024);
+          bq[slot][j][2] = *reinterpret_cast<const pk_bf16x8*>(Bj + 2048);
+        }
+      };
+#ifdef AVID_PK_PREFETCH
+      constexpr bool PF = TM * TN <= 2 && !STRIDED;     // (the 128 x 128 tiles have no registers for a second set: spills)
+#else
+      constexpr bool PF = false;
+#endif
+      fetch(0, 0);
+#pragma unroll
+      for (int st = 0; st < BK / 16; ++st) {
+        if (PF) {
+          if (st + 1 < BK / 16) fetch(st + 1, (st + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (st > 0) {
+          fetch(st, st & 1);
+        }
+        if (decltype(ST)::value && st == 0) store_stage(nxt);
+        if (decltype(LD)::value && st == 1) issue_loads();
+        pk_bf16x8 ah[TM], am[TM], al[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) pk_split8(ar[st & 1][i][0], ar[st & 1][i][1], ah[i], am[i], al[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const pk_bf16x8 bh = bq[st & 1][j][0], bm = bq[st & 1][j][1], bl = bq[st & 1][j][2];
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
