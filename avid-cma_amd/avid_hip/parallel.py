@@ -178,6 +178,7 @@ class GradBuckets:
             self.counts[b] += 1
         self.pending = list(self.counts)
         self.launched = [False] * len(self.bounds)        # bucket b's collective has been issued this step
+        self.reported = [False] * len(flat.params)        # parameter i's gradient was reported (ready(i)) this step
         self.works = []
         self.hooks = []
         self.comm_used = []           # every collectives' stream a bucket went out on this step (normally one)
@@ -197,6 +198,7 @@ class GradBuckets:
         """Gradient of parameter i has been issued on ``stream`` (default: the current one) — autograd hook,
         ops.GradSlots for kernels that write the flat buffer directly, or a launch program's segment end: launch its
         bucket's all-reduce once the bucket is complete."""
+        self.reported[i] = True
         if not self.comm:
             return
         b = self.bucket_of[i]
@@ -309,10 +311,18 @@ class GradBuckets:
             if timed:
                 e1.record()
                 self.wait_events.append((e0, e1))
+        self.reset()
+
+    def reset(self):
+        """The per-step state as a step finds it.  ``finish()`` ends with it; DistributedDataParallel.forward starts with it, so a
+        backward pass that raised half-way (out of memory, 'backward a second time') cannot leave counts behind that keep the
+        next step's buckets from ever launching — torch's reducer does the same in prepare_for_backward."""
         self.works = []
+        self.comm_used = []
         self.step_set = None
         self.pending = list(self.counts)
         self.launched = [False] * len(self.bounds)
+        self.reported = [False] * len(self.flat.params)
         for p in self.producers:
             p.clear()
 
@@ -642,8 +652,30 @@ class _WrapperEngine(TrainStep):
 
     def _after_backward(self):
         self._armed = False
+        reported = list(self.buckets.reported)
         self.buckets.finish()
-        self.flat.seat_grads()
+        self._seat_reported(reported)
+
+    def _seat_reported(self, reported):
+        """`.grad` = the flat view for every parameter whose gradient was produced this step.  A parameter nothing reported
+        (frozen for this step, unused) keeps `.grad is None` if the caller's zero_grad(set_to_none=True) left it so — torch's DDP +
+        optimizer then skip it, and handing it the view would hand it the previous step's gradient — unless the buffer was
+        zeroed (avid_hip.parallel.Adam.zero_grad: the view is then a true zero gradient and stays seated)."""
+        flat = self.flat
+        if all(reported) or not any(reported):       # (launch programs report per segment: all of them; CPU / hook-less paths: none)
+            flat.seat_grads()
+            return
+        for p, v, r in zip(flat.params, flat.grad_views, reported):
+            if r:
+                if p.grad is not v:
+                    p.grad = v
+            elif p.grad is None:
+                v.zero_()                            # stale bytes must not reach an optimizer that reads the flat buffer
+
+    def begin_step(self):
+        """A new forward in training mode: whatever a failed backward pass left behind is dropped."""
+        self._armed = False
+        self.buckets.reset()
 
     def _plan_backward(self, pl, fa, video, audio, dv, da):
         self._arm()
@@ -681,6 +713,7 @@ class DistributedDataParallel(torch.nn.Module):
             return self.module(*inputs, **kwargs)
         from . import plan
         eng = self._engine
+        eng.begin_step()
         if eng.broadcast_buffers == "step":
             eng.sync_buffers()
         with plan.engine(eng):
@@ -697,7 +730,12 @@ class Adam(torch.optim.Optimizer):
     format (`state[i] = {step, exp_avg, exp_avg_sq}`), so checkpoints written by either load into the other.
 
     The parameters are used where they lie if they already are the views of one flat buffer (the model went through
-    `DistributedDataParallel` above or `TrainStep`), otherwise they are re-seated into one here.  One parameter group."""
+    `DistributedDataParallel` above or `TrainStep`), otherwise they are re-seated into one here.  One parameter group.
+
+    Differences from torch.optim.Adam, by construction of the one-launch step: `zero_grad()` always zero-fills (set_to_none is
+    accepted and ignored: `.grad` stays the view of the flat buffer), and `step()` updates EVERY parameter of the buffer — one
+    that received no gradient this step is stepped with a zero gradient (its moments decay, L2 weight decay still applies),
+    where torch.optim.Adam would skip a parameter whose `.grad` is None.  The reference freezes nothing (main-avid.py:106)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **unsupported):
         if amsgrad or any(unsupported.get(k) for k in ("maximize", "capturable", "differentiable")):
@@ -706,7 +744,18 @@ class Adam(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise NotImplementedError("avid_hip.parallel.Adam: one parameter group")
         ps = self.param_groups[0]["params"]
-        self.flat = flat_of(ps) or FlatParams(ps)
+        self.flat = flat_of(ps)
+        if self.flat is None:
+            # Some of them may already BE views of a live flat buffer (the model went through DistributedDataParallel / TrainStep)
+            # while the list is not exactly that buffer's set (extra trainable criterion parameters, a subset): re-seating them
+            # into a second buffer here would orphan the first — the launch programs and collectives would keep writing the
+            # engine's gradient buffer while this optimizer read its own zeros: a silent no-learning failure.
+            owned = [p for p in ps if _FLAT_OF.get(id(p)) is not None and _FLAT_OF[id(p)]() is not None]
+            if owned:
+                raise ValueError("avid_hip.parallel.Adam: %d of the %d parameters already live in a flat buffer (DistributedDataParallel / "
+                                 "TrainStep) but the list is not exactly that buffer's parameter set (or they were moved after it was built); "
+                                 "pass exactly the wrapped model's parameters, or use torch.optim.Adam for a different set" % (len(owned), len(ps)))
+            self.flat = FlatParams(ps)
         self.m = torch.zeros_like(self.flat.flat)
         self.v = torch.zeros_like(self.flat.flat)
         self._t = 0

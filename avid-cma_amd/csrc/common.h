@@ -58,6 +58,7 @@ size_t stem_wgrad_ws_bytes(const avid_conv_desc* d);
 int stem_fwd(const avid_conv_desc* d, const float* x, const float* w, float* y, float* stats, void* ws, hipStream_t s);
 int stem_fwd_grid(const avid_conv_desc* d);
 bool stem_fwd_is_split(const avid_conv_desc* d);     // runs as stem_fwd3_kernel (fp32-accurate split-bf16 products)
+bool stem_fwd_is_presplit(const avid_conv_desc* d);  // ... as stem_fwd3p_kernel (its patch split once, at commit time)
 int stem_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, hipStream_t s);
 
 // wino.hip: Winograd F(2x2, 3x3) forward / input gradient of the (1,3,3) stride-1 layers (mode 0 / 1)

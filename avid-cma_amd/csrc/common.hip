@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
 #include "common.h"
 
 namespace avid {
@@ -50,7 +51,9 @@ ScopedTimer::~ScopedTimer() {
 }
 
 // ---- CU budget of the persistent kernels (include/avid_hip.h: avid_set_cu_budget)
-static int g_cu_budget = -1;      // -1: not configured (AVID_CU_RESERVE from the environment on first use); 0: every CU
+// -1: not configured (AVID_CU_RESERVE from the environment on first use); 0: every CU.  Read from the forward thread and from
+// autograd's backward thread: atomic (relaxed; both would initialise it to the same value)
+static std::atomic<int> g_cu_budget{-1};
 
 static int physical_cus() {       // per device: a process may touch more than one
   static int cus[64] = {0};
@@ -67,20 +70,22 @@ static int physical_cus() {       // per device: a process may touch more than o
 
 int device_cus() {
   const int phys = physical_cus();
-  if (g_cu_budget < 0) {
+  int budget = g_cu_budget.load(std::memory_order_relaxed);
+  if (budget < 0) {
     const char* e = getenv("AVID_CU_RESERVE");
     const int reserve = e ? atoi(e) : 0;
-    g_cu_budget = reserve > 0 && reserve < phys ? phys - reserve : 0;
+    budget = reserve > 0 && reserve < phys ? phys - reserve : 0;
+    g_cu_budget.store(budget, std::memory_order_relaxed);
   }
-  if (g_cu_budget <= 0 || g_cu_budget >= phys) return phys;
+  if (budget <= 0 || budget >= phys) return phys;
   // whole CUs per XCD (the logical workgroup numberings deal a contiguous eighth of every round to each XCD), at least one
-  const int c = g_cu_budget / 8 * 8;
+  const int c = budget / 8 * 8;
   return c >= 8 ? c : 8;
 }
 }  // namespace avid
 
 extern "C" int avid_set_cu_budget(int cus) {
-  avid::g_cu_budget = cus > 0 ? cus : 0;
+  avid::g_cu_budget.store(cus > 0 ? cus : 0, std::memory_order_relaxed);
   return avid::device_cus();
 }
 

@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -2937,7 +2938,9 @@ static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_o
     //  measured and rejected in rounds 2 / 3: DESIGN.md 8c, 9.2)
   }
   const int ntn = Cd / k.BN;
-  const int C = cus / ntn * ntn;                    // CUs, a whole number of M-tiles
+  // CUs, a whole number of M-tiles — at least one (a CU budget below the column-block count, avid_set_cu_budget / AVID_CU_RESERVE
+  // with a wide Cd: one workgroup per column block is the smallest grid the deal below can express)
+  const int C = cus / ntn * ntn > 0 ? cus / ntn * ntn : ntn;
   const int G = per_cu * C;
   const long long mt_all = (M + k.BM - 1) / k.BM;
   const long long T = mt_all * ntn;
@@ -3060,7 +3063,9 @@ static bool bs_rows() {
 }
 static bool bs_wide(const PkPlan& pk) { return pk.tile == 0 && (bs_wide_mode() == 2 || (bs_wide_mode() == 1 && pk.full == 0)); }
 
-static long long g_presplit_launches = 0;    // avid_debug_presplit_launches (tests: which instruction sequence a layer ran)
+// avid_debug_presplit_launches (tests: which instruction sequence a layer ran); incremented from the forward thread and from
+// autograd's backward thread
+static std::atomic<long long> g_presplit_launches{0};
 
 template <int WM, int WN, int TM, int TN, int MODE, bool STRIDED, int EPI>
 static void launch_pk_e(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
@@ -3081,9 +3086,10 @@ static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const size_t lds = sizeof(float) * 2 * (BM + BN) * LDK + (STRIDED ? sizeof(int) * 2 * BM : 0);
   static char name[64] = "";
-  // (the 128 x 128 tile as four waves of 32 rows x 128 columns is the same tile of the same plan: the timers pool it with <2,2,2,2>)
-  if (!name[0]) snprintf(name, sizeof(name), "igemm_pk_kernel<%d,%d,%d,%d,%d>%s", TN == 4 ? 2 : WM, TN == 4 ? 2 : WN, TN == 4 ? 2 : TM,
-                         TN == 4 ? 2 : TN, MODE, STRIDED ? "s2" : "");
+  // (every instantiation under its own template arguments, as rocprofv3 names it: the 128 x 128 tile as four waves of 32 rows x 128
+  //  columns is igemm_pk_kernel<4,1,1,4,*>; the epilogue / pre-split arguments that follow MODE are pooled, here and in
+  //  tools/pmc_traffic.py)
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_pk_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, MODE, STRIDED ? "s2" : "");
   const double K = (double)a.kt * a.kh * a.kw * a.Cs;
   const double srcpix = (double)a.B * a.Ts * a.Hs * a.Ws;
   // algorithmic work = the multiply-adds of the FORWARD convolution this launch belongs to: 2 * (output pixels) *
@@ -3113,14 +3119,17 @@ static int launch_pk(const ConvArgs& a, int grid, hipStream_t s) {
 
 // ---- tconv64_kernel: which launches take it, and the launch
 constexpr int TCONV_PARTS_DEFAULT = 5;      // forward + weight gradient (the input gradient: see tconv_parts)
-static int g_tconv_mode = -1;     // -1: AVID_TCONV from the environment (default 1); 0 off; 1 layers with >= 3 rounds of tiles; 2 whenever it can
+// -1: AVID_TCONV from the environment (default 1); 0 off; 1 layers with >= 3 rounds of tiles; 2 whenever it can (atomic: see g_presplit_launches)
+static std::atomic<int> g_tconv_mode{-1};
 static int tconv_mode() {
-  if (g_tconv_mode < 0) {
+  int m = g_tconv_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
     const char* e = getenv("AVID_TCONV");
-    g_tconv_mode = e ? atoi(e) : 1;
-    if (g_tconv_mode < 0 || g_tconv_mode > 2) g_tconv_mode = 1;
+    m = e ? atoi(e) : 1;
+    if (m < 0 || m > 2) m = 1;
+    g_tconv_mode.store(m, std::memory_order_relaxed);
   }
-  return g_tconv_mode;
+  return m;
 }
 // Which of the three kernels the rule applies to: bit 0 forward, bit 1 input gradient, bit 2 weight gradient (AVID_TCONV_PARTS;
 // avid_tconv_configure(2) = tests: all three).  Default 5: the input gradient stays on igemm_pk_kernel IN THE STEP.  Layer
@@ -3624,10 +3633,10 @@ static bool conv_takes_split(const avid_conv_desc* d, int which) {
   return pk.tile == 1 || bs_wide(pk);
 }
 
-extern "C" long long avid_debug_presplit_launches(void) { return g_presplit_launches; }
+extern "C" long long avid_debug_presplit_launches(void) { return g_presplit_launches.load(std::memory_order_relaxed); }
 
 extern "C" int avid_tconv_configure(int mode) {
-  g_tconv_mode = (mode >= 0 && mode <= 2) ? mode : -1;
+  g_tconv_mode.store((mode >= 0 && mode <= 2) ? mode : -1, std::memory_order_relaxed);
   return tconv_mode();
 }
 
@@ -4300,7 +4309,10 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
   auto pk_name = [&](long long M, int Cd, int nk, int mode) {
     const PkPlan pk = plan_pk(M, Cd, nk, mode);
     static const char* kPk[] = {"2,2,2,2", "4,1,1,2", "4,2,2,2", "4,2,2,1", "2,1,2,2"};
-    snprintf(buf, len, "igemm_pk_kernel<%s,%d> full=%d tail_units=%d f=%d", kPk[pk.tile], mode, pk.full, pk.tail_units, pk.f);
+    // (the 128 x 128 tile of a layer that is handed its pre-split weights runs as four waves of 32 x 128 with the epilogues
+    //  convolution layers use — dispatch_igemm's `rows`; a caller that passes no table or a bias / ReLU epilogue gets <2,2,2,2>)
+    const char* tile = pk.tile == 0 && bs_rows() && conv_takes_split(d, mode) ? "4,1,1,4" : kPk[pk.tile];
+    snprintf(buf, len, "igemm_pk_kernel<%s,%d> full=%d tail_units=%d f=%d", tile, mode, pk.full, pk.tail_units, pk.f);
   };
   // conv2x's temporal layers (given their pre-split weights): tconv64_kernel — the descriptor-level form of tconv_takes
   const long long tc_tiles = ((long long)d->B * d->Hi * d->Wi + TC_P - 1) / TC_P;
@@ -4316,7 +4328,8 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
     const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
     if (!vec) {
       if (stem_fwd_supported(d))
-        snprintf(buf, len, stem_fwd_is_split(d) ? "stem_fwd3_kernel<%d,%d>" : "stem_fwd_kernel<%d,%d>", d->Cin, d->kt);
+        snprintf(buf, len, stem_fwd_is_split(d) ? (stem_fwd_is_presplit(d) ? "stem_fwd3p_kernel<%d,%d>" : "stem_fwd3_kernel<%d,%d>")
+                                                : "stem_fwd_kernel<%d,%d>", d->Cin, d->kt);
       else
         snprintf(buf, len, "igemm_gather_kernel<%s>", ((M + 127) / 128) * (d->Cout / 64) >= 256 ? "4,1,1,2" : "2,2,1,1");
     } else if (wino_supported(d, 0)) {

@@ -1477,7 +1477,7 @@ static int stem_fwd3_launch(const avid_conv_desc* d, const float* x, const float
     set = true;
   }
   const double M = (double)d->B * d->To * d->Ho * d->Wo, K = (double)CIN * KT * 49;
-  ScopedTimer t(s, "stem_fwd3_kernel<3,3>", 2.0 * M * 64 * K,
+  ScopedTimer t(s, pre ? "stem_fwd3p_kernel<3,3>" : "stem_fwd3_kernel<3,3>", 2.0 * M * 64 * K,
                 4.0 * ((double)d->B * CIN * d->Ti * d->Hi * d->Wi + 64 * K + M * 64));
   const int grid = a.ntiles < device_cus() ? a.ntiles : device_cus();
   if (pre && stem_fwd3p_tm() == 2) hipLaunchKernelGGL((stem_fwd3p_kernel<CIN, KT, 2>), dim3(grid), dim3(256), stem_fwd3p_lds(d), s, a);
@@ -1502,6 +1502,7 @@ int stem_fwd_grid(const avid_conv_desc* d) {
 }
 
 bool stem_fwd_is_split(const avid_conv_desc* d) { return stem_fwd_supported(d) && stem_fwd3_ok(d); }
+bool stem_fwd_is_presplit(const avid_conv_desc* d) { return stem_fwd_is_split(d) && stem_fwd3p_ok(d); }
 
 int stem_fwd(const avid_conv_desc* d, const float* x, const float* w, float* y, float* stats, void* ws, hipStream_t s) {
   if (stem_fwd3_ok(d)) return stem_fwd3_launch<3, 3>(d, x, w, y, stats, ws, s);

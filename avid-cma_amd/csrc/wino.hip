@@ -1661,11 +1661,13 @@ int wino_conv(const avid_conv_desc* d, int mode, const float* src, const float* 
   // direct form's 2.25x larger count, and not the padding of the 2 x 2 tiles that hang over an odd extent (7 x 7 frames
   // run 4 x 4 tiles: 31 % more matrix instructions than pixels / 4; round 4 counted those as achieved work);
   // bytes: source + destination (+ addend, + x of the BatchNorm-backward sums)
-  static const char* kNames[16] = {"wino_kernel<0>", "wino_kernel<1>", "wino_kernel<2>", "wino_kernel<3>",
+  static const char* kNames[24] = {"wino_kernel<0>", "wino_kernel<1>", "wino_kernel<2>", "wino_kernel<3>",
                                    "wino_kernel<4>", "wino_kernel<5>", "wino_kernel<6>", "wino_kernel<7>",
                                    "wino2_kernel<0>", "wino2_kernel<1>", "wino2_kernel<2>", "wino2_kernel<3>",
-                                   "wino2_kernel<4>", "wino2_kernel<5>", "wino2_kernel<6>", "wino2_kernel<7>"};
-  ScopedTimer t(s, kNames[(epi & 7) + 8 * a.v2], 2.0 * 16.0 * (M / 4.0) * a.Cr * a.Cn,
+                                   "wino2_kernel<4>", "wino2_kernel<5>", "wino2_kernel<6>", "wino2_kernel<7>",
+                                   "wino2p_kernel<0>", "wino2p_kernel<1>", "wino2p_kernel<2>", "wino2p_kernel<3>",
+                                   "wino2p_kernel<4>", "wino2p_kernel<5>", "wino2p_kernel<6>", "wino2p_kernel<7>"};
+  ScopedTimer t(s, kNames[(epi & 7) + 8 * (a.v2 ? (wino2_pre() ? 2 : 1) : 0)], 2.0 * 16.0 * (M / 4.0) * a.Cr * a.Cn,
                 4.0 * M * (a.Cr + a.Cn * (1 + (addend ? 1 : 0) + ((epi & 4) ? 1 : 0))));
   switch (epi) {
     case 0: wino_launch<0>(a, grid, s); break;

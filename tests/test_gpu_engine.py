@@ -309,7 +309,7 @@ def test_winograd_weight_tables_change_nothing(variant, helper_stream, gpu_devic
             rep = lib.timing_report()
             lib.timing_enable(False)
             n_weight = rep.get("wino_weight_kernel", {"launches": 0})["launches"]
-            n_wino = sum(v["launches"] for k, v in rep.items() if k.startswith("wino2_kernel<" if variant == "wino2" else "wino_kernel<"))
+            n_wino = sum(v["launches"] for k, v in rep.items() if k.startswith(("wino2_kernel<", "wino2p_kernel<") if variant == "wino2" else "wino_kernel<"))
             assert n_wino >= 18                                   # 9 layers, forward and input gradient
             if table:             # input gradients from the table, the forward transforms in the call
                 assert ts.twt.n_wino == n_wino // 2 and n_weight == n_wino // 2, (ts.twt.n_wino, n_wino, n_weight)

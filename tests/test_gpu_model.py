@@ -65,7 +65,7 @@ def test_blocks_vs_reference_golden(tag, golden, gpu_device, wino_mode, kernel_l
     # stride-1 3x3 layers of the block: both spatial convs of an unstrided block, the second one of a strided block
     n_s1 = 2 if all(v == 1 for v in stride) else 1
     assert log.launches("wino_kernel") == (2 * n_s1 if wino_mode == "wino_forced" else 0), sorted(log.report)
-    assert log.launches("wino2_kernel") == (2 * n_s1 if wino_mode == "wino2_forced" else 0), sorted(log.report)
+    assert log.launches("wino2p_kernel") + log.launches("wino2_kernel") == (2 * n_s1 if wino_mode == "wino2_forced" else 0), sorted(log.report)
 
     def close(a, ref, tol):
         a, ref = np.asarray(a, dtype=np.float64), np.asarray(ref, dtype=np.float64)
@@ -142,7 +142,7 @@ def test_av_wrapper_vs_reference_golden(golden, gpu_device, wino_mode, kernel_lo
         ((ve * gv).sum() + (ae * ga).sum()).backward()
     # video: 4 (conv2x) + 3 (conv3x) stride-1 spatial layers, audio: one in block 1, one in block 2; x 2 directions
     assert log.launches("wino_kernel") == (2 * 9 if wino_mode == "wino_forced" else 0), sorted(log.report)
-    assert log.launches("wino2_kernel") == (2 * 9 if wino_mode == "wino2_forced" else 0), sorted(log.report)
+    assert log.launches("wino2p_kernel") + log.launches("wino2_kernel") == (2 * 9 if wino_mode == "wino2_forced" else 0), sorted(log.report)
 
     def err(a, ref):
         a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
@@ -455,8 +455,8 @@ def test_full_step_vs_oracle_bs64(gpu_device):
     v1 = torch.nn.functional.normalize(torch.randn(N, 128, generator=g), dim=1)
     v2 = torch.nn.functional.normalize(torch.randn(N, 128, generator=g), dim=1)
     report = _full_step_vs_oracle(gpu_device, bs, N, K, video, audio, y, idx, v1, v2, 2.5e8, flip_bound=2e-4)
-    wino = sum(v["launches"] for k, v in report.items() if k.startswith(("wino_kernel", "wino2_kernel")))
-    assert any(k.startswith("wino2_kernel") for k in report)      # conv2x / conv3x have the 64-tile units wino2_kernel wants
+    wino = sum(v["launches"] for k, v in report.items() if k.startswith(("wino_kernel", "wino2_kernel", "wino2p_kernel")))
+    assert any(k.startswith("wino2p_kernel") for k in report)     # conv2x / conv3x have the 64-tile units wino2_kernel wants; its default form is wino2p_kernel
     # conv2x 4 + conv3x 3 + conv4x 3 layers of the video tower and the stride-1 layer of audio block 1, forward and
     # input gradient
     assert wino == 22, (wino, sorted(report))

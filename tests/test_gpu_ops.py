@@ -94,9 +94,9 @@ def test_conv_fwd_dgrad_wgrad(case, gpu_device, kernel_log, wino_variant):
     if wino_variant == "wino2":
         assert log.launches("wino_kernel") == 0
     if name in WINO_CASES:          # forward and input gradient really took the Winograd kernel
-        assert log.launches("wino_kernel") + log.launches("wino2_kernel") == 2 and log.launches("wino_wgrad_kernel") == 1, log.report.keys()
+        assert log.launches("wino_kernel") + log.launches("wino2_kernel") + log.launches("wino2p_kernel") == 2 and log.launches("wino_wgrad_kernel") == 1, log.report.keys()
     else:
-        assert log.launches("wino_kernel") + log.launches("wino2_kernel") == 0 and log.launches("wino_wgrad_kernel") == 0
+        assert log.launches("wino_kernel") + log.launches("wino2_kernel") + log.launches("wino2p_kernel") == 0 and log.launches("wino_wgrad_kernel") == 0
 
 
 @pytest.mark.parametrize("mode", [5, 6])
@@ -409,7 +409,8 @@ def test_stem_fwd_presplit_patch(shp, gpu_device, kernel_log):
             pre(on)
             with kernel_log() as log:
                 y, part = ops.conv_cl(xd, wd, stride, pad, channel_first=True, bn_stats=True)
-            assert log.launches("stem_fwd3_kernel") == 1, sorted(log.report)
+            # which form ran, from the launch log: the timers name the two kernels apart
+            assert log.launches("stem_fwd3p_kernel") == (1 if on else 0) and log.launches("stem_fwd3_kernel") == (0 if on else 1), sorted(log.report)
             res[on] = (ncdhw(y).cpu(), part.clone())
     finally:
         pre(-1)
@@ -1033,7 +1034,9 @@ def test_wino2_presplit_is_bit_identical(shape, cin, cout, gpu_device, kernel_lo
                 y2 = ops.conv_cl(hh, w, (1, 1, 1), (0, 1, 1), bn_src=src)
                 (y2 * gy).sum().backward()
                 out += [y2.detach(), xx.grad, g_.grad, b_.grad]
-            assert log.launches("wino2_kernel") >= 5 and log.launches("wino_kernel") == 0, sorted(log.report)
+            # which form ran, from the launch log: wino2p_kernel (V split once) with the switch on, wino2_kernel with it off
+            assert log.launches("wino2p_kernel" if on else "wino2_kernel") >= 5 and log.launches("wino2_kernel" if on else "wino2p_kernel") == 0 \
+                and log.launches("wino_kernel") == 0, sorted(log.report)
             res[on] = [t.clone() for t in out]
     finally:
         pre(-1)

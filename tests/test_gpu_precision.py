@@ -44,16 +44,17 @@ def rms_rel(got, want64):
 CASES = [
     # both stems' split-bf16 kernels: forward and weight gradient of models/video.py:20 at two clips
     ("stem", 3, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3), (2, 8, 112, 112), True, False,
-     ("stem_fwd3_kernel", "stem_wgrad3_kernel")),
+     ("stem_fwd3p_kernel", "stem_wgrad3_kernel")),
     # 128 x 64 tile, weights pre-split (avid_wt_desc mode 5 / 6), input rows split in registers; wgrad_tab_kernel<1,3>
     ("pk_128x64_temporal", 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (3, 7, 40, 41), False, False,
      ("igemm_pk_kernel<4,1,1,2,0>", "igemm_pk_kernel<4,1,1,2,1>", "wgrad_tab_kernel")),
-    # 128 x 128 tile: both fragments split in registers; wgrad_tab_kernel<2,2> (conv3x temporal at 32 clips)
+    # 128 x 128 tile, weights pre-split, as four waves of 32 x 128 (every input fragment split once); wgrad_tab_kernel<2,2>
+    # (conv3x temporal at 32 clips)
     ("pk_128x128_temporal", 128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (32, 4, 14, 14), False, False,
-     ("igemm_pk_kernel<2,2,2,2,0>", "igemm_pk_kernel<2,2,2,2,1>", "wgrad_tab_kernel<2,2>")),
+     ("igemm_pk_kernel<4,1,1,4,0>", "igemm_pk_kernel<4,1,1,4,1>", "wgrad_tab_kernel<2,2>")),
     # 128 x 128 tile with a nine-way K-split + reduce (conv4x spatial off the Winograd path: 1568 pixels)
     ("pk_128x128_ksplit", 256, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (16, 2, 7, 7), False, False,
-     ("igemm_pk_kernel<2,2,2,2,0>", "igemm_pk_kernel<2,2,2,2,1>", "wgrad_tab_kernel<2,2>")),
+     ("igemm_pk_kernel<4,1,1,4,0>", "igemm_pk_kernel<4,1,1,4,1>", "wgrad_tab_kernel<2,2>")),
     # the longest contraction of the network (conv5x spatial, K = 4608, sixteen-way K-split + reduce)
     ("pk_K4608", 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), (16, 1, 4, 4), False, False,
      ("igemm_pk_kernel<4,1,1,2,0>", "igemm_pk_kernel<4,1,1,2,1>", "wgrad_tab_kernel<2,2>")),
@@ -67,8 +68,8 @@ CASES = [
     ("tconv64", 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (5, 8, 27, 29), False, False,
      ("tconv64_kernel<0>", "tconv64_kernel<1>", "twgrad64_kernel")),
     # Winograd F(2x2,3x3) with split-bf16 products (wino2_kernel, forward and input gradient)
-    ("wino2_64", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 8, 48, 48), False, True, ("wino2_kernel",)),
-    ("wino2_128", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (9, 4, 27, 29), False, True, ("wino2_kernel",)),
+    ("wino2_64", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (4, 8, 48, 48), False, True, ("wino2p_kernel",)),
+    ("wino2_128", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (9, 4, 27, 29), False, True, ("wino2p_kernel",)),
 ]
 BAR = 6e-7          # rms(err) / rms(output) against float64
 
@@ -231,7 +232,7 @@ def test_uses_split_agrees_with_the_kernel_that_ran(gpu_device, kernel_log):
         fwd_kernel = names[0].split(" ")[0]
         assert log.launches(fwd_kernel) == 1, (names, sorted(log.report))
         if cf:
-            assert fwd_kernel.startswith("stem_fwd3_kernel") and d.split_fwd is False      # (its own split: no table)
+            assert fwd_kernel.startswith("stem_fwd3p_kernel") and d.split_fwd is False      # (its own split: no table)
         elif not d.wino_dgrad and "sub-sampled" not in names[1]:
             assert log_b.launches(names[1].split(" ")[0]) == 1, (names, sorted(log_b.report))
     assert seen_split >= 4 and seen_plain >= 3

@@ -68,3 +68,41 @@ def test_lab_kernels_still_compile(name, tmp_path):
     out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-c", "--cuda-device-only", src, "-o", str(tmp_path / "o.o")],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-800:]
+
+
+# ---- register / scratch budget of the kernels the bs-64 step launches: read from the code objects'
+# metadata notes of the built library (tools/kernel_resources.py).  STEP_KERNELS are the instantiations rocprofv3 sees in a
+# default bench.py run (profiles/r0*_kernel_stats.csv); ALLOWED lists the ones that still carry a private segment, with the
+# bytes they are allowed — a number here may only go down.
+STEP_KERNEL_PREFIXES = ("igemm_pk_kernel<4, 1, 1, 2, 0, false, 0, true>", "igemm_pk_kernel<4, 1, 1, 2, 0, false, 1, true>",
+                        "igemm_pk_kernel<4, 1, 1, 2, 0, false, 2, false>", "igemm_pk_kernel<4, 1, 1, 2, 0, false, 3, false>",
+                        "igemm_pk_kernel<4, 1, 1, 2, 1, false, 0, true>", "igemm_pk_kernel<4, 1, 1, 2, 1, false, 8, true>",
+                        "igemm_pk_kernel<4, 1, 1, 2, 1, false, 9, true>", "igemm_pk_kernel<4, 1, 1, 2, 1, true, 8, true>",
+                        "igemm_pk_kernel<4, 1, 1, 2, 1, true, 9, true>", "igemm_pk_kernel<4, 1, 1, 4, 0, false, 0, true>",
+                        "igemm_pk_kernel<4, 1, 1, 4, 0, false, 1, true>", "igemm_pk_kernel<4, 1, 1, 4, 1, false, 8, true>",
+                        "igemm_pk_kernel<2, 2, 2, 2, 1, true, 8, false>", "igemm_pk_kernel<2, 2, 2, 2, 1, true, 9, false>",
+                        "wino2p_kernel<1>", "wino2p_kernel<2>", "wino2p_kernel<4>", "wino2p_kernel<6>",
+                        "wino_kernel<1>", "wino_kernel<4>", "wino_kernel<6>", "wino_wgrad_kernel", "tconv64_kernel<0, 0>",
+                        "tconv64_kernel<0, 1>", "twgrad64_kernel", "stem_fwd3p_kernel<3, 3, 1>", "stem_wgrad3_kernel<3, 3, true>",
+                        "wgrad_group_kernel<true, true>", "wgrad_tab_kernel<1, 3, true>", "xmodal_fused_kernel<false, 64, false>",
+                        "adam_flat_kernel", "bn_apply_kernel", "bn_bwd_apply_kernel", "bn_fin_apply_kernel", "bn_bwd_fin_apply_kernel")
+SCRATCH_ALLOWED = {          # name: (vgpr spills, private-segment bytes) — round 5's state where round 6 has not removed it yet
+    "igemm_pk_kernel<4, 1, 1, 2, 1, true, 8, true>": (0, 68), "igemm_pk_kernel<4, 1, 1, 2, 1, true, 9, true>": (0, 68),
+    "igemm_pk_kernel<2, 2, 2, 2, 1, true, 8, false>": (0, 100), "igemm_pk_kernel<2, 2, 2, 2, 1, true, 9, false>": (43, 272),
+    "wino2p_kernel<4>": (13, 56), "wino2p_kernel<6>": (23, 96),
+    "wino_kernel<1>": (14, 60), "wino_kernel<4>": (22, 92), "wino_kernel<6>": (24, 100),
+}
+
+
+def test_step_kernels_have_no_scratch():
+    from tools_path import kernel_table
+    rows = {r["name"]: r for r in kernel_table()}
+    missing = [k for k in STEP_KERNEL_PREFIXES if k not in rows]
+    assert not missing, ("instantiations the step is supposed to launch are not in libavid_hip.so", missing)
+    bad = {}
+    for k in STEP_KERNEL_PREFIXES:
+        r = rows[k]
+        spills, scratch = SCRATCH_ALLOWED.get(k, (0, 0))
+        if r["vgpr_spill_count"] > spills or r["private_segment_fixed_size"] > scratch:
+            bad[k] = (r["vgpr_spill_count"], r["private_segment_fixed_size"])
+    assert not bad, f"(vgpr spills, scratch bytes) of step kernels: {bad}"

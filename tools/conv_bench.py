@@ -85,9 +85,9 @@ for name, cin, cout, k, st, pd, (T, H, W) in L:
     def pick_w(rep, mode):     # the Winograd path: kernel + its weight transform
         t = 0.0; names = []
         for n, v in rep.items():
-            if n.startswith(("wino_kernel<", "wino2_kernel<", "winot_kernel<")) or n == "wino_weight_kernel":
+            if n.startswith(("wino_kernel<", "wino2_kernel<", "wino2p_kernel<", "winot_kernel<")) or n == "wino_weight_kernel":
                 t += v["ms"]; names.append(n)
-        return t / reps * 1e3, [n for n in names if n.startswith(("wino_kernel", "wino2_kernel", "winot_kernel"))]
+        return t / reps * 1e3, [n for n in names if n.startswith(("wino_kernel", "wino2_kernel", "wino2p_kernel", "winot_kernel"))]
     f_us, fn = pick(res["fwd"], "igemm_", 0)
     tf_us, tfn = pick(res["fwd"], "tconv64_kernel<0>")
     f_us += tf_us; fn += tfn

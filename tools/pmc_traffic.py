@@ -1,40 +1,18 @@
 """profiles/<pmc_summary>.csv (+ the kernel trace of the same run for launch counts) -> profiles/pmc_traffic.json:
 HBM bytes per launch per kernel = (2 * FETCH_SIZE + WRITE_SIZE) KiB / launches  (FETCH_SIZE is doubled as
 MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is uncalibrated there and taken as is).
-Keys are the names the library's HIP-event timers (and bench.py) use: the epilogue variants of igemm_pk_kernel
-(its last template argument) are one kernel there, so their bytes and launches are pooled."""
-import csv, json, re, sys, collections
+Keys are the names the library's HIP-event timers (and bench.py) use = rocprofv3's names without the namespace: every
+kernel under its own template arguments; only the trailing epilogue / pre-split arguments of igemm_pk_kernel and tconv64_kernel
+(one kernel per layer shape to the timers) are pooled."""
+import csv, json, os, re, sys, collections
 summary, trace, out = sys.argv[1], sys.argv[2], sys.argv[3]
 calls = collections.Counter()
 for r in csv.DictReader(open(trace)):
     calls[r["Kernel_Name"].split("(")[0]] += 1
 
 
-def short_name(name):
-    m = re.match(r"(?:void )?avid::(\w+)(?:<(.*)>)?", name)
-    if not m:
-        return None
-    short = m.group(1)
-    if short == "wino2p_kernel":                  # wino2_kernel's default form (V split by the transform): the timers' name
-        short = "wino2_kernel"
-    if short == "stem_fwd3p_kernel":              # stem_fwd3_kernel's default form (patch split at commit time): likewise
-        short = "stem_fwd3_kernel"
-    if m.group(2):
-        args = [a.strip() for a in m.group(2).split(",")]
-        strided = False
-        if short == "igemm_pk_kernel" and len(args) >= 7:          # <WM,WN,TM,TN,MODE,STRIDED,EPI>
-            strided, args = args[5] == "true", args[:5]
-        elif short == "tconv64_kernel" and len(args) >= 2:                # <MODE,EPI>: the timers pool the epilogue variants
-            args = args[:1]
-        elif short.startswith(("igemm", "stem")) and args[-1] in ("true", "false"):   # trailing bool = STRIDED
-            strided, args = args[-1] == "true", args[:-1]
-        elif short in ("xmodal_fused_kernel", "xmodal_finish_kernel") and args[-1] in ("true", "false"):   # <CMA>: the timers' names
-            short = short.replace("xmodal", "cma") if args[-1] == "true" else short
-            args = args[:-1]
-        elif short.startswith("wgrad_") and args[-1] in ("true", "false"):            # trailing bool = SPLIT (split-bf16 products): same timer name
-            args = args[:-1]
-        short += ("<" + ",".join(args) + ">" if args else "") + ("s2" if strided else "")
-    return short
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import timer_name as short_name      # rocprofv3's name -> the library timers' name
 
 
 tot_bytes, tot_calls = collections.Counter(), collections.Counter()
