@@ -81,6 +81,11 @@ struct ConvArgs {
   int bnb_relu;
   int pk_rot;      // tail unit u runs on workgroup (u + pk_rot) mod G: the ones that got one full tile less
   int pk_paired;   // grid = 2 workgroups per CU: number them so that v and v + G/2 share a CU
+  // Weight-stationary order of the tail units (0: tile-major — unit u = (tile u / f, piece u % f): the pieces and column blocks
+  // of an M-tile are neighbours; > 0 = the tail's M-tile count: unit u = (M-tile u % mtt, piece (u / mtt) % f, column block
+  // u / mtt / f): the M-tiles of one (column block, K piece) are neighbours — consecutive units sit on one XCD, so each weight
+  // byte is fetched into ONE L2 and the (small) activations are what the XCDs replicate: plan_pk_order)
+  int pk_ws;
   // igemm_pk_kernel<..., BS>: the weights pre-split into three bf16 terms, in the kernel's operand-fragment order
   // (avid_wt_desc mode 5 / 6): base of the first live tap's chunks, bytes addressable from it, bytes between two k-tiles
   const void* wsp;
@@ -499,7 +504,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       }
     }
     __syncthreads();
-    const int nb = slot % ntn;                           // this workgroup's column block
+    // this workgroup's column block (weight-stationary tails — no full tiles then: plan_pk_order — deal column blocks by unit)
+    const int nb = p.pk_ws ? (tslot < p.pk_tail_units ? (tslot / p.pk_ws / p.pk_f) % ntn : 0) : slot % ntn;
     float* row = p.stats + (long long)slot * 2 * p.Cd;
     for (int c = tid; c < p.Cd; c += NT) {
       float a = 0.f, b = 0.f;
@@ -541,8 +547,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     } else if (j < n_full) {
       tile = slot + j * G; k0 = 0; k1 = nk; split = -1;
     } else {
-      tile = p.pk_full + tslot / p.pk_f;
-      const int piece = tslot % p.pk_f;
+      int piece;
+      if (p.pk_ws) {                            // weight-stationary order (ConvArgs::pk_ws = M-tiles of the tail)
+        const int r = tslot / p.pk_ws, mt = tslot - r * p.pk_ws;
+        const int nt = r / p.pk_f;
+        piece = r - nt * p.pk_f;
+        tile = p.pk_full + mt * ntn + nt;
+      } else {
+        tile = p.pk_full + tslot / p.pk_f;
+        piece = tslot % p.pk_f;
+      }
       split = p.pk_f > 1 ? piece : -1;          // unsplit tail tiles take the direct epilogue
       k0 = piece * p.pk_kps;
       k1 = k0 + p.pk_kps < nk ? k0 + p.pk_kps : nk;
@@ -2991,6 +3005,91 @@ static PkPlan plan_pk(long long M, int Cd, int nk, int mode) {
   return c1 * 1.04 < c0 ? narrow : wide;
 }
 
+// ---- order of the tail units: tile-major or weight-stationary (ConvArgs::pk_ws).
+// The hardware deals workgroup ids round-robin to the 8 XCDs; the kernel's logical slots give every XCD contiguous runs of
+// units, and each XCD's L2 fetches what its units read.  Tile-major (round 2): the K pieces and column blocks of an M-tile are
+// neighbours — each activation row is fetched by one XCD, and every XCD fetches ALL weights; right for the wide layers (conv2x,
+// conv3x: MBs of activations against KBs of weights).  conv4x / conv5x / audio blocks 3-4 are the other way round (9.4 MB of
+// weights, 14 MB pre-split, against 2 MB of activations): profiles/r05_f counted 3.5x the algorithmic bytes at the L2s' memory
+// side.  Weight-stationary: M-tile fastest, then K piece, then column block — an XCD's run covers all M-tiles of a few (column
+// block, K piece) weight blocks: each weight byte goes to ONE L2, the activations are what replicates.  Both orders are priced
+// with the L2 fills they cause under the kernel's slot -> XCD map (distinct weight blocks + distinct (M-tile, channel block)
+// activation blocks per XCD, taps assumed to re-use their rows) and the cheaper one is taken — weight-stationary only with a
+// 20 % margin (the tap re-use is optimistic for temporal layers) and only for tails without full tiles (the BatchNorm partial
+// row of a workgroup covers ONE column block: igemm_pk_kernel's write_stats).  Outputs do not depend on the order: a unit
+// computes the same (tile, K range) and the slabs are summed in piece order.  AVID_PK_WS: 0 never, 1 (default) by the model,
+// 2 whenever the tail has no full tiles.
+static int pk_ws_mode() {
+  static std::atomic<int> v{-1};
+  int m = v.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("AVID_PK_WS");
+    m = e ? atoi(e) : 1;
+    if (m < 0 || m > 2) m = 1;
+    v.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+static int pk_slot_xcd(int slot, int G, bool paired) {      // mirrors igemm_pk_kernel's slot numbering (pk_paired / xcd_remap)
+  if (paired) return (slot % (G >> 1)) / (G >> 4);
+  if (G < 8) return slot;
+  const int q = G / 8, r = G % 8;
+  return slot < r * (q + 1) ? slot / (q + 1) : r + (slot - r * (q + 1)) / q;
+}
+static double pk_order_bytes(const PkPlan& pk, int ntn, int mtt, int nk, int cpt, double wbytes, bool ws) {
+  if (mtt > 512 || ntn * pk.f > 1024) return 1e300;
+  double total = 0.0;
+  const int cb = cpt < 64 ? cpt : 64;
+  for (int x = 0; x < 8; ++x) {
+    bool wblk[1024] = {false};
+    unsigned long long ablk[512] = {0};
+    for (int u = 0; u < pk.tail_units; ++u) {
+      if (pk_slot_xcd((u + pk.rot) % pk.grid, pk.grid, pk.paired) != x) continue;
+      int mt, nt, piece;
+      if (ws) { const int r = u / mtt; mt = u - r * mtt; nt = r / pk.f; piece = r - nt * pk.f; }
+      else { const int t = u / pk.f; piece = u - t * pk.f; mt = t / ntn; nt = t - mt * ntn; }
+      wblk[nt * pk.f + piece] = true;
+      const int k0 = piece * pk.kps, k1 = k0 + pk.kps < nk ? k0 + pk.kps : nk;
+      if (k1 - k0 >= cb) ablk[mt] = ~0ull;
+      else for (int k = k0; k < k1; ++k) ablk[mt] |= 1ull << ((k % cpt) & 63);
+    }
+    int nw = 0, na = 0;
+    for (int i = 0; i < ntn * pk.f; ++i) nw += wblk[i] ? 1 : 0;
+    for (int i = 0; i < mtt; ++i) na += ablk[i] == ~0ull ? cb : __builtin_popcountll(ablk[i]);
+    total += (double)nw * pk.BN * pk.kps * BK * wbytes + (double)na * pk.BM * BK * 4.0;
+  }
+  return total;
+}
+// ConvArgs::pk_ws of a planned launch (0: tile-major), memoised: the launch programs call this once per layer and step
+static int plan_pk_order(const PkPlan& pk, long long M, int Cd, int nk, int cpt, bool presplit) {
+  const int mode = pk_ws_mode();
+  if (mode == 0 || pk.full != 0 || pk.tail_units == 0 || cpt <= 0) return 0;
+  const int ntn = Cd / pk.BN;
+  const int mtt = (int)((M + pk.BM - 1) / pk.BM);
+  if (mtt * ntn * pk.f != pk.tail_units || mtt < 2) return 0;
+  if (mode == 2) return mtt;
+  // (an unsplit tail leaves its BatchNorm partial sums in the workgroups' rows: another order of the units would add them in
+  //  another order — the model only re-orders K-split tails, whose sums come out of the reduce; outputs stay bit-identical)
+  if (pk.f == 1) return 0;
+  struct Entry { long long M; int Cd, nk, cpt, presplit, grid, f, rot, cus, ws; };
+  static Entry cache[64];
+  static std::atomic_flag lock = ATOMIC_FLAG_INIT;
+  const unsigned h = (unsigned)((M * 2654435761ull + (unsigned)Cd * 40503u + (unsigned)nk * 97u + (unsigned)cpt * 7u + (presplit ? 1 : 0) +
+                                 (unsigned)pk.grid * 31u + (unsigned)pk.f * 131u) & 63u);
+  while (lock.test_and_set(std::memory_order_acquire)) {}
+  Entry& e = cache[h];
+  const int cus = device_cus();
+  if (!(e.cus == cus && e.M == M && e.Cd == Cd && e.nk == nk && e.cpt == cpt && e.presplit == (presplit ? 1 : 0) && e.grid == pk.grid &&
+        e.f == pk.f && e.rot == pk.rot)) {
+    const double wb = presplit ? 6.0 : 4.0;
+    const double tile_major = pk_order_bytes(pk, ntn, mtt, nk, cpt, wb, false), stationary = pk_order_bytes(pk, ntn, mtt, nk, cpt, wb, true);
+    e = Entry{M, Cd, nk, cpt, presplit ? 1 : 0, pk.grid, pk.f, pk.rot, cus, stationary * 1.2 < tile_major ? mtt : 0};
+  }
+  const int ws = e.ws;
+  lock.clear(std::memory_order_release);
+  return ws;
+}
+
 // n / d == (n * magic) >> shift for every n < 2^31 (d >= 1)
 static void magic_for(int d, unsigned& magic, int& shift) {
   int l = 0;
@@ -3376,6 +3475,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     k.pk_f = 1;
     k.pk_kps = 0;
     k.pk_rot = 0;
+    k.pk_ws = 0;
     const int cus = device_cus();
     const int grid = pl.grid;
     k.pk_paired = (grid == 2 * cus && grid % 16 == 0) ? 1 : 0;
@@ -3453,6 +3553,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
     k.pk_kps = pk.kps;
     k.pk_rot = pk.rot;
     k.pk_paired = pk.paired ? 1 : 0;
+    k.pk_ws = plan_pk_order(pk, a.M, a.Cd, nk_total, a.Cs / BK, a.wsp != nullptr);
     k.stats = (MODE == 0 || a.bnb_x) ? a.stats : nullptr;
     k.part = static_cast<float*>(ws);
     k.part_row_begin = (int)pk.tail_row0;
@@ -3585,7 +3686,7 @@ int sim_gemm_nt(const float* A, const float* Bq, float* Cout_, const float* Cin,
                 hipStream_t s) {
   AVID_REQUIRE(N % 64 == 0 && K % 32 == 0 && M > 0 && M < (1ll << 31), AVID_E_UNSUPPORTED,
                "sim_gemm: need N %% 64 == 0, K %% 32 == 0 (N=%d K=%d)", N, K);
-  ConvArgs a;
+  ConvArgs a{};
   a.kt = a.kh = a.kw = 1; a.st = a.sh = a.sw = 1; a.pt = a.ph = a.pw = 0;
   a.B = 1; a.Ts = 1; a.Hs = 1; a.Ws = (int)M; a.Cs = K;
   a.Td = 1; a.Hd = 1; a.Wd = (int)M; a.Cd = N;
@@ -3698,7 +3799,7 @@ extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const floa
       return wino_conv(d, 0, x, w, u, y, addend, bn_partials, nullptr, ws, (hipStream_t)stream);
   }
   const Trim tr = trim_taps(d);
-  ConvArgs a;
+  ConvArgs a{};
   fill_common(a, &tr.d);
   a.src = x; a.addend = addend; a.bias = bias; a.dst = y;
   {   // weights: the live temporal taps of every [kt][kh][kw][Cin] row
@@ -3797,7 +3898,7 @@ extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
   if (d->st > 1 || d->sh > 1 || d->sw > 1) {   // strided: the plan of dispatch_igemm<1>'s parity-class branch
     if (M * d->Cin * 4 >= (1ll << 31)) return 0;
     const Trim tr = trim_taps(d);
-    ConvArgs a;
+    ConvArgs a{};
     fill_common(a, &tr.d);
     a.Td = d->Ti; a.Hd = d->Hi; a.Wd = d->Wi; a.Cd = d->Cin;
     const int BN = d->Cin % 128 == 0 ? 128 : 64;
@@ -3873,7 +3974,7 @@ extern "C" int avid_conv_dgrad(const avid_conv_desc* d, const float* dy, const f
     wt = wt_ws;
   }
   const Trim tr = trim_taps(d);
-  ConvArgs a;
+  ConvArgs a{};
   fill_common(a, &tr.d);
   a.src = dy; a.addend = addend; a.bias = nullptr; a.dst = dx;
   {   // transposed weights [Cin][kt][kh][kw][Cout]: the live temporal taps of every row
@@ -4312,7 +4413,10 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
     // (the 128 x 128 tile of a layer that is handed its pre-split weights runs as four waves of 32 x 128 with the epilogues
     //  convolution layers use — dispatch_igemm's `rows`; a caller that passes no table or a bias / ReLU epilogue gets <2,2,2,2>)
     const char* tile = pk.tile == 0 && bs_rows() && conv_takes_split(d, mode) ? "4,1,1,4" : kPk[pk.tile];
-    snprintf(buf, len, "igemm_pk_kernel<%s,%d> full=%d tail_units=%d f=%d", tile, mode, pk.full, pk.tail_units, pk.f);
+    const int cs = mode == 0 ? d->Cin : d->Cout;
+    const int ws = plan_pk_order(pk, M, Cd, nk, cs / BK, conv_takes_split(d, mode));
+    snprintf(buf, len, "igemm_pk_kernel<%s,%d> full=%d tail_units=%d f=%d%s", tile, mode, pk.full, pk.tail_units, pk.f,
+             ws ? " weight-stationary" : "");
   };
   // conv2x's temporal layers (given their pre-split weights): tconv64_kernel — the descriptor-level form of tconv_takes
   const long long tc_tiles = ((long long)d->B * d->Hi * d->Wi + TC_P - 1) / TC_P;

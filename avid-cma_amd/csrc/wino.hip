@@ -1248,6 +1248,26 @@ __global__ __launch_bounds__(256) void wino2p_kernel(const WinoArgs p) {
 //   epilogue: G^T . G in registers — columns j inside a wave, rows i as two partial sums; the e = 1 waves hand theirs
 //   over through LDS, the e = 0 waves write the block as dw[n][3][3][c] into this split's slab; wgrad_reduce_kernel
 //   (csrc/conv.hip) sums the slabs in fixed order.
+// Development switches of wino_wgrad_kernel (tools/build_variant.sh NAME wino "-DAVID_WW_DBG=n"; results are WRONG with any of
+// them: timing only).  1: no global loads; 2: no transform / LDS stores of the next chunk; 4: no barrier per chunk; 8: the products
+// as one vector multiply-add each (fragment reads stay); 16: no fragment reads (the products on registers).
+#ifndef AVID_WW_DBG
+#define AVID_WW_DBG 0
+#endif
+constexpr int WW_DBG = AVID_WW_DBG;
+// -DAVID_WW_TRACE: shader cycles per wave, summed over its chunks — [0] k-step 0 (products + transform of the next chunk),
+// [1] k-step 1 (+ the loads of the chunk after), [2] k-steps 2-3, [3] at the barrier, [4] first half of k-step 0 (the left factor),
+// [6] / [7] shader cycles / 10 ns ticks over the loop; tools/wino_wgrad_trace.py
+#ifdef AVID_WW_TRACE
+__device__ long long g_ww_trace[1024 * 8 * 8];
+extern "C" int avid_debug_ww_trace(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ww_trace), sizeof(long long) * 1024 * 8 * 8);
+}
+#define WW_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = clock64(); ww_t[i] += now_ - ww_prev; ww_prev = now_; \
+                         __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WW_STAMP(i) do {} while (0)
+#endif
 constexpr int WW_TK = 8;                               // tiles per LDS stage (GEMM-K of a stage)
 constexpr int WW_HALF = WW_TK * 16 * 64;               // floats of V (or dM) in one stage: [tile][xi][64 channels]
 constexpr int WW_STAGE = 2 * WW_HALF;                  // V | dM
@@ -1311,6 +1331,7 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& p, float* s
       for (int b = 0; b < NP; ++b) {
         const int pb = b + O;                                    // patch column 0..3
         const unsigned vo = pb == 0 ? rowoff - (unsigned)px_b : rowoff;
+        if (WW_DBG & 1) { raw[a][b] = floatx2{(float)vo, 1.f}; continue; }
         raw[a][b] = __builtin_bit_cast(floatx2, __builtin_amdgcn_raw_buffer_load_b64(
                                                     rs, (oky4[a + O] && okx4[pb]) ? vo : 0x80000000u, pb == 0 ? 0 : (pb - 1) * px_b, 0));
       }
@@ -1356,6 +1377,14 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& p, float* s
   for (int a = 0; a < 4; ++a) row_store(sm, a);
   load_chunk(ch0 + 1);
   __syncthreads();
+#ifdef AVID_WW_TRACE
+  long long ww_t[6] = {0, 0, 0, 0, 0, 0}, ww_prev = clock64();
+  const long long ww_wall0 = wall_clock64(), ww_c0 = ww_prev;
+#endif
+  auto product = [&](int x8, float a, float b) {
+    if (WW_DBG & 8) acc[x8][0] = fmaf(a, b, acc[x8][0]);
+    else acc[x8] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[x8], 0, 0, 0);
+  };
   for (int ch = ch0; ch < ch1; ++ch) {
     const int u = (ch - ch0) & 1;
     const float* cur = sm + u * WW_STAGE;
@@ -1364,6 +1393,7 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& p, float* s
     const float* Bb = cur + b_frag;
     float af[2][8], bf[2][8];
     auto frag = [&](int kk, int x8) {
+      if (WW_DBG & 16) { af[kk & 1][x8] = (float)(kk + x8); bf[kk & 1][x8] = (float)(ch + x8); return; }
       af[kk & 1][x8] = Ab[(kk * 2 * 16 + x8) * 64];
       bf[kk & 1][x8] = Bb[(kk * 2 * 16 + x8) * 64];
     };
@@ -1373,21 +1403,26 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& p, float* s
 #pragma unroll
     for (int x8 = 0; x8 < 8; ++x8) {
       frag(1, x8);
-      acc[x8] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][x8], bf[0][x8], acc[x8], 0, 0, 0);
-      if (x8 < 4) {
-        if (x8 < NP) col(x8);
-      } else {
-        row_store(nxt, x8 - 4);
+      product(x8, af[0][x8], bf[0][x8]);
+      if (!(WW_DBG & 2)) {
+        if (x8 < 4) {
+          if (x8 < NP) col(x8);
+        } else {
+          row_store(nxt, x8 - 4);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef AVID_WW_TRACE
+      if (x8 == 3) WW_STAMP(4);
+#endif
     }
+    WW_STAMP(0);
     // k-step 1: the loads of chunk ch + 2 are issued (address arithmetic and VMEM spread over the MFMAs)
 #pragma unroll
     for (int x8 = 0; x8 < 8; ++x8) frag(2, x8);
     load_chunk(ch + 2);
 #pragma unroll
-    for (int x8 = 0; x8 < 8; ++x8)
-      acc[x8] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][x8], bf[1][x8], acc[x8], 0, 0, 0);
+    for (int x8 = 0; x8 < 8; ++x8) product(x8, af[1][x8], bf[1][x8]);
 #pragma unroll
     for (int x8 = 0; x8 < 8; ++x8) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // MFMA
@@ -1396,16 +1431,26 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& p, float* s
       __builtin_amdgcn_sched_group_barrier(0x020, ROLE == 0 ? 2 : 1, 0);     // VMEM read
     }
     __builtin_amdgcn_sched_barrier(0);
+    WW_STAMP(1);
 #pragma unroll
     for (int kk = 2; kk < WW_TK / 2; ++kk) {
 #pragma unroll
       for (int x8 = 0; x8 < 8; ++x8) {
         if (kk + 1 < WW_TK / 2) frag(kk + 1, x8);
-        acc[x8] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][x8], bf[kk & 1][x8], acc[x8], 0, 0, 0);
+        product(x8, af[kk & 1][x8], bf[kk & 1][x8]);
       }
     }
-    __syncthreads();       // the other stage is written; everyone is done reading this one
+    WW_STAMP(2);
+    if (!(WW_DBG & 4)) __syncthreads();       // the other stage is written; everyone is done reading this one
+    WW_STAMP(3);
   }
+#ifdef AVID_WW_TRACE
+  if (lane == 0) {
+    for (int i = 0; i < 6; ++i) g_ww_trace[((blockIdx.x & 1023) * 8 + wave) * 8 + i] = ww_t[i];
+    g_ww_trace[((blockIdx.x & 1023) * 8 + wave) * 8 + 6] = clock64() - ww_c0;            // shader cycles ...
+    g_ww_trace[((blockIdx.x & 1023) * 8 + wave) * 8 + 7] = wall_clock64() - ww_wall0;    // ... per 10 ns ticks: the clock in the kernel
+  }
+#endif
 }
 
 __global__ __launch_bounds__(512) void wino_wgrad_kernel(const WinoWgradArgs p) {

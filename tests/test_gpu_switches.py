@@ -32,6 +32,7 @@ def default_run(gpu_device):
 IDENTICAL = [{"AVID_PLAN": "0"}, {"AVID_STEM_WGRAD_PRE": "0"},    # (dy split at commit time or per use: the same split, the same sums)
              {"AVID_WINO2_PRE": "0"},                             # (V split by the transform or by every product wave: likewise)
              {"AVID_WGRAD_PRE": "0"},                             # (grouped weight gradients: fragments split at the LDS write or per use)
+             {"AVID_PK_WS": "0"},                                 # (K-split tails dealt tile-major or weight-stationary: same units, same slab order)
               {"AVID_OVERLAP_TOWERS": "0"}, {"AVID_DEFER_WGRAD": "0"}, {"AVID_STREAM_PROBE": "0"},
              {"AVID_FORCE_DIST": "1"}, {"AVID_FORCE_DIST": "1", "AVID_BUCKET_MB": "2"},
              {"AVID_HIP_LIB": os.path.join(os.path.dirname(HERE), "avid-cma_amd", "avid_hip", "libavid_hip.so")}]
@@ -42,7 +43,9 @@ CLOSE = [{"AVID_GROUP_WGRAD": "0"}, {"AVID_WGRAD_BF16X3": "0"}, {"AVID_FUSE_BN_B
          {"AVID_CU_RESERVE": "8"},
          # conv2x's temporal layers through tconv64_kernel / twgrad64_kernel at this small batch too (the default rule wants
          # three rounds of tiles), pre-split weights for every launch of the 128 x 128 tile, the criterion kernel's variants
-         {"AVID_TCONV": "2"}, {"AVID_TCONV": "0"}, {"AVID_BS_WIDE": "1"}, {"AVID_BS_WIDE": "0"}, {"AVID_BS_ROWS": "0"}, {"AVID_XM_ROWS": "128"}, {"AVID_XM_NT": "1"}]
+         {"AVID_TCONV": "2"}, {"AVID_TCONV": "0"}, {"AVID_BS_WIDE": "1"}, {"AVID_BS_WIDE": "0"}, {"AVID_BS_ROWS": "0"}, {"AVID_XM_ROWS": "128"}, {"AVID_XM_NT": "1"},
+         # every tail without full tiles weight-stationary, unsplit ones too: their BatchNorm partial rows change owners
+         {"AVID_PK_WS": "2"}]
 
 
 @pytest.mark.parametrize("env", IDENTICAL, ids=lambda e: ",".join(f"{k}={v if len(v) < 9 else '...'}" for k, v in e.items()))
