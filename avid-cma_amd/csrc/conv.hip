@@ -446,6 +446,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   constexpr int ALD = ASWZ ? BK : LDK;
   constexpr int STAGE = BS ? BM * ALD + BCH / 4 : (BM + BN) * LDK;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // The class tables of the strided input gradient are indexed with run-time class numbers.  Read through `p` (the by-value
+  // argument = a private copy the optimiser has to dissolve) such an index keeps the copy alive whenever the optimiser's
+  // forwarding to the argument block gives up — the whole 1 KB argument then lives in scratch (1056 B of private segment, seen
+  // with tools/kernel_resources.py after an unrelated edit).  So they are read where they are: from the kernel-argument segment
+  // itself (constant address space, scalar loads at computed offsets); `p` is only ever accessed at constant offsets.
+  typedef const ConvArgs __attribute__((address_space(4)))* KArgs;
+  const KArgs kp = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int lrow = tid >> 3, lcol = (tid & 7) * 4;
@@ -526,20 +533,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   // so its K extent differs (and may be empty: those tiles only write zeros / the addend).
   auto cls_of = [&](int tile) {
     int c = 0;
-    while (c + 1 < p.ncls && tile >= p.cls_begin[c + 1]) ++c;
+    while (c + 1 < p.ncls && tile >= kp->cls_begin[c + 1]) ++c;
     return c;
   };
   auto seg_info = [&](int j, int& tile, int& k0, int& k1, int& split) {
     if (STRIDED) {   // units = (tile, piece of its own K range), all dealt round-robin; pieces per tile vary by class
       const int u = slot + j * G;
       int c = 0;
-      while (c + 1 < p.ncls && u >= p.cls_ubegin[c + 1]) ++c;
-      const int fc = p.cls_f[c];
-      const int local = u - p.cls_ubegin[c];
+      while (c + 1 < p.ncls && u >= kp->cls_ubegin[c + 1]) ++c;
+      const int fc = kp->cls_f[c];
+      const int local = u - kp->cls_ubegin[c];
       const int lt = local / fc;
       const int piece = local - lt * fc;
-      tile = p.cls_begin[c] + lt;
-      const int nkc = p.cls_nd[c][0] * p.cls_nd[c][1] * p.cls_nd[c][2] * cpt;
+      tile = kp->cls_begin[c] + lt;
+      const int nkc = kp->cls_nd[c][0] * kp->cls_nd[c][1] * kp->cls_nd[c][2] * cpt;
       const int kps = (nkc + fc - 1) / fc;
       k0 = piece * kps < nkc ? piece * kps : nkc;
       k1 = k0 + kps < nkc ? k0 + kps : nkc;
@@ -597,17 +604,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
     int offt = p.pt, offh = p.ph, offw = p.pw, ndt = p.kt, ndh = p.kh, ndw = p.kw;
     if (STRIDED) {
       c = ld_cls;
-      lt = tile - p.cls_begin[c];
-      cT = p.cls_n[c][0]; cH = p.cls_n[c][1]; cW = p.cls_n[c][2];
+      lt = tile - kp->cls_begin[c];
+      cT = kp->cls_n[c][0]; cH = kp->cls_n[c][1]; cW = kp->cls_n[c][2];
       cpix = cT * cH * cW;
       cM = p.B * cpix;
-      mgT = p.cls_mg[c][0]; mgH = p.cls_mg[c][1]; mgW = p.cls_mg[c][2];
-      shT = p.cls_shf[c][0]; shH = p.cls_shf[c][1]; shW = p.cls_shf[c][2];
+      mgT = kp->cls_mg[c][0]; mgH = kp->cls_mg[c][1]; mgW = kp->cls_mg[c][2];
+      shT = kp->cls_shf[c][0]; shH = kp->cls_shf[c][1]; shW = kp->cls_shf[c][2];
       // source coordinate of class tap j for class-local position q: q + off - j  (off is exact by construction)
-      offt = (p.cls_p0[c][0] + p.pt - p.cls_d0[c][0]) / p.st;
-      offh = (p.cls_p0[c][1] + p.ph - p.cls_d0[c][1]) / p.sh;
-      offw = (p.cls_p0[c][2] + p.pw - p.cls_d0[c][2]) / p.sw;
-      ndt = p.cls_nd[c][0]; ndh = p.cls_nd[c][1]; ndw = p.cls_nd[c][2];
+      offt = (kp->cls_p0[c][0] + p.pt - kp->cls_d0[c][0]) / p.st;
+      offh = (kp->cls_p0[c][1] + p.ph - kp->cls_d0[c][1]) / p.sh;
+      offw = (kp->cls_p0[c][2] + p.pw - kp->cls_d0[c][2]) / p.sw;
+      ndt = kp->cls_nd[c][0]; ndh = kp->cls_nd[c][1]; ndw = kp->cls_nd[c][2];
     }
     const int mt = lt / ntn, nt = lt - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -694,7 +701,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
   auto set_tap = [&]() {
     if (STRIDED) {
       const int c = ld_cls;
-      ld_tap = sgpr(((p.cls_d0[c][0] + ld_dt * p.st) * p.kh + p.cls_d0[c][1] + ld_dh * p.sh) * p.kw + p.cls_d0[c][2] +
+      ld_tap = sgpr(((kp->cls_d0[c][0] + ld_dt * p.st) * p.kh + kp->cls_d0[c][1] + ld_dh * p.sh) * p.kw + kp->cls_d0[c][2] +
                     ld_dw * p.sw);
     } else {
       ld_tap = sgpr((ld_dt * p.kh + ld_dh) * p.kw + ld_dw);
@@ -710,8 +717,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       ld_seg = sgpr(k1 == k0 ? nseg : j);
       if (k1 == k0) return;
       ld_cls = sgpr(cls_of(tile));
-      ld_nh = sgpr(p.cls_nd[ld_cls][1]);
-      ld_nw = sgpr(p.cls_nd[ld_cls][2]);
+      ld_nh = sgpr(kp->cls_nd[ld_cls][1]);
+      ld_nw = sgpr(kp->cls_nd[ld_cls][2]);
     }
     ld_ks = sgpr(k0);
     ld_kend = sgpr(k1);
@@ -1000,26 +1007,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_pk_kernel(const ConvArg
       int* arow = drow + BM;               // row offsets into the addend (== drow unless the addend is compact)
       const bool sparse_add = p.add_s[0] * p.add_s[1] * p.add_s[2] > 1;
       const int c = cls_of(tile);
-      const int lt = tile - p.cls_begin[c];
+      const int lt = tile - kp->cls_begin[c];
       const int mt = lt / ntn, nt = lt - mt * ntn;
       const int n0 = nt * BN;
-      const int cT = p.cls_n[c][0], cH = p.cls_n[c][1], cW = p.cls_n[c][2];
+      const int cT = kp->cls_n[c][0], cH = kp->cls_n[c][1], cW = kp->cls_n[c][2];
       __syncthreads();
       if (tid < BM) {
         const unsigned m = mt * BM + tid;
         const bool ok = m < (unsigned)(p.B * cT * cH * cW);
         const unsigned mm = ok ? m : 0u;
-        const unsigned q1 = magic_div(mm, p.cls_mg[c][2], p.cls_shf[c][2]);
+        const unsigned q1 = magic_div(mm, kp->cls_mg[c][2], kp->cls_shf[c][2]);
         const int wd = mm - q1 * cW;
-        const unsigned q2 = magic_div(q1, p.cls_mg[c][1], p.cls_shf[c][1]);
+        const unsigned q2 = magic_div(q1, kp->cls_mg[c][1], kp->cls_shf[c][1]);
         const int hd = q1 - q2 * cH;
-        const int b = magic_div(q2, p.cls_mg[c][0], p.cls_shf[c][0]);
+        const int b = magic_div(q2, kp->cls_mg[c][0], kp->cls_shf[c][0]);
         const int td = q2 - b * cT;
-        const int dst = ((b * p.Td + p.cls_p0[c][0] + td * p.st) * p.Hd + p.cls_p0[c][1] + hd * p.sh) * p.Wd +
-                        p.cls_p0[c][2] + wd * p.sw;
+        const int dst = ((b * p.Td + kp->cls_p0[c][0] + td * p.st) * p.Hd + kp->cls_p0[c][1] + hd * p.sh) * p.Wd +
+                        kp->cls_p0[c][2] + wd * p.sw;
         drow[tid] = ok ? dst * row_bytes : (int)OOB;
         if (sparse_add) {   // strides are 1 or 2: position -> compact position where every strided coordinate is even
-          const int t = p.cls_p0[c][0] + td * p.st, hh = p.cls_p0[c][1] + hd * p.sh, w = p.cls_p0[c][2] + wd * p.sw;
+          const int t = kp->cls_p0[c][0] + td * p.st, hh = kp->cls_p0[c][1] + hd * p.sh, w = kp->cls_p0[c][2] + wd * p.sw;
           const bool on = ok && (t & (p.add_s[0] - 1)) == 0 && (hh & (p.add_s[1] - 1)) == 0 && (w & (p.add_s[2] - 1)) == 0;
           const int ar = ((b * p.add_n[0] + (t >> (p.add_s[0] - 1))) * p.add_n[1] + (hh >> (p.add_s[1] - 1))) * p.add_n[2] +
                          (w >> (p.add_s[2] - 1));
@@ -3139,6 +3146,7 @@ constexpr bool pk_takes_split() {
 // CU again — conv3x temporal 49.2 -> 45.2 / 54.5 -> 51.0, conv3x strided spatial forward 109.7 -> 104.5, `<2,2,2,2,*>` 0.78 -> 0.74 ms
 // per step, the step 9.782 -> 9.746 ms (three alternating pairs of 300 steps, one box).
 // AVID_BS_WIDE: 2 (default) every launch of the tile, 1 only plans without a full round of tiles, 0 never.
+constexpr int S2_WIDE_DEFAULT = 1;
 static int bs_wide_mode() {
   static int v = -1;
   if (v < 0) {
@@ -3159,6 +3167,18 @@ static bool bs_rows() {
     v = e ? (atoi(e) != 0 ? 1 : 0) : 1;
   }
   return v != 0;
+}
+// Strided input gradients (stride-parity classes) of layers whose Cin is a multiple of 128: AVID_S2_WIDE = 1 the 128 x 128 tile
+// (2 x 2 waves, both operands split in registers), 0 the 128 x 64 tile with pre-split weights (four waves of 32 x 64).
+static bool s2_wide() {
+  static std::atomic<int> v{-1};
+  int m = v.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("AVID_S2_WIDE");
+    m = e ? (atoi(e) != 0 ? 1 : 0) : S2_WIDE_DEFAULT;
+    v.store(m, std::memory_order_relaxed);
+  }
+  return m != 0;
 }
 static bool bs_wide(const PkPlan& pk) { return pk.tile == 0 && (bs_wide_mode() == 2 || (bs_wide_mode() == 1 && pk.full == 0)); }
 
@@ -3464,7 +3484,7 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
       a.st <= 2 && a.sh <= 2 && a.sw <= 2) {
     // strided dgrad on the persistent kernel: (class tile, K piece) units dealt round-robin, heavy classes first
     ConvArgs k = a;
-    const bool wide = a.Cd % 128 == 0;
+    const bool wide = a.Cd % 128 == 0 && s2_wide();
     const int BN = wide ? 128 : 64;
     const StridedPlan pl = plan_strided(k, 128, BN, ws ? ws_bytes / sizeof(float) : 0);
     k.nsplit = 1;
@@ -3729,7 +3749,7 @@ static bool conv_takes_split(const avid_conv_desc* d, int which) {
   }
   if (d->Cin % 64 || d->Cout % 32 || d->st > 2 || d->sh > 2 || d->sw > 2 || wino_supported(d, 1)) return false;
   const long long M = (long long)d->B * d->Ti * d->Hi * d->Wi;
-  if (d->st > 1 || d->sh > 1 || d->sw > 1) return M * d->Cin * 4 < (1ll << 31) && d->Cin % 128 != 0;
+  if (d->st > 1 || d->sh > 1 || d->sw > 1) return M * d->Cin * 4 < (1ll << 31) && (d->Cin % 128 != 0 || !s2_wide());
   const PkPlan pk = plan_pk(M, d->Cin, trim_taps(d).d.kt * d->kh * d->kw * (d->Cout / BK), 1);
   return pk.tile == 1 || bs_wide(pk);
 }
@@ -3901,7 +3921,7 @@ extern "C" int avid_conv_dgrad_bn_rows(const avid_conv_desc* d) {
     ConvArgs a{};
     fill_common(a, &tr.d);
     a.Td = d->Ti; a.Hd = d->Hi; a.Wd = d->Wi; a.Cd = d->Cin;
-    const int BN = d->Cin % 128 == 0 ? 128 : 64;
+    const int BN = d->Cin % 128 == 0 && s2_wide() ? 128 : 64;
     a.Cs = d->Cout;
     a.M = (int)M;
     const StridedPlan pl = plan_strided(a, 128, BN, (size_t)8 * (size_t)M * d->Cin);
@@ -4449,7 +4469,7 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
     } else if (strided && dgrad_compactable(d)) {
       snprintf(buf, len, "igemm_pk_kernel over the sub-sampled grid + dx_scatter_strided_kernel");
     } else if (strided) {
-      snprintf(buf, len, "igemm_pk_kernel<%s,1>s2 (stride-parity classes)", d->Cin % 128 == 0 ? "2,2,2,2" : "4,1,1,2");
+      snprintf(buf, len, "igemm_pk_kernel<%s,1>s2 (stride-parity classes)", d->Cin % 128 == 0 && s2_wide() ? "2,2,2,2" : "4,1,1,2");
     } else {
       pk_name(M, d->Cin, ktl * d->kh * d->kw * (d->Cout / BK), 1);
     }

@@ -141,14 +141,16 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
   // of the epilogue (~1000 VALU instructions per wave and unit, on the matrix pipe's time)
   int4* tabs = reinterpret_cast<int4*>(sm + W_LDS_FLOATS);
   auto fill_tab = [&](int blk, int buf) {
-    if (tid < W_TB) {
-      const long long t = (long long)blk * W_TB + tid;
+    int tid_t = tid, tpf = TPF, tw = TW;             // (opaque copies: the divisions' reciprocals and the table address are
+    asm volatile("" : "+v"(tid_t), "+s"(tpf), "+s"(tw));   //  recomputed per unit instead of being spilled as loop invariants)
+    if (tid_t < W_TB) {
+      const long long t = (long long)blk * W_TB + tid_t;
       int4 e = {-1, 0, 0, 0};
       if (blk < nblk && t < p.ntiles) {
-        const int f = (int)(t / TPF), rem = (int)(t - (long long)f * TPF);
-        e.x = f; e.y = rem / TW; e.z = rem - e.y * TW;
+        const int f = (int)(t / tpf), rem = (int)(t - (long long)f * tpf);
+        e.x = f; e.y = rem / tw; e.z = rem - e.y * tw;
       }
-      tabs[buf * W_TB + tid] = e;
+      tabs[buf * W_TB + tid_t] = e;
     }
   };
   // this thread's item of the input transform: (4 channels = tid & 7, tile = tid >> 3).  The 4x4 patch of the NEXT
@@ -279,35 +281,41 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
       T0[j] = acc[0][j] + acc[1][j] + acc[2][j];
       T1[j] = acc[1][j] - acc[2][j] - acc[3][j];
     }
-    __syncthreads();                           // V is dead: the LDS becomes the exchange buffer T[r][q][j][reg / 4][lane]
-    float* ex = sm;                             // ex[row][q][j][r / 4][lane][r % 4]: 16-byte accesses, conflict-free
-    auto ex_at = [&](int row, int q_, int j, int r4) { return ex + (((((row * 2 + q_) * 2 + j) * 4 + r4) * 64 + lane) << 2); };
+    // the output phase's lane constants, recomputed per unit from a thread id the compiler cannot see through: as loop invariants
+    // they were hoisted in front of the unit loop and spilled there (wino_kernel<1> / <4> / <6>: 14 / 22 / 24 registers stored once
+    // and re-read per unit, tools/kernel_resources.py)
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    const int lane_o = tid_o & 63, wave_o = __builtin_amdgcn_readfirstlane(tid_o >> 6), l31o = lane_o & 31, h_o = lane_o >> 5;
+    __syncthreads();                           // V is dead: the LDS becomes the exchange buffer T[r][q][j][reg / 4][lane_o]
+    float* ex = sm;                             // ex[row][q][j][r / 4][lane_o][r % 4]: 16-byte accesses, conflict-free
+    auto ex_at = [&](int row, int q_, int j, int r4) { return ex + (((((row * 2 + q_) * 2 + j) * 4 + r4) * 64 + lane_o) << 2); };
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        *reinterpret_cast<floatx4*>(ex_at(wave, 0, j, r4)) = floatx4{T0[j][4 * r4], T0[j][4 * r4 + 1], T0[j][4 * r4 + 2], T0[j][4 * r4 + 3]};
-        *reinterpret_cast<floatx4*>(ex_at(wave, 1, j, r4)) = floatx4{T1[j][4 * r4], T1[j][4 * r4 + 1], T1[j][4 * r4 + 2], T1[j][4 * r4 + 3]};
+        *reinterpret_cast<floatx4*>(ex_at(wave_o, 0, j, r4)) = floatx4{T0[j][4 * r4], T0[j][4 * r4 + 1], T0[j][4 * r4 + 2], T0[j][4 * r4 + 3]};
+        *reinterpret_cast<floatx4*>(ex_at(wave_o, 1, j, r4)) = floatx4{T1[j][4 * r4], T1[j][4 * r4 + 1], T1[j][4 * r4 + 2], T1[j][4 * r4 + 3]};
       }
     __syncthreads();
-    // rows across waves: this wave writes output pixel (po, qo) of every tile:
+    // rows across waves: this wave_o writes output pixel (po, qo) of every tile:
     //   Y[0][q] = T[0][q] + T[1][q] + T[2][q],  Y[1][q] = T[1][q] - T[2][q] - T[3][q]
-    const int po = wave >> 1, qo = wave & 1;
-    int ooff;                                   // destination offset (in floats, < 2^29) of the lane's tile, or -1
+    const int po = wave_o >> 1, qo = wave_o & 1;
+    int ooff;                                   // destination offset (in floats, < 2^29) of the lane_o's tile, or -1
     {
-      const int4 e = tab[l31];
+      const int4 e = tab[l31o];
       const int yy = 2 * e.y + po, xx = 2 * e.z + qo;
-      ooff = (e.x >= 0 && yy < H && xx < W) ? ((e.x * H + yy) * W + xx) * Cn + cb * 64 + 4 * h : -1;
+      ooff = (e.x >= 0 && yy < H && xx < W) ? ((e.x * H + yy) * W + xx) * Cn + cb * 64 + 4 * h_o : -1;
     }
     const bool ok = ooff >= 0;
     const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
-    // statistics staging: st[wave][tile 32][16 channels] (2 KB per wave, behind the exchange buffer), 16-byte slots
+    // statistics staging: st[wave_o][tile 32][16 channels] (2 KB per wave_o, behind the exchange buffer), 16-byte slots
     // XOR-swizzled by the tile so that the eight lanes of a 16-byte store group and the 32 lanes of a 4-byte load group
-    // hit distinct banks.  One term at a time; LDS operations of a wave execute in order, so no barrier is involved.
-    float* st = sm + 4 * 2 * 2 * 4 * 64 * 4 + wave * (W_TB * 16);
-    const int st_row = l31 * 16, st_sw = ((l31 >> 1) & 3) * 4;
-    const int st_ch = lane & 15, st_tg = lane >> 4;
-    auto col_sums = [&]() {                      // sum over this lane's 8 tiles of channel st_ch of the staged round
+    // hit distinct banks.  One term at a time; LDS operations of a wave_o execute in order, so no barrier is involved.
+    float* st = sm + 4 * 2 * 2 * 4 * 64 * 4 + wave_o * (W_TB * 16);
+    const int st_row = l31o * 16, st_sw = ((l31o >> 1) & 3) * 4;
+    const int st_ch = lane_o & 15, st_tg = lane_o >> 4;
+    auto col_sums = [&]() {                      // sum over this lane_o's 8 tiles of channel st_ch of the staged round
       float s_ = 0.f;
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
             if (EPI & 1) {
               t1[gl] = t0[gl] * t0[gl];
             } else {
-              const int col = cb * 64 + j * 32 + 8 * g + 4 * h;
+              const int col = cb * 64 + j * 32 + 8 * g + 4 * h_o;
               const floatx4 bsc = *reinterpret_cast<const floatx4*>(p.bnb_scale + col), bsh = *reinterpret_cast<const floatx4*>(p.bnb_shift + col);
               const floatx4 bmu = *reinterpret_cast<const floatx4*>(p.bnb_mean + col), bis = *reinterpret_cast<const floatx4*>(p.bnb_invstd + col);
 #pragma unroll
@@ -357,11 +365,11 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
         }
         if (EPI & 5) {            // round r = 2 j + gp: channels 16 r .. 16 r + 15 of this column block
           const int r = 2 * j + gp;
-          *reinterpret_cast<floatx4*>(st + st_row + ((4 * h) ^ st_sw)) = t0[0];
-          *reinterpret_cast<floatx4*>(st + st_row + ((8 + 4 * h) ^ st_sw)) = t0[1];
+          *reinterpret_cast<floatx4*>(st + st_row + ((4 * h_o) ^ st_sw)) = t0[0];
+          *reinterpret_cast<floatx4*>(st + st_row + ((8 + 4 * h_o) ^ st_sw)) = t0[1];
           cs[r] += col_sums();
-          *reinterpret_cast<floatx4*>(st + st_row + ((4 * h) ^ st_sw)) = t1[0];
-          *reinterpret_cast<floatx4*>(st + st_row + ((8 + 4 * h) ^ st_sw)) = t1[1];
+          *reinterpret_cast<floatx4*>(st + st_row + ((4 * h_o) ^ st_sw)) = t1[0];
+          *reinterpret_cast<floatx4*>(st + st_row + ((8 + 4 * h_o) ^ st_sw)) = t1[1];
           cq[r] += col_sums();
         }
       }
@@ -371,14 +379,16 @@ __global__ __launch_bounds__(256, 2) void wino_kernel(const WinoArgs p) {
   if ((EPI & 5) && p.stats) {   // one partial row [2][Cn] per workgroup: the four tile groups of a wave, then the four waves
     __syncthreads();
     float* red = sm;            // [2][4][64]
+    int lane_r = lane;
+    asm volatile("" : "+v"(lane_r));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float a = cs[r], b = cq[r];
       a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
       a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-      if (lane < 16) {
-        red[wave * 64 + 16 * r + lane] = a;
-        red[256 + wave * 64 + 16 * r + lane] = b;
+      if (lane_r < 16) {
+        red[wave * 64 + 16 * r + lane_r] = a;
+        red[256 + wave * 64 + 16 * r + lane_r] = b;
       }
     }
     __syncthreads();
@@ -897,14 +907,18 @@ __global__ __launch_bounds__(256) void wino2p_kernel(const WinoArgs p) {
   const int blk0 = q < fullq ? q : (xl ? qlast : q);
   int4* tabs = reinterpret_cast<int4*>(smb + W2P_TAB_OFF);
   auto fill_tab = [&](int blk, int buf) {
-    if (tid < W2_TB) {
-      const long long t = (long long)blk * W2_TB + tid;
+    int tid_t = tid;                                 // (per unit, from an opaque copy: as loop invariants the table address and the
+    asm volatile("" : "+v"(tid_t));                  //  divisions' reciprocals were spilled in front of the unit loop)
+    if (tid_t < W2_TB) {
+      const long long t = (long long)blk * W2_TB + tid_t;
       int4 e = {-1, 0, 0, 0};
       if (blk < nblk && t < p.ntiles) {
-        const int f = (int)(t / TPF), rem = (int)(t - (long long)f * TPF);
-        e.x = f; e.y = rem / TW; e.z = rem - e.y * TW;
+        int tpf = TPF, tw = TW;
+        asm volatile("" : "+s"(tpf), "+s"(tw));
+        const int f = (int)(t / tpf), rem = (int)(t - (long long)f * tpf);
+        e.x = f; e.y = rem / tw; e.z = rem - e.y * tw;
       }
-      tabs[buf * W2_TB + tid] = e;
+      tabs[buf * W2_TB + tid_t] = e;
     }
   };
   // ---- this thread's item of the input transform: tile tt, channels c4 .. c4 + 3 of the chunk
@@ -1080,15 +1094,14 @@ __global__ __launch_bounds__(256) void wino2p_kernel(const WinoArgs p) {
   };
 
   // ---- output phase (see wino2_kernel), the exchange buffer in the ring's dead buffer, two output pixels per pass
-  const int xw_row = l31 * 32, xw_sw = l31 & 7;
-  const int t8 = lane >> 3, slot = lane & 7;
-  const int xr_off = t8 * 32 + ((slot ^ t8) << 2);
-  const int ccol = cb * 64 + nh * 32 + 4 * slot;
-  floatx4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, bis = bsc;
-  if (EPI & 4) {
-    bsc = *reinterpret_cast<const floatx4*>(p.bnb_scale + ccol); bsh = *reinterpret_cast<const floatx4*>(p.bnb_shift + ccol);
-    bmu = *reinterpret_cast<const floatx4*>(p.bnb_mean + ccol); bis = *reinterpret_cast<const floatx4*>(p.bnb_invstd + ccol);
-  }
+  // The BatchNorm's per-channel vectors of this thread's four channels are fetched per UNIT, behind the output transform (buffer
+  // loads next to the loop's stores: the compiler cannot hoist them).  Loaded once in front of the unit loop they were 16
+  // registers that lived through every chunk loop: the 13 / 23 spilled registers of the two BatchNorm-backward forms
+  // (tools/kernel_resources.py) were exactly such loop-invariants, stored once and re-read per unit.
+  const __amdgpu_buffer_rsrc_t rsSc = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI & 4) ? p.bnb_scale : p.src), 0, (EPI & 4) ? Cn * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsSh = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI & 4) ? p.bnb_shift : p.src), 0, (EPI & 4) ? Cn * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsMu = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI & 4) ? p.bnb_mean : p.src), 0, (EPI & 4) ? Cn * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsIs = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI & 4) ? p.bnb_invstd : p.src), 0, (EPI & 4) ? Cn * 4 : 0, 0x00020000);
   floatx4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   const int pix_b[4] = {0, Cn * 4, W * Cn * 4, (W + 1) * Cn * 4};
 
@@ -1100,12 +1113,24 @@ __global__ __launch_bounds__(256) void wino2p_kernel(const WinoArgs p) {
     for (int ck = 1; ck < nchunks; ++ck) chunk(std::false_type{}, ck);
     // (the barrier behind the last half: every wave is done with it — rb now names the buffer the NEXT chunk's first half sits in,
     //  the one before it in the ring is the dead one)
-    float* xch = reinterpret_cast<float*>(smb + (rb == 0 ? 2 : rb - 1) * W2P_HS) + wave * 2048;
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    const int wave_o = __builtin_amdgcn_readfirstlane(tid_o >> 6), th_o = wave_o & 1;
+    float* xch = reinterpret_cast<float*>(smb + (rb == 0 ? 2 : rb - 1) * W2P_HS) + wave_o * 2048;
+    // the output phase's lane constants, recomputed per unit from a lane id the compiler cannot see through: as loop invariants
+    // they were hoisted in front of the unit loop and — the chunk loops use every register — spilled there (nine scratch stores
+    // and reloads per unit where eight vector instructions do)
+    const int lane_o = tid_o & 63, h_o = lane_o >> 5;
+    const int l31o = lane_o & 31;
+    const int xw_row = l31o * 32, xw_sw = l31o & 7;
+    const int t8 = lane_o >> 3, slot = lane_o & 7;
+    const int xr_off = t8 * 32 + ((slot ^ t8) << 2);
+    const int ccol = cb * 64 + nh * 32 + 4 * slot;
     unsigned voff[4];
     int okm = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int4 te = tabs[ubuf * W2_TB + 32 * th + 8 * k + t8];
+      const int4 te = tabs[ubuf * W2_TB + 32 * th_o + 8 * k + t8];
       const int y0 = 2 * te.y, x0 = 2 * te.z;
       const bool tok = te.x >= 0, okx = x0 + 1 < W, oky = y0 + 1 < H;
       voff[k] = (unsigned)((((te.x * H + y0) * W + x0) * Cn + ccol) * 4);
@@ -1135,7 +1160,9 @@ __global__ __launch_bounds__(256) void wino2p_kernel(const WinoArgs p) {
       for (int k = 0; k < 4; ++k)
         ad[pq & 1][k] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, epi_off(k, pq), pix_b[pq], 0));
     };
-    if (EPI & 4) { load_xb(0); load_xb(1); }
+    // (the first pair only: 16 more registers held across the output transform — its peak — were 13 / 23 spilled registers in the
+    //  two BatchNorm-backward forms; the second pixel's rows are requested behind the transform, with the addend's)
+    if (EPI & 4) load_xb(0);
     floatx4 low[4][2];                 // output row 1 (pixels 2, 3) of every channel group: the second pass
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1154,7 +1181,7 @@ __global__ __launch_bounds__(256) void wino2p_kernel(const WinoArgs p) {
         T[a][0] = pk4_add(pk4_add(M[0], M[1]), M[2]);
         T[a][1] = pk4_sub(pk4_sub(M[1], M[2]), M[3]);
       }
-      float* wp = xch + xw_row + (((2 * g + h) ^ xw_sw) << 2);
+      float* wp = xch + xw_row + (((2 * g + h_o) ^ xw_sw) << 2);
 #pragma unroll
       for (int qo = 0; qo < 2; ++qo) {
         *reinterpret_cast<floatx4*>(wp + qo * 1024) = pk4_add(pk4_add(T[0][qo], T[1][qo]), T[2][qo]);
@@ -1162,13 +1189,21 @@ __global__ __launch_bounds__(256) void wino2p_kernel(const WinoArgs p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (EPI & 4) load_xb(1);
     if (EPI & 2) { load_ad(0); load_ad(1); }
+    floatx4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, bis = bsc;
+    if (EPI & 4) {
+      bsc = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsSc, ccol * 4, 0, 0));
+      bsh = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsSh, ccol * 4, 0, 0));
+      bmu = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsMu, ccol * 4, 0, 0));
+      bis = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsIs, ccol * 4, 0, 0));
+    }
 #pragma unroll
     for (int pq = 0; pq < 4; ++pq) {
       if (pq == 2) {      // second pass (a wave's LDS operations execute in order: its loads of the first pass are behind it)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float* wp = xch + xw_row + (((2 * g + h) ^ xw_sw) << 2);
+          float* wp = xch + xw_row + (((2 * g + h_o) ^ xw_sw) << 2);
           *reinterpret_cast<floatx4*>(wp) = low[g][0];
           *reinterpret_cast<floatx4*>(wp + 1024) = low[g][1];
         }
@@ -1206,15 +1241,17 @@ __global__ __launch_bounds__(256) void wino2p_kernel(const WinoArgs p) {
   if ((EPI & 5) && p.stats) {
     __syncthreads();
     float* red = sm;            // [2 terms][4 waves][32]
+    int lane_r = lane;
+    asm volatile("" : "+v"(lane_r));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float a = s0[i], b = s1[i];
       a += __shfl_xor(a, 8, 64); b += __shfl_xor(b, 8, 64);
       a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
       a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-      if (lane < 8) {
-        red[wave * 32 + 4 * lane + i] = a;
-        red[128 + wave * 32 + 4 * lane + i] = b;
+      if (lane_r < 8) {
+        red[wave * 32 + 4 * lane_r + i] = a;
+        red[128 + wave * 32 + 4 * lane_r + i] = b;
       }
     }
     __syncthreads();
