@@ -3146,7 +3146,12 @@ constexpr bool pk_takes_split() {
 // CU again — conv3x temporal 49.2 -> 45.2 / 54.5 -> 51.0, conv3x strided spatial forward 109.7 -> 104.5, `<2,2,2,2,*>` 0.78 -> 0.74 ms
 // per step, the step 9.782 -> 9.746 ms (three alternating pairs of 300 steps, one box).
 // AVID_BS_WIDE: 2 (default) every launch of the tile, 1 only plans without a full round of tiles, 0 never.
-constexpr int S2_WIDE_DEFAULT = 1;
+// (round 6, same box, alternating, us per layer 1 -> 0: conv3x strided temporal 60.9 / 62.1 -> 55.6 / 55.2, conv4x strided spatial
+//  85.0 / 83.5 -> 78.9 / 79.2, conv4x strided temporal 52.0 / 51.1 -> 40.7 / 42.2, conv5x strided spatial 59.9 / 59.8 -> 50.9 / 50.7,
+//  conv5x strided temporal 37.3 / 37.2 -> 30.7 / 30.4, audio block 3 33.2 / 33.0 -> 33.6 / 31.2; the strided kernels of the step
+//  0.454 -> 0.42 ms, the step 9.638 / 9.729 -> 9.548 / 9.589 ms; the wide form with the BatchNorm-backward + addend epilogue was
+//  also the last kernel of the step with spilled registers: 44)
+constexpr int S2_WIDE_DEFAULT = 0;
 static int bs_wide_mode() {
   static int v = -1;
   if (v < 0) {

@@ -62,7 +62,7 @@ CASES = [
     ("pk_strided_64", 64, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (4, 4, 28, 28), False, False,
      ("igemm_pk_kernel<4,1,1,2,0>", "igemm_pk_kernel<4,1,1,2,1>s2", "wgrad_tab_kernel<2,2>")),
     ("pk_strided_128", 128, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), (16, 2, 14, 14), False, False,
-     ("igemm_pk_kernel<4,1,1,2,0>", "igemm_pk_kernel<2,2,2,2,1>s2", "wgrad_tab_kernel<2,2>")),
+     ("igemm_pk_kernel<4,1,1,2,0>", "igemm_pk_kernel<4,1,1,2,1>s2", "wgrad_tab_kernel<2,2>")),
     # conv2x's temporal layers: tconv64_kernel (taps staged once, weights resident in LDS), forward and input gradient, and
     # twgrad64_kernel (the taps share their split fragments), weight gradient
     ("tconv64", 64, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (5, 8, 27, 29), False, False,

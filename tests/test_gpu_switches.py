@@ -45,7 +45,9 @@ CLOSE = [{"AVID_GROUP_WGRAD": "0"}, {"AVID_WGRAD_BF16X3": "0"}, {"AVID_FUSE_BN_B
          # three rounds of tiles), pre-split weights for every launch of the 128 x 128 tile, the criterion kernel's variants
          {"AVID_TCONV": "2"}, {"AVID_TCONV": "0"}, {"AVID_BS_WIDE": "1"}, {"AVID_BS_WIDE": "0"}, {"AVID_BS_ROWS": "0"}, {"AVID_XM_ROWS": "128"}, {"AVID_XM_NT": "1"},
          # every tail without full tiles weight-stationary, unsplit ones too: their BatchNorm partial rows change owners
-         {"AVID_PK_WS": "2"}]
+         {"AVID_PK_WS": "2"},
+         # the strided input gradients of the Cin % 128 == 0 layers on the 128 x 128 tile (both operands split in registers)
+         {"AVID_S2_WIDE": "1"}]
 
 
 @pytest.mark.parametrize("env", IDENTICAL, ids=lambda e: ",".join(f"{k}={v if len(v) < 9 else '...'}" for k, v in e.items()))
