@@ -36,6 +36,11 @@ class BnBwdFuse(C.Structure):
                 ("invstd", C.c_void_p), ("relu", C.c_int32), ("partials", C.c_void_p)]
 
 
+class InAffine(C.Structure):
+    """Mirror of ``avid_in_affine`` (include/avid_hip.h): the BatchNorm (+ReLU) a convolution applies to its input."""
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int32)]
+
+
 class ConvDesc(C.Structure):
     """Mirror of ``avid_conv_desc`` (include/avid_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (
@@ -110,6 +115,9 @@ SIGNATURES = {
     "avid_conv_fwd_workspace_bytes": (_sz, [_dp]),
     "avid_conv_fwd_stats_rows": (_i, [_dp]),
     "avid_conv_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "avid_conv_takes_in_affine": (_i, [_dp]),
+    "avid_conv_fwd_in": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "avid_debug_in_affine_launches": (C.c_longlong, [_i]),
     "avid_conv_dgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_dgrad_bn_rows": (_i, [_dp]),
     "avid_conv_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -117,6 +125,7 @@ SIGNATURES = {
     "avid_weight_transform": (_i, [_vp, _vp]),
     "avid_conv_wgrad_workspace_bytes": (_sz, [_dp]),
     "avid_conv_wgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avid_conv_wgrad_in": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avid_conv_wgrad_groupable": (_i, [_dp]),
     "avid_conv_wgrad_group_workspace_bytes": (_sz, [_i, C.POINTER(WgradItem)]),
     "avid_conv_wgrad_group": (_i, [_i, C.POINTER(WgradItem), _vp, _sz, _vp]),

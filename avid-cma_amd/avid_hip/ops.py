@@ -312,6 +312,9 @@ def _desc_cached(xs, cin, cout, k, stride, pad, channel_first):
         # the 128 x 64 implicit-GEMM tile takes its weights pre-split into bf16 terms (avid_wt_desc mode 5 / 6)
         d.split_fwd = bool(lib.raw("avid_conv_uses_split")(C.byref(d), 0))
         d.split_dgrad = False if channel_first else bool(lib.raw("avid_conv_uses_split")(C.byref(d), 1))
+        # the layer can read the INPUT of the BatchNorm (+ReLU) in front of it and apply the map while staging (forward and weight
+        # gradient): avid_conv_fwd_in / avid_conv_wgrad_in — the launch programs then never write the normalised tensor
+        d.in_affine = bool(lib.raw("avid_conv_takes_in_affine")(C.byref(d)))
         _DESC_CACHE[key] = hit
     return hit
 
@@ -860,6 +863,35 @@ class _ConvCL(Function):
         if d_tap is not None and not need_dx:
             dx = d_tap
         return dx, dw, dadd, dbias, None, None, None, None, None, None, None, dw_res, None
+
+
+def conv_fwd_in(x, w, stride, pad, scale, shift, relu=True, addend=None, bn_stats=False):
+    """``avid_conv_fwd_in`` as a plain call (no autograd): conv(ReLU?(x * scale + shift), w) [+ addend] with x the INPUT of the
+    BatchNorm in front of the layer — what the launch programs emit for conv2x's temporal layers.  Returns y, or (y, partials).
+    Raises for a layer that cannot (``_desc_cached(...)[0].in_affine``)."""
+    _need_cuda(x, w, addend, scale, shift)
+    B, Ti, Hi, Wi, cin = x.shape
+    d, nb, _, _, srows = _desc_cached((B, Ti, Hi, Wi), cin, w.shape[0], _kdims(w), tuple(stride), tuple(pad), False)
+    y = torch.empty((B, d.To, d.Ho, d.Wo, w.shape[0]), dtype=torch.float32, device=x.device)
+    stats = torch.empty((srows, 2, w.shape[0]), dtype=torch.float32, device=x.device) if bn_stats and srows > 0 else None
+    ws = workspace(x.device, nb) if nb else None
+    aff = lib.InAffine(scale.data_ptr(), shift.data_ptr(), int(bool(relu)))
+    lib.call("avid_conv_fwd_in", C.byref(d), _p(x), C.byref(aff), _p(w), _p(_fwd_u(w, d)), _p(addend), None, 0, _p(y), _p(stats),
+             _p(ws), ws.numel() if ws is not None else 0, _stream())
+    return (y, stats) if bn_stats else y
+
+
+def conv_wgrad_in(x, dy, w_like, stride, pad, scale, shift, relu=True):
+    """``avid_conv_wgrad_in`` as a plain call: the weight gradient of conv(ReLU?(x * scale + shift), w) given dy."""
+    _need_cuda(x, dy, scale, shift)
+    B, Ti, Hi, Wi, cin = x.shape
+    d, _, _, nbw, _ = _desc_cached((B, Ti, Hi, Wi), cin, w_like.shape[0], _kdims(w_like), tuple(stride), tuple(pad), False)
+    dw = torch.empty_like(w_like)
+    ws = workspace(x.device, nbw) if nbw else None
+    aff = lib.InAffine(scale.data_ptr(), shift.data_ptr(), int(bool(relu)))
+    lib.call("avid_conv_wgrad_in", C.byref(d), _p(x), C.byref(aff), _p(dy), _p(dw), _p(ws), ws.numel() if ws is not None else 0,
+             _stream())
+    return dw
 
 
 def conv_cl(x, w, stride=(1, 1, 1), pad=(0, 0, 0), addend=None, bias=None, relu=False, channel_first=False,

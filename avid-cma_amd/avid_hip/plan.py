@@ -73,10 +73,13 @@ class Arena:
 class Sym:
     """A tensor known to the compiler: reference, channels-last shape, and — for the output of a training-mode
     BatchNorm(+ReLU) whose only consumer is the next convolution — that BatchNorm's record (``ops.BnSource``)."""
-    __slots__ = ("ref", "shape", "bn")
+    __slots__ = ("ref", "shape", "bn", "affine")
 
-    def __init__(self, ref, shape, bn=None):
-        self.ref, self.shape, self.bn = ref, tuple(shape), bn
+    def __init__(self, ref, shape, bn=None, affine=None):
+        """``affine`` = (reference of the BatchNorm's saved [4][C] vectors, relu, C): ``ref`` is then the BatchNorm's INPUT and
+        the tensor this Sym stands for — ReLU(bn(ref)) — exists nowhere: its consumers apply the map themselves
+        (OP_CONV_FWD's i1 / OP_CONV_WGRAD's i0)."""
+        self.ref, self.shape, self.bn, self.affine = ref, tuple(shape), bn, affine
 
     @property
     def numel(self):
@@ -241,15 +244,25 @@ class Builder:
             raise Unsupported("weight layout")
         return ops._desc_cached((B, Ti, Hi, Wi), cin, cout, ops._kdims(conv_w), tuple(stride), tuple(pad), channel_first)
 
-    def conv_bn_fwd(self, conv, bn, x, addend=None, res=None, sole=True):
-        """ReLU(bn(conv(x) [+ addend])) (network_blocks._conv_bn in training mode).  Returns the layer record."""
+    def conv_bn_fwd(self, conv, bn, x, addend=None, res=None, sole=True, next_conv=None):
+        """ReLU(bn(conv(x) [+ addend])) (network_blocks._conv_bn in training mode).  Returns the layer record.
+
+        ``next_conv``: the ONLY consumer of this layer's output, if that is known to be a convolution.  When its kernels can apply
+        a BatchNorm (+ReLU) to their input while they stage it (``d.in_affine``: conv2x's temporal layers), this layer's
+        BatchNorm makes its statistics only and the returned ``h`` is the convolution's OUTPUT tagged with the map
+        (``Sym.affine``): the normalised tensor is never written or read."""
         w = conv.weight
         d, _, _, _, srows = self.desc(x.shape, w, conv.stride3, conv.padding3, conv.channel_first)
         ysh = (d.B, d.To, d.Ho, d.Wo, d.Cout)
         M = d.B * d.To * d.Ho * d.Wo
         y = self.fa.alloc(4 * M * d.Cout)
         stats = self.fa.alloc(4 * srows * 2 * d.Cout) if srows > 0 else None
-        self.emit(OP_CONV_FWD, d=d, i=(0,), t=(x.ref, self.ext(w), self.fwd_u(w, d), addend.ref if addend is not None else None, None, y, stats))
+        xa = x.affine
+        if xa is not None and not (d.in_affine and res is None):
+            raise Unsupported("a tensor with a pending BatchNorm reached a layer that cannot apply it")
+        self.emit(OP_CONV_FWD, d=d, i=(0,) if xa is None else (0, 2 if xa[1] else 1, xa[2]),
+                  t=(x.ref, self.ext(w), self.fwd_u(w, d), addend.ref if addend is not None else None, None, y, stats) +
+                    (() if xa is None else (xa[0],)))
         L = {"conv": conv, "bn": bn, "d": d, "x": x, "y": y, "w": w, "sole": sole, "res": None, "M": M}
         if res is not None:
             rconv = res
@@ -261,14 +274,19 @@ class Builder:
             self.emit(OP_CONV_FWD, d=dr, i=(0,), t=(x.ref, self.ext(rw), self.fwd_u(rw, dr), None, None, y_res, None))
             L["res"] = {"conv": rconv, "d": dr, "w": rw, "y": Sym(y_res, (d.B, dr.To, dr.Ho, dr.Wo, dr.Cout))}
         Cc = d.Cout
-        h = self.fa.alloc(4 * M * Cc)
+        defer = False
+        if next_conv is not None and addend is None and res is None:
+            nw = next_conv.weight
+            if ops.weight_layout_ok(nw) and nw.dtype == torch.float32 and nw.shape[1] == Cc and not next_conv.channel_first:
+                defer = self.desc(ysh, nw, next_conv.stride3, next_conv.padding3, False)[0].in_affine
+        h = None if defer else self.fa.alloc(4 * M * Cc)
         s4 = self.fa.alloc(4 * 4 * Cc)
         self.emit(OP_BN_FWD, n=(M,), i=(Cc, 1, srows if stats is not None else 0), f=(bn.momentum, bn.eps),
                   t=(y, self.ext(bn.weight), self.ext(bn.bias), self.ext(bn.running_mean), self.ext(bn.running_var), h, s4,
                      self.ext(bn.num_batches_tracked), stats))
         rec = BnRec(y, s4, 1, Cc)
         L["bnrec"] = rec
-        L["h"] = Sym(h, ysh, bn=rec)
+        L["h"] = Sym(y, ysh, bn=rec, affine=(s4, 1, Cc)) if defer else Sym(h, ysh, bn=rec)
         return L
 
     def linear_fwd(self, lin, x, relu):
@@ -310,10 +328,12 @@ class Builder:
             self.emit(OP_WGRAD_ITEM, stream=stream, d=d, t=(xr, dyr, self.grad(w)))
         self._ready(stream, *[t[3] for t in lst])
 
-    def wgrad(self, d, xr, dyr, w, flush_check=True):
+    def wgrad(self, d, xr, dyr, w, flush_check=True, xa=None):
         """The weight gradient of one layer: queued for a grouped launch (small layers), or its own launch on the
         trailing stream; False = the caller emits it on the compute stream (behind the input gradient)."""
         if self.group and d.groupable:
+            if xa is not None:
+                raise Unsupported("a grouped weight gradient cannot apply its input's BatchNorm")
             self.pending[self.S].append((d, xr, dyr, w))
             if len(self.pending[self.S]) >= ops.GROUP_MAX:
                 self.flush_group()
@@ -323,21 +343,29 @@ class Builder:
         if self.trailing:
             tr = self.trail()
             self.wait(tr, self.S)
-            self.emit(OP_CONV_WGRAD, stream=tr, d=d, t=(xr, dyr, self.grad(w)))
+            self.emit(OP_CONV_WGRAD, stream=tr, d=d, **self._wgrad_args(xr, dyr, w, xa))
             self._ready(tr, w)
             self.trail_used.add(tr)
             return True
         return False                                   # the caller emits it behind the input gradient
 
-    def wgrad_inline(self, d, xr, dyr, w):
-        self.emit(OP_CONV_WGRAD, d=d, t=(xr, dyr, self.grad(w)))
+    def _wgrad_args(self, xr, dyr, w, xa):
+        """i / t of an OP_CONV_WGRAD record; xa = Sym.affine of the layer's input (None: x is read as it is)."""
+        if xa is None:
+            return {"t": (xr, dyr, self.grad(w))}
+        return {"i": (2 if xa[1] else 1, xa[2]), "t": (xr, dyr, self.grad(w), xa[0])}
+
+    def wgrad_inline(self, d, xr, dyr, w, xa=None):
+        self.emit(OP_CONV_WGRAD, d=d, **self._wgrad_args(xr, dyr, w, xa))
         self._ready(self.S, w)
 
     def conv_bwd(self, d, w, x, g, need_dx, add=None, add_stride=None, res=None, g_res=None):
         """Backward of one convolution given g = d(loss)/d(conv output): weight gradient, [residual branch,] input
         gradient (ops._ConvCL.backward, same order of launches per stream).  Returns the reference of dx."""
-        done = self.wgrad(d, x.ref, g, w)
+        done = self.wgrad(d, x.ref, g, w, xa=x.affine)
         if res is not None:
+            if x.affine is not None:
+                raise Unsupported("residual convolution on a tensor with a pending BatchNorm")
             dr, rw = res["d"], res["w"]
             if need_dx:
                 # compact input gradient of the residual convolution: a dense 1x1x1 dgrad over the sub-sampled grid
@@ -365,7 +393,7 @@ class Builder:
                 iv += [0, 0]
             self.emit(OP_CONV_DGRAD, d=d, i=iv, t=t)
         if not done:
-            self.wgrad_inline(d, x.ref, g, w)
+            self.wgrad_inline(d, x.ref, g, w, xa=x.affine)
         return dx
 
     def conv_bn_bwd(self, L, dh, need_dx=True, add=None, g_res=None):
@@ -378,7 +406,7 @@ class Builder:
         self._ready(self.S, bn.weight, bn.bias)
         x = L["x"]
         if not L["sole"]:
-            x = Sym(x.ref, x.shape)                   # not the only consumer: no BatchNorm hand-over
+            x = Sym(x.ref, x.shape, affine=x.affine)  # not the only consumer: no BatchNorm hand-over
         dx = self.conv_bwd(d, L["w"], x, g, need_dx, add=add, res=L["res"], g_res=g_res)
         return g, dx
 
@@ -411,9 +439,11 @@ class Builder:
             if not (nb._FUSE_RES and any(v == 2 for v in rs) and all(v in (1, 2) for v in rs)
                     and any(v == 2 for v in ss) and all(v in (1, 2) for v in ss) and x.numel * 4 < (1 << 31)):
                 raise Unsupported("residual convolution outside the fused pattern")
-        L1 = self.conv_bn_fwd(blk.spt_conv1, blk.spt_bn1, x, res=blk.res_conv if blk.res else None)
+        # (spt_bn1 -> tmp_conv1 and spt_bn2 -> tmp_conv2: each BatchNorm's output has exactly one reader, the next convolution)
+        L1 = self.conv_bn_fwd(blk.spt_conv1, blk.spt_bn1, x, res=blk.res_conv if blk.res else None,
+                              next_conv=None if blk.res else blk.tmp_conv1)
         L2 = self.conv_bn_fwd(blk.tmp_conv1, blk.tmp_bn1, L1["h"])
-        L3 = self.conv_bn_fwd(blk.spt_conv2, blk.spt_bn2, L2["h"])
+        L3 = self.conv_bn_fwd(blk.spt_conv2, blk.spt_bn2, L2["h"], next_conv=blk.tmp_conv2)
         addend = L1["res"]["y"] if blk.res else x
         L4 = self.conv_bn_fwd(blk.tmp_conv2, blk.out_bn, L3["h"], addend=addend)
         return (L1, L2, L3, L4), L4["h"]

@@ -134,7 +134,7 @@ extern "C" int avid_timing_report(char* buf, size_t len) {
 }
 
 extern "C" const char* avid_last_error(void) { return avid::g_err; }
-extern "C" int avid_version(void) { return 120; }
+extern "C" int avid_version(void) { return 130; }
 
 extern "C" int avid_device_info(int device, int* cu_count, int* lds_bytes, char* arch, int arch_len) {
   hipDeviceProp_t prop;

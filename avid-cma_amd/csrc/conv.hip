@@ -91,6 +91,12 @@ struct ConvArgs {
   const void* wsp;
   int wsp_nrec, wsp_kstep;
   int stats_rows;  // tconv64_kernel: rows of `stats` the caller will fold (avid_conv_fwd_stats_rows / avid_conv_dgrad_bn_rows)
+  // avid_conv_fwd_in: `src` is the INPUT of a BatchNorm (+ReLU) whose output this convolution consumes; the loader applies
+  // fma(x, in_scale[c], in_shift[c]) (+ max(., 0)) to every element it stages — bn_apply_kernel's expression, bit for bit — so
+  // the normalised tensor is never written (tconv64_kernel only; null = src is read as it is)
+  const float* in_scale;
+  const float* in_shift;
+  int in_relu;
 };
 
 constexpr int BK = 32;
@@ -1201,10 +1207,12 @@ constexpr int TC_T = 8;                       // frames (= waves)
 constexpr int TC_ROWS = TC_P * TC_T;
 constexpr int TC_B_BYTES = 6 * PK_BCH;        // 3 taps x 2 channel blocks
 constexpr int TC_STAGE = TC_ROWS * LDK;       // floats per A stage (one 32-channel block)
-constexpr size_t TC_LDS = TC_B_BYTES + (2 * TC_STAGE + TC_P * LDK) * sizeof(float);     // weights | two A stages | a frame of zeros
+constexpr size_t TC_LDS = TC_B_BYTES + (2 * TC_STAGE + TC_P * LDK + 128) * sizeof(float);     // weights | two A stages | a frame of zeros | AFF: scale, shift
 
-template <int MODE, int EPI>
+// AFF (forward): the staged rows are the input of a BatchNorm (+ReLU); the staging threads apply it (ConvArgs::in_scale)
+template <int MODE, int EPI, bool AFF = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void tconv64_kernel(const ConvArgs p) {
+  static_assert(!AFF || MODE == 0, "the input affine map belongs to the forward");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* Bs = reinterpret_cast<char*>(smem);
   float* As = smem + TC_B_BYTES / 4;
@@ -1284,9 +1292,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       va[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
                                               rsA, ld_voff, __builtin_amdgcn_readfirstlane(c128 + i * frame_bytes), 0));
   };
-  auto store_stage = [&](float* st) {
+  // AFF: scale / shift of this thread's four channels in either channel block; rows past the last position stay zero (their
+  // loads fell off the buffer: the outputs computed from them must not reach the BatchNorm partial sums)
+  // (the vectors sit in LDS behind the padding frame — scale[64] | shift[64], written by the leading waves in the prologue — and
+  //  are read per item: held in registers for the whole kernel they were 16 of them, and 8 / 19 spilled ones)
+  const float* aff = As + 2 * TC_STAGE + TC_P * LDK;
+  auto store_stage = [&](float* st, int blk, bool first = false) {   // blk: the channel block of the item in the registers
+    floatx4 asc = {0.f, 0.f, 0.f, 0.f}, ash = asc;
+    if (AFF) {
+      if (first) {                                          // the prologue's item: before the barrier that publishes the LDS copy
+        asc = *reinterpret_cast<const floatx4*>(p.in_scale + blk * 32 + lcol);
+        ash = *reinterpret_cast<const floatx4*>(p.in_shift + blk * 32 + lcol);
+      } else {
+        asc = *reinterpret_cast<const floatx4*>(aff + blk * 32 + lcol);
+        ash = *reinterpret_cast<const floatx4*>(aff + 64 + blk * 32 + lcol);
+      }
+    }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<floatx4*>(&st[(trow + 32 * i) * LDK + lcol]) = va[i];
+    for (int i = 0; i < 8; ++i) {
+      floatx4 v = va[i];
+      if (AFF) {
+        const bool ok = ld_voff != OOB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float o = fmaf(v[j], asc[j], ash[j]);             // bn_apply_kernel's expression, bit for bit
+          if (p.in_relu) o = fmaxf(o, 0.f);
+          v[j] = ok ? o : 0.f;
+        }
+      }
+      *reinterpret_cast<floatx4*>(&st[(trow + 32 * i) * LDK + lcol]) = v;
+    }
   };
 
   // ---- prologue: the weights -> LDS (72 KB, once; the older waves), item 0 -> stage 0, item 1 -> registers (the younger)
@@ -1297,12 +1332,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < 18; ++i)
       wv[i] = __builtin_bit_cast(pk_uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (tid + 256 * i) * 16, 0, 0));
     for (int i = tid; i < TC_P * LDK; i += 256) As[2 * TC_STAGE + i] = 0.f;       // the padding frame
+    if (AFF && tid < 128) As[2 * TC_STAGE + TC_P * LDK + tid] = tid < 64 ? p.in_scale[tid] : p.in_shift[tid - 64];
 #pragma unroll
     for (int i = 0; i < 18; ++i) *reinterpret_cast<pk_uintx4*>(Bs + (tid + 256 * i) * 16) = wv[i];
   } else {
     ld_tile(0);
     issue_loads(0);
-    store_stage(As);
+    store_stage(As, 0, true);
     if (nitems > 1) issue_loads(1);
   }
   __syncthreads();
@@ -1448,7 +1484,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // one item (trailing waves): the registers hold item it + 1 -> the other stage (every wave left it at the last barrier),
   // item it + 2's loads go out; then, all waves, the products of item it from its stage; one barrier per item
   auto stage_next = [&](int it, int cb) {
-    if (it + 1 < nitems) store_stage(As + (cb ^ 1) * TC_STAGE);
+    if (it + 1 < nitems) store_stage(As + (cb ^ 1) * TC_STAGE, cb ^ 1);
     if (it + 2 < nitems) {
       if (cb == 0) ld_tile(it + 2);
       issue_loads(it + 2);
@@ -1519,8 +1555,11 @@ struct TwgradArgs {
   const float* x; const float* dy; float* part;    // part: [grid][64][3][64]
   int B, HW;
   unsigned mg; int sh;                             // multiply-shift division by HW
+  const float* in_scale; const float* in_shift;    // AFF: x is the input of a BatchNorm (+ReLU) the staging threads apply (ConvArgs::in_scale)
+  int in_relu;
 };
 
+template <bool AFF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void twgrad64_kernel(const TwgradArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1554,11 +1593,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       vx[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ld_voff, so, 0));
     }
   };
+  floatx4 asc = {0.f, 0.f, 0.f, 0.f}, ash = asc;           // AFF: scale / shift of this thread's four channels
+  if (AFF) {
+    asc = *reinterpret_cast<const floatx4*>(p.in_scale + lcol);
+    ash = *reinterpret_cast<const floatx4*>(p.in_shift + lcol);
+  }
   auto store_stage = [&](float* st) {                     // st: [dy plane | x plane]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      floatx4 v = vx[i];
+      if (AFF) {                                          // (rows past the last position stay zero: their loads fell off the buffer)
+        const bool ok = ld_voff != OOB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float o = fmaf(v[j], asc[j], ash[j]);           // bn_apply_kernel's expression, bit for bit
+          if (p.in_relu) o = fmaxf(o, 0.f);
+          v[j] = ok ? o : 0.f;
+        }
+      }
       *reinterpret_cast<floatx4*>(&st[(trow + 32 * i) * WG_LD_C + lcol]) = vy[i];
-      *reinterpret_cast<floatx4*>(&st[TWG_PLANE + (trow + 32 * i) * WG_LD_C + lcol]) = vx[i];
+      *reinterpret_cast<floatx4*>(&st[TWG_PLANE + (trow + 32 * i) * WG_LD_C + lcol]) = v;
     }
   };
   floatx16 acc[3];
@@ -3298,17 +3352,27 @@ static bool tconv_takes(const ConvArgs& a, int mode) {
   return tconv_mode() == 2 || ntiles >= 3ll * device_cus();
 }
 
-template <int MODE, int EPI>
-static void launch_tconv_e(const ConvArgs& a, int grid, hipStream_t s) {
+template <int MODE, int EPI, bool AFF>
+static void launch_tconv_ea(const ConvArgs& a, int grid, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = tconv64_kernel<MODE, EPI>;
+  auto kern = tconv64_kernel<MODE, EPI, AFF>;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TC_LDS);
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), TC_LDS, s, a);
 }
+template <int MODE, int EPI>
+static void launch_tconv_e(const ConvArgs& a, int grid, hipStream_t s) {
+  if constexpr (MODE == 0) {
+    if (a.in_scale) { launch_tconv_ea<MODE, EPI, true>(a, grid, s); return; }
+  }
+  launch_tconv_ea<MODE, EPI, false>(a, grid, s);
+}
 
+// launches of tconv64_kernel / twgrad64_kernel since the library was loaded: [0] reading their input as it is, [1] applying a
+// BatchNorm to it while staging (avid_debug_in_affine_launches: tests assert that the fused form is what ran)
+static std::atomic<long long> g_tconv_launches[2];
 template <int MODE>
 static int launch_tconv(ConvArgs& a, hipStream_t s) {
   magic_for(a.Hs * a.Ws, a.mgW, a.shW);       // position -> clip
@@ -3319,6 +3383,7 @@ static int launch_tconv(ConvArgs& a, hipStream_t s) {
     if (MODE == 1 && cap > 0 && grid > cap) grid = cap;
   }
   const double K = 3.0 * 64;
+  ++g_tconv_launches[MODE == 0 && a.in_scale ? 1 : 0];
   ScopedTimer t(s, MODE == 0 ? "tconv64_kernel<0>" : "tconv64_kernel<1>", 2.0 * a.M * 64 * K,
                 4.0 * ((double)a.M * 64 + 64 * K + (double)a.M * 64 * (1 + (a.addend ? 1 : 0) + (a.bnb_x ? 1 : 0))));
   const int epi = (a.addend ? 1 : 0) | ((MODE == 1 && a.bnb_x) ? 8 : 0);
@@ -3561,6 +3626,8 @@ static int dispatch_igemm(ConvArgs& a, void* ws, size_t ws_bytes, hipStream_t s)
         return launch_tconv<MODE>(k, s);
       }
     }
+    AVID_REQUIRE(!a.in_scale, AVID_E_UNSUPPORTED,
+                 "conv_fwd_in: this layer does not run on a kernel that applies the input's BatchNorm (avid_conv_takes_in_affine)");
     if (pk.f > 1 && (ws == nullptr || ws_bytes < sizeof(float) * pk.ws_floats)) {   // no scratch: unsplit
       AVID_REQUIRE(!a.stats, AVID_E_BADARG, "conv: BatchNorm partials need the planned workspace");
       pk.tail_units /= pk.f;
@@ -3808,12 +3875,55 @@ extern "C" int avid_conv_fwd_stats_rows(const avid_conv_desc* d) {
   return pk.grid + (pk.f > 1 ? (int)ceil_div(M - pk.tail_row0, stats_rpb(M - pk.tail_row0, d->Cout)) : 0);
 }
 
+// conv2x's temporal layers at the descriptor level (the twin of tconv_takes, which sees the call's arguments): forward (which 0)
+// / input gradient (1) on tconv64_kernel — given the layer's pre-split weights
+static bool tconv_layer(const avid_conv_desc* d, int which) {
+  const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
+  const long long tc_tiles = ((long long)d->B * d->Hi * d->Wi + TC_P - 1) / TC_P;
+  return PK_SPLIT && tconv_mode() && vec && which >= 0 && which < 2 && (tconv_parts() & (1 << which)) && d->kt == 3 && d->kh == 1 && d->kw == 1 &&
+         d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 1 && d->ph == 0 && d->pw == 0 && d->Cin == 64 && d->Cout == 64 && d->Ti == TC_T &&
+         d->To == TC_T && (long long)d->B * d->Ti * d->Hi * d->Wi * 256 < (1ll << 31) &&
+         (tconv_mode() == 2 || tc_tiles >= 3ll * device_cus());
+}
+static bool twgrad_takes(const avid_conv_desc* d);
+
+// AVID_IN_AFFINE (default 1): 0 = no layer offers to apply its input's BatchNorm (every BatchNorm writes its output)
+static bool in_affine_on() {
+  static std::atomic<int> v{-1};
+  int m = v.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("AVID_IN_AFFINE");
+    m = e ? (atoi(e) != 0 ? 1 : 0) : 1;
+    v.store(m, std::memory_order_relaxed);
+  }
+  return m != 0;
+}
+
+extern "C" int avid_conv_takes_in_affine(const avid_conv_desc* d) {
+  if (!d || validate(d) || !in_affine_on()) return 0;
+  // both readers of the layer's input have to apply the map: the forward (tconv64_kernel) and the weight gradient (twgrad64_kernel)
+  return tconv_layer(d, 0) && twgrad_takes(d) && conv_takes_split(d, 0) ? 1 : 0;
+}
+
+extern "C" long long avid_debug_in_affine_launches(int fused) { return g_tconv_launches[fused ? 1 : 0].load(std::memory_order_relaxed); }
+
 extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const float* u, const float* addend,
                              const float* bias, int relu, float* y, float* bn_partials, void* ws, size_t ws_bytes,
                              avid_stream_t stream) {
+  return avid_conv_fwd_in(d, x, nullptr, w, u, addend, bias, relu, y, bn_partials, ws, ws_bytes, stream);
+}
+
+extern "C" int avid_conv_fwd_in(const avid_conv_desc* d, const float* x, const avid_in_affine* in, const float* w, const float* u,
+                                const float* addend, const float* bias, int relu, float* y, float* bn_partials, void* ws,
+                                size_t ws_bytes, avid_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
   AVID_REQUIRE(x && w && y, AVID_E_BADARG, "conv_fwd: null pointer");
+  if (in) {
+    AVID_REQUIRE(in->scale && in->shift, AVID_E_BADARG, "conv_fwd_in: null scale / shift");
+    AVID_REQUIRE(avid_conv_takes_in_affine(d) && u, AVID_E_UNSUPPORTED,
+                 "conv_fwd_in: this layer does not apply its input's BatchNorm (avid_conv_takes_in_affine; needs its pre-split weights)");
+  }
   if (stem_fwd_supported(d) && !addend && !bias && !relu && ws && ws_bytes >= stem_fwd_ws_bytes(d))
     return stem_fwd(d, x, w, y, bn_partials, ws, (hipStream_t)stream);
   if (wino_supported(d, 0) && !bias && !relu) {
@@ -3839,6 +3949,7 @@ extern "C" int avid_conv_fwd(const avid_conv_desc* d, const float* x, const floa
   a.M = d->B * d->To * d->Ho * d->Wo;
   a.mode = 0;
   a.relu = relu;
+  if (in) { a.in_scale = in->scale; a.in_shift = in->shift; a.in_relu = in->relu; }
   fill_src_strides(d, a.ssB, a.ssT, a.ssH, a.ssW, a.ssC);
   const bool vec = (d->Cin % 32 == 0) && !d->x_channel_first;
   if (bn_partials) {
@@ -4143,9 +4254,19 @@ extern "C" size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d) {
 
 extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,
                                size_t ws_bytes, avid_stream_t stream) {
+  return avid_conv_wgrad_in(d, x, nullptr, dy, dw, ws, ws_bytes, stream);
+}
+
+extern "C" int avid_conv_wgrad_in(const avid_conv_desc* d, const float* x, const avid_in_affine* in, const float* dy, float* dw,
+                                  void* ws, size_t ws_bytes, avid_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
   AVID_REQUIRE(x && dy && dw, AVID_E_BADARG, "conv_wgrad: null pointer");
+  if (in) {
+    AVID_REQUIRE(in->scale && in->shift, AVID_E_BADARG, "conv_wgrad_in: null scale / shift");
+    AVID_REQUIRE(avid_conv_takes_in_affine(d) && ws && ws_bytes >= twgrad_ws_bytes(d), AVID_E_UNSUPPORTED,
+                 "conv_wgrad_in: this layer does not apply its input's BatchNorm (avid_conv_takes_in_affine; needs its workspace)");
+  }
   if (stem_wgrad_supported(d) && ws && ws_bytes >= stem_wgrad_ws_bytes(d))
     return stem_wgrad(d, x, dy, dw, ws, (hipStream_t)stream);
   if (wino_wgrad_supported(d) && ws && ws_bytes >= wino_wgrad_ws_bytes(d)) {
@@ -4161,20 +4282,23 @@ extern "C" int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const fl
   }
   if (twgrad_takes(d) && ws && ws_bytes >= twgrad_ws_bytes(d)) {   // conv2x's temporal layers: the taps share their split fragments
     hipStream_t s = (hipStream_t)stream;
-    TwgradArgs a;
+    TwgradArgs a{};
     a.x = x; a.dy = dy; a.part = static_cast<float*>(ws);
     a.B = d->B; a.HW = d->Hi * d->Wi;
+    if (in) { a.in_scale = in->scale; a.in_shift = in->shift; a.in_relu = in->relu; }
     magic_for(a.HW, a.mg, a.sh);
     const int grid = twgrad_grid(d);
     static bool set = false;
     if (!set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(twgrad64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TWG_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(twgrad64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TWG_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(twgrad64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TWG_LDS);
       set = true;
     }
     const double M = (double)d->B * TC_T * a.HW, K = 3.0 * 64;
     {
       ScopedTimer t(s, "twgrad64_kernel", 2.0 * M * 64 * K, 4.0 * (M * 64 + M * 64 + 64 * K));
-      hipLaunchKernelGGL(twgrad64_kernel, dim3(grid), dim3(512), TWG_LDS, s, a);
+      if (in) hipLaunchKernelGGL(twgrad64_kernel<true>, dim3(grid), dim3(512), TWG_LDS, s, a);
+      else hipLaunchKernelGGL(twgrad64_kernel<false>, dim3(grid), dim3(512), TWG_LDS, s, a);
     }
     rc = check_launch("twgrad64");
     if (rc) return rc;
@@ -4445,10 +4569,7 @@ extern "C" int avid_conv_kernel_name(const avid_conv_desc* d, int which, char* b
   };
   // conv2x's temporal layers (given their pre-split weights): tconv64_kernel — the descriptor-level form of tconv_takes
   const long long tc_tiles = ((long long)d->B * d->Hi * d->Wi + TC_P - 1) / TC_P;
-  const bool tc = PK_SPLIT && tconv_mode() && vec && which < 2 && (tconv_parts() & (1 << which)) && d->kt == 3 && d->kh == 1 && d->kw == 1 && d->st == 1 && d->sh == 1 &&
-                  d->sw == 1 && d->pt == 1 && d->ph == 0 && d->pw == 0 && d->Cin == 64 && d->Cout == 64 && d->Ti == TC_T &&
-                  d->To == TC_T && (long long)d->B * d->Ti * d->Hi * d->Wi * 256 < (1ll << 31) &&
-                  (tconv_mode() == 2 || tc_tiles >= 3ll * device_cus());
+  const bool tc = tconv_layer(d, which);
   if (tc) {
     snprintf(buf, len, "tconv64_kernel<%d> grid=%d", which, balanced_grid(tc_tiles));
     return AVID_OK;

@@ -979,9 +979,12 @@ extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* 
                                  void* ws, size_t ws_bytes, avid_stream_t stream) {
   int rc = bn_check(M, C, "bn_fwd_train");
   if (rc) return rc;
-  AVID_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && save_scale && save_shift && ws, AVID_E_BADARG,
+  AVID_REQUIRE(x && gamma && beta && save_mean && save_invstd && save_scale && save_shift && ws, AVID_E_BADARG,
                "bn_fwd_train: null pointer");
   AVID_REQUIRE(ws_bytes >= avid_bn_workspace_bytes(M, C), AVID_E_BADARG, "bn_fwd_train: workspace too small");
+  // y == NULL: statistics only — mean / invstd / scale / shift (and the running statistics) are made, the normalised tensor is
+  // not: its consumer applies fma(x, scale, shift) (+ReLU) while it stages x (avid_conv_fwd_in / avid_conv_wgrad_in)
+
   hipStream_t s = (hipStream_t)stream;
   BnPlan p = bn_plan(M, C);
   float* part = static_cast<float*>(ws);
@@ -996,7 +999,7 @@ extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* 
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk), dim3(256), 0, s, x, part, (long long)M, C, p.G,
                        p.rows_per_pass, p.rows_per_block);
   }
-  if (bn_fused_ok(M, C)) {
+  if (y && bn_fused_ok(M, C)) {
     ScopedTimer t(s, "bn_fin_apply_kernel", 0.0, 8.0 * M * C);
     hipLaunchKernelGGL(bn_fin_apply_kernel, dim3(bn_fused_grid(M, C)), dim3(256), 0, s, part, nblk, (long long)M, C, gamma,
                        beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift,
@@ -1007,7 +1010,7 @@ extern "C" int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* 
                      C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift,
                      reinterpret_cast<long long*>(num_batches_tracked));
   const long long n4 = (long long)M * p.G;
-  {
+  if (y) {
     ScopedTimer t(s, "bn_apply_kernel", 0.0, 8.0 * M * C);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, x, y, scale, shift, n4, p.G, relu);
   }

@@ -205,9 +205,16 @@ extern "C" int avid_program_run(const avid_instr* prog, int begin, int end, void
         }
         break;
       }
-      case AVID_OP_CONV_FWD:
-        rc = avid_conv_fwd(&in.d, F(t[0]), F(t[1]), F(t[2]), F(t[3]), F(t[4]), in.i[0], F(t[5]), F(t[6]), w, wb, s);
+      case AVID_OP_CONV_FWD: {
+        avid_in_affine aff;       // i[1]: 0 none, 1 the input's BatchNorm, 2 ... + ReLU; t[7]: its saved [4][C] vectors, i[2] = C
+        if (in.i[1]) {
+          const float* s4 = F(t[7]);
+          aff.scale = s4 + 2 * in.i[2]; aff.shift = s4 + 3 * in.i[2]; aff.relu = in.i[1] == 2;
+        }
+        rc = avid_conv_fwd_in(&in.d, F(t[0]), in.i[1] ? &aff : nullptr, F(t[1]), F(t[2]), F(t[3]), F(t[4]), in.i[0], F(t[5]), F(t[6]),
+                              w, wb, s);
         break;
+      }
       case AVID_OP_CONV_DGRAD: {
         avid_bn_bwd_fuse bn;
         if (in.i[4]) {
@@ -220,9 +227,15 @@ extern "C" int avid_program_run(const avid_instr* prog, int begin, int end, void
                              in.i[4] ? &bn : nullptr, w, wb, s);
         break;
       }
-      case AVID_OP_CONV_WGRAD:
-        rc = avid_conv_wgrad(&in.d, F(t[0]), F(t[1]), F(t[2]), w, wb, s);
+      case AVID_OP_CONV_WGRAD: {
+        avid_in_affine aff;       // i[0]: 0 none, 1 the input's BatchNorm, 2 ... + ReLU; t[3]: its saved [4][C] vectors, i[1] = C
+        if (in.i[0]) {
+          const float* s4 = F(t[3]);
+          aff.scale = s4 + 2 * in.i[1]; aff.shift = s4 + 3 * in.i[1]; aff.relu = in.i[0] == 2;
+        }
+        rc = avid_conv_wgrad_in(&in.d, F(t[0]), in.i[0] ? &aff : nullptr, F(t[1]), F(t[2]), w, wb, s);
         break;
+      }
       case AVID_OP_WGRAD_GROUP: {
         const int n = in.i[0];
         AVID_REQUIRE(n >= 1 && n <= 12 && k + n < end, AVID_E_BADARG, "program record %d: a group of %d items", k, n);

@@ -84,6 +84,28 @@ int avid_conv_fwd(const avid_conv_desc* d, const float* x, const float* w, const
                   const float* bias, int relu, float* y, float* bn_partials, void* ws, size_t ws_bytes,
                   avid_stream_t stream);
 
+/* The same convolution reading the INPUT of a BatchNorm (+ReLU) instead of its output (version >= 130): x is the tensor the
+ * BatchNorm normalises (the previous convolution's output), `in` its saved scale / shift ([Cin] each, avid_bn_fwd_train's
+ * save_scale / save_shift) — the kernel applies fma(x, scale[c], shift[c]) (+ max(., 0) if relu) to every element it stages,
+ * the expression of avid_bn_fwd_train's own apply pass, bit for bit; padding stays zero.  The normalised tensor is then never
+ * written: avid_bn_fwd_train(y = NULL) makes the statistics only.  Replaces the `x = ReLU(bn(x))` round trip through memory
+ * between models/network_blocks.py:36 / 41 and :37 / 42 (spt_bn1 -> tmp_conv1, spt_bn2 -> tmp_conv2).  in = NULL: avid_conv_fwd.
+ * Only layers for which avid_conv_takes_in_affine() answers 1 (conv2x's temporal layers: tconv64_kernel / twgrad64_kernel, given
+ * their pre-split weights as u); anything else returns AVID_E_UNSUPPORTED.  A layer that takes it must be given the same pair
+ * in its weight gradient (avid_conv_wgrad_in); its input gradient does not read x. */
+typedef struct avid_in_affine {
+  const float* scale;
+  const float* shift;
+  int32_t relu;
+} avid_in_affine;
+int avid_conv_takes_in_affine(const avid_conv_desc* d);
+int avid_conv_fwd_in(const avid_conv_desc* d, const float* x, const avid_in_affine* in, const float* w, const float* u,
+                     const float* addend, const float* bias, int relu, float* y, float* bn_partials, void* ws, size_t ws_bytes,
+                     avid_stream_t stream);
+/* Launches of tconv64_kernel's forward / twgrad64_kernel since the library was loaded that read their input as it is
+ * (fused = 0) or applied a BatchNorm to it while staging (fused = 1): tests assert which form ran. */
+long long avid_debug_in_affine_launches(int fused);
+
 /* dx = conv_transpose(dy, w) [+ addend].  ws: scratch for the transposed weights (+ split-K slabs).
  * wt (nullable): the weights already repacked as [Cin][taps][Cout] by avid_weight_transpose_batched (mode 0, current
  * for this w); NULL = repack inside the call (one extra small launch per layer).
@@ -217,6 +239,10 @@ int avid_cu_budget(void);
 size_t avid_conv_wgrad_workspace_bytes(const avid_conv_desc* d);
 int avid_conv_wgrad(const avid_conv_desc* d, const float* x, const float* dy, float* dw, void* ws,
                     size_t ws_bytes, avid_stream_t stream);
+/* ... with x the input of the BatchNorm (+ReLU) whose output the layer convolved (avid_conv_fwd_in's twin; in = NULL:
+ * avid_conv_wgrad).  Needs the layer's workspace. */
+int avid_conv_wgrad_in(const avid_conv_desc* d, const float* x, const avid_in_affine* in, const float* dy, float* dw, void* ws,
+                       size_t ws_bytes, avid_stream_t stream);
 
 /* The weight gradients of up to 12 layers in ONE persistent launch (+ one grouped reduce): the small layers of a stage
  * (conv3x-5x temporal / strided / residual convolutions, audio blocks, heads — backward of models/network_blocks.py:
@@ -245,7 +271,9 @@ size_t avid_bn_workspace_bytes(int64_t M, int C);
  * (momentum, unbiased var); y = [relu](fma(x, scale, shift)) with scale = gamma * invstd,
  * shift = beta - mean * scale, both also saved ([C]) so backward can recompute the ReLU mask bit-exactly.
  * num_batches_tracked: device int64 counter bumped by one (nn.BatchNorm's buffer), or NULL.
- * partials / nparts: [nparts][2][C] partial sums of x from avid_conv_fwd (skips the statistics pass), or NULL / 0. */
+ * partials / nparts: [nparts][2][C] partial sums of x from avid_conv_fwd (skips the statistics pass), or NULL / 0.
+ * y = NULL (version >= 130): statistics only — the saved vectors and the running statistics are made, the normalised tensor
+ * is not; its consumer applies the map while it stages x (avid_conv_fwd_in / avid_conv_wgrad_in). */
 int avid_bn_fwd_train(int64_t M, int C, const float* x, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps, int relu,
                       float* y, float* save_mean, float* save_invstd, float* save_scale,
@@ -487,10 +515,11 @@ enum {
   AVID_OP_NOP = 0,
   AVID_OP_WAIT = 1,          /* stream i[0] waits for everything issued so far on stream i[1] (event record + wait) */
   AVID_OP_MEMSET0 = 2,       /* t0 <- zeros, n[0] bytes */
-  AVID_OP_CONV_FWD = 3,      /* d; t: x w u addend bias y bn_partials; i0 relu */
+  AVID_OP_CONV_FWD = 3,      /* d; t: x w u addend bias y bn_partials [in_s4]; i0 relu, i1 input BatchNorm (0 none, 1 affine, 2 + ReLU:
+                                x is then that BatchNorm's input and t7 its saved [4][C] vectors, i2 = C: avid_conv_fwd_in) */
   AVID_OP_CONV_DGRAD = 4,    /* d; t: dy w wt u addend dx bn.x bn.scale bn.shift bn.mean bn.invstd bn.partials;
                                 i0..2 addend strides (0 = dense addend), i3 bn.relu, i4 bn present */
-  AVID_OP_CONV_WGRAD = 5,    /* d; t: x dy dw */
+  AVID_OP_CONV_WGRAD = 5,    /* d; t: x dy dw [in_s4]; i0 input BatchNorm as AVID_OP_CONV_FWD's i1 (t3, i1 = C: avid_conv_wgrad_in) */
   AVID_OP_WGRAD_GROUP = 6,   /* i0 = n, followed by n AVID_OP_WGRAD_ITEM records (d; t: x dy dw) */
   AVID_OP_WGRAD_ITEM = 7,
   AVID_OP_BN_FWD = 8,        /* n0 M; i0 C, i1 relu, i2 nparts; f0 momentum, f1 eps;

@@ -29,7 +29,7 @@ def main():
     sd = m.state_dict()
     m.load_state_dict({k: torch.from_numpy(detgen.det_param(f"w:{k}", tuple(v.shape)).copy()).to(v.dtype) for k, v in sd.items()})
     m = m.to(dev).train()
-    N, K, bs = 2000, 128, 4
+    N, K, bs = 2000, 128, int(os.environ.get("PROBE_BS", "4"))
     crit = criterions.AVID(num_data=N, embedding_dim=128, num_negatives=K, momentum=0.5, device=0)
     gg = torch.Generator().manual_seed(3)
     crit.nce_average.view1_mem.copy_(F.normalize(torch.randn(N, 128, generator=gg), dim=1))

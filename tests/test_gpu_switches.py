@@ -93,3 +93,13 @@ def test_cu_budget_is_deterministic_and_reported(gpu_device):
         assert ops.set_cu_budget(10 * full) == full
     finally:
         assert ops.set_cu_budget(0) == full == torch.cuda.get_device_properties(0).multi_processor_count
+
+
+def test_batchnorm_applied_by_its_consumer_is_bit_identical_at_batch_64(gpu_device):
+    """AVID_IN_AFFINE: at the benchmark's batch conv2x's temporal layers (tconv64_kernel / twgrad64_kernel) apply the BatchNorm
+    (+ReLU) in front of them while they stage its INPUT — fma(x, scale, shift), max(., 0): bn_apply_kernel's expression — and the
+    four normalised tensors are never written.  Same values element for element, so three steps are bit-identical to the
+    unfused arrangement (which the small-batch probes above run: tconv64_kernel wants three rounds of tiles)."""
+    on = _probe({"PROBE_BS": "64"})
+    off = _probe({"PROBE_BS": "64", "AVID_IN_AFFINE": "0"})
+    assert on["losses"] == off["losses"] and on["grad_sha"] == off["grad_sha"]

@@ -168,3 +168,69 @@ def test_tconv_dispatch_rule(gpu_device, kernel_log, tconv):
         with kernel_log() as log:
             ops.conv_cl(x, w, stride, (1, 0, 0))
         assert log.launches("tconv64_kernel") == 0
+
+
+@pytest.mark.parametrize("relu", [True, False], ids=["relu", "linear"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_tconv_applies_the_batchnorm_in_front_of_it_bit_identically(shape, relu, gpu_device, kernel_log, tconv):
+    """avid_conv_fwd_in / avid_conv_wgrad_in (models/network_blocks.py:36-37, 41-42: spt_bn -> ReLU -> tmp_conv): the layer reads
+    the BatchNorm's INPUT and its saved scale / shift and applies fma(x, scale, shift) (+ max(., 0)) while it stages — against the
+    same layer reading the tensor avid_bn_fwd_train wrote with that very expression: outputs, BatchNorm partial sums of the output
+    and the weight gradient are bit-identical, with and without the residual addend, on ragged tiles (rows past the last
+    position must stay zero: ReLU(shift) there would leak into the partial sums) and in clips' padding frames."""
+    from avid_hip import lib, ops
+    ops._DESC_CACHE.clear()                       # (what a layer offers depends on the tconv switch the fixture set)
+    try:
+        B, Hi, Wi = shape
+        stride, pad = (1, 1, 1), (1, 0, 0)
+        x = T(detgen.det_normalish(f"tcaff:{shape}:x", (B, 8, Hi, Wi, 64))).to(gpu_device)
+        gamma = T(detgen.det_uniform(f"tcaff:{shape}:gamma", (64,)) * 3.0 - 1.0).to(gpu_device)     # some negative scales
+        beta = T(detgen.det_uniform(f"tcaff:{shape}:beta", (64,)) - 0.5).to(gpu_device)
+        rm, rv = torch.zeros(64, device=gpu_device), torch.ones(64, device=gpu_device)
+        src = ops.BnSource(None, None, relu)
+        z = ops.batch_norm_cl(x, gamma, beta, rm, rv, True, relu=relu, src=src)                      # statistics + apply pass
+        scale, shift = src.stats4[2].contiguous(), src.stats4[3].contiguous()
+        w = ops.make_weight(64, 64, 3, 1, 1)
+        w.copy_(T(detgen.det_param(f"tcaff:{shape}:w.weight", (64, 64, 3, 1, 1))))
+        w = w.to(gpu_device)
+        d = ops._desc_cached((B, 8, Hi, Wi), 64, 64, (3, 1, 1), stride, pad, False)[0]
+        assert d.in_affine
+        count = lib.raw("avid_debug_in_affine_launches")
+        add = T(detgen.det_uniform(f"tcaff:{shape}:add", (B, 8, Hi, Wi, 64))).to(gpu_device)
+        for addend in (None, add):
+            y_ref, p_ref = ops.conv_cl(z, w, stride, pad, addend=addend, bn_stats=True)
+            before = count(1), count(0)
+            with kernel_log() as log:
+                y, part = ops.conv_fwd_in(x, w, stride, pad, scale, shift, relu=relu, addend=addend, bn_stats=True)
+            assert (count(1) - before[0], count(0) - before[1]) == (1, 0) and log.launches("tconv64_kernel<0>") == 1
+            assert torch.equal(y, y_ref) and torch.equal(part, p_ref)
+        dy = T(detgen.det_uniform(f"tcaff:{shape}:dy", (B, 8, Hi, Wi, 64)) - 0.5).to(gpu_device)
+        wg = w.clone().requires_grad_(True)
+        with kernel_log() as log:
+            ops.conv_cl(z, wg, stride, pad).backward(dy)
+        assert log.launches("twgrad64_kernel") == 1
+        before = count(1)
+        dw = ops.conv_wgrad_in(x, dy, w, stride, pad, scale, shift, relu=relu)
+        assert count(1) - before == 1
+        assert torch.equal(dw, wg.grad)
+    finally:
+        ops._DESC_CACHE.clear()
+
+
+def test_layers_that_cannot_apply_a_batchnorm_say_so(gpu_device, tconv):
+    """avid_conv_takes_in_affine is 0 for everything but conv2x's temporal layers, and avid_conv_fwd_in / avid_conv_wgrad_in refuse
+    (AVID_E_UNSUPPORTED through the error convention) instead of reading the un-normalised tensor."""
+    from avid_hip import lib, ops
+    ops._DESC_CACHE.clear()
+    try:
+        x = torch.randn(2, 4, 14, 14, 128, device=gpu_device)
+        w = ops.make_weight(128, 128, 3, 1, 1).normal_().to(gpu_device)
+        d = ops._desc_cached((2, 4, 14, 14), 128, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), False)[0]
+        assert not d.in_affine
+        sc, sh = torch.ones(128, device=gpu_device), torch.zeros(128, device=gpu_device)
+        with pytest.raises(Exception, match="does not apply its input's BatchNorm"):
+            ops.conv_fwd_in(x, w, (1, 1, 1), (1, 0, 0), sc, sh)
+        with pytest.raises(Exception, match="does not apply its input's BatchNorm"):
+            ops.conv_wgrad_in(x, torch.randn_like(x), w, (1, 1, 1), (1, 0, 0), sc, sh)
+    finally:
+        ops._DESC_CACHE.clear()

@@ -113,3 +113,40 @@ def test_weight_tables_and_the_tail_of_the_backward(compiled):
     assert sorted(pl.bwd_prog[k].i[1] for k in waits) == [plan.ST_MAIN, plan.ST_AUDIO, plan.ST_TRAIL]
     first_stem = min(k for k in range(pl.n_bwd) if pl.bwd_prog[k].op == plan.OP_BN_POOL_BWD)
     assert max(waits) < first_stem
+
+
+def test_conv2x_temporal_layers_apply_their_inputs_batchnorm_at_batch_64():
+    """At the benchmark's batch conv2x's (3,1,1) layers run on tconv64_kernel / twgrad64_kernel, which apply the BatchNorm (+ReLU) in
+    front of them while they stage their input (avid_conv_fwd_in / avid_conv_wgrad_in): spt_bn1 and spt_bn2 of both conv2x blocks
+    then make statistics only (no output tensor), the four temporal convolutions read the BatchNorm's INPUT + its saved vectors
+    in the forward and in the weight gradient — and the forward arena loses the four normalised tensors (103 MB each)."""
+    import models
+    from avid_hip import plan
+    m = models.av_wrapper("R2Plus1D", {"depth": 18}, "Conv2D", {"depth": 10}, proj_dim=[512, 512, 128]).train()
+    pl = plan.Plan(m, (64, 3, 8, 112, 112), (64, 1, 40, 100), torch.device("cpu"), True, True, True)
+    fwd = [pl.fwd_prog[k] for k in range(pl.n_fwd)]
+    bwd = [pl.bwd_prog[k] for k in range(pl.n_bwd)]
+    stats_only = [r for r in fwd if r.op == plan.OP_BN_FWD and r.t[5].slot < 0]
+    fused_fwd = [r for r in fwd if r.op == plan.OP_CONV_FWD and r.i[1] != 0]
+    fused_wgrad = [r for r in bwd if r.op == plan.OP_CONV_WGRAD and r.i[0] != 0]
+    assert len(stats_only) == len(fused_fwd) == len(fused_wgrad) == 4
+    for r in fused_fwd + fused_wgrad:
+        assert (r.d.kt, r.d.kh, r.d.kw, r.d.Cin, r.d.Cout) == (3, 1, 1, 64, 64)
+    for r in fused_fwd:
+        assert r.i[1] == 2 and r.i[2] == 64 and r.t[7].slot == plan.S_FWD          # ReLU'd BatchNorm of 64 channels, vectors in the arena
+        # the convolution reads what the statistics-only BatchNorm normalises
+        assert any(b.t[0].slot == r.t[0].slot and b.t[0].off == r.t[0].off and b.t[6].off == r.t[7].off for b in stats_only)
+    for r in fused_wgrad:
+        assert r.i[0] == 2 and r.i[1] == 64 and r.t[3].slot == plan.S_FWD
+    # with the fusion off every BatchNorm writes its output: four more tensors of 64 x 8 x 28 x 28 x 64 floats in the forward arena
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import models; from avid_hip import plan; "
+            "m = models.av_wrapper('R2Plus1D', {'depth': 18}, 'Conv2D', {'depth': 10}, proj_dim=[512, 512, 128]).train(); "
+            "pl = plan.Plan(m, (64, 3, 8, 112, 112), (64, 1, 40, 100), torch.device('cpu'), True, True, True); print(pl.fa_bytes)"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "avid-cma_amd")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, AVID_IN_AFFINE="0"))
+    assert out.returncode == 0, out.stderr[-500:]
+    assert int(out.stdout.strip().splitlines()[-1]) - pl.fa_bytes >= 4 * 64 * 8 * 28 * 28 * 64 * 4

@@ -81,8 +81,9 @@ STEP_KERNEL_PREFIXES = ("igemm_pk_kernel<4, 1, 1, 2, 0, false, 0, true>", "igemm
                         "igemm_pk_kernel<4, 1, 1, 2, 1, true, 9, true>", "igemm_pk_kernel<4, 1, 1, 4, 0, false, 0, true>",
                         "igemm_pk_kernel<4, 1, 1, 4, 0, false, 1, true>", "igemm_pk_kernel<4, 1, 1, 4, 1, false, 8, true>",
                         "wino2p_kernel<1>", "wino2p_kernel<2>", "wino2p_kernel<4>", "wino2p_kernel<6>",
-                        "wino_kernel<1>", "wino_kernel<4>", "wino_kernel<6>", "wino_wgrad_kernel", "tconv64_kernel<0, 0>",
-                        "tconv64_kernel<0, 1>", "twgrad64_kernel", "stem_fwd3p_kernel<3, 3, 1>", "stem_wgrad3_kernel<3, 3, true>",
+                        "wino_kernel<1>", "wino_kernel<4>", "wino_kernel<6>", "wino_wgrad_kernel", "tconv64_kernel<0, 0, true>",
+                        "tconv64_kernel<0, 1, true>", "tconv64_kernel<0, 0, false>", "tconv64_kernel<0, 1, false>",
+                        "twgrad64_kernel<true>", "twgrad64_kernel<false>", "stem_fwd3p_kernel<3, 3, 1>", "stem_wgrad3_kernel<3, 3, true>",
                         "wgrad_group_kernel<true, true>", "wgrad_tab_kernel<1, 3, true>", "xmodal_fused_kernel<false, 64, false>",
                         "adam_flat_kernel", "bn_apply_kernel", "bn_bwd_apply_kernel", "bn_fin_apply_kernel", "bn_bwd_fin_apply_kernel")
 SCRATCH_ALLOWED = {}        # name: (vgpr spills, private-segment bytes) of a step kernel that is allowed any: none since round 6

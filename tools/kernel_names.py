@@ -11,7 +11,8 @@ import re
 KEEP = {
     "igemm_pk_kernel": 5,          # <WM,WN,TM,TN,MODE | STRIDED,EPI,BS>: STRIDED becomes the suffix "s2"
     "igemm_kernel": 5,             # <WM,WN,TM,TN,MODE | STRIDED>
-    "tconv64_kernel": 1,           # <MODE | EPI>
+    "tconv64_kernel": 1,           # <MODE | EPI, AFF (applies the BatchNorm in front of the layer)>
+    "twgrad64_kernel": 0,          # <AFF>
     "stem_fwd3p_kernel": 2,        # <CIN,KT | TM (wave shape)>
     "stem_fwd_kernel": 2,          # <CIN,KT | WAVES>
     "stem_wgrad3_kernel": 2,       # <CIN,KT | PRE (dy fragments split by the loader)>
