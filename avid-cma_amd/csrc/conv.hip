@@ -4296,6 +4296,7 @@ extern "C" int avid_conv_wgrad_in(const avid_conv_desc* d, const float* x, const
     }
     const double M = (double)d->B * TC_T * a.HW, K = 3.0 * 64;
     {
+      ++g_tconv_launches[in ? 1 : 0];
       ScopedTimer t(s, "twgrad64_kernel", 2.0 * M * 64 * K, 4.0 * (M * 64 + M * 64 + 64 * K));
       if (in) hipLaunchKernelGGL(twgrad64_kernel<true>, dim3(grid), dim3(512), TWG_LDS, s, a);
       else hipLaunchKernelGGL(twgrad64_kernel<false>, dim3(grid), dim3(512), TWG_LDS, s, a);

@@ -50,7 +50,13 @@ int avid_timing_enable(int on);
 int avid_timing_report(char* buf, size_t len);
 
 /* ------------------------------------------------------------------------------------------------
- * Convolution = implicit GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32), exact-fp32 numerics.
+ * Convolution: fp32 in, fp32 out, fp32 accumulation, fp32-accurate products.  Which kernel a layer runs on is the library's
+ * business (avid_conv_kernel_name tells): implicit GEMM, Winograd F(2x2,3x3) for the stride-1 3x3 layers, LDS-patch kernels for
+ * the stems, a tap-sharing kernel for conv2x's (3,1,1) layers.  Since version 110 most of them assemble every fp32 product
+ * from SIX bf16 matrix instructions (v_mfma_f32_32x32x16_bf16 on operands split into three bf16 terms: error against float64
+ * at or below the fp32 instruction's, tests/test_gpu_precision.py; a non-finite input becomes NaN where the fp32 instruction
+ * would keep an infinity); wino_kernel, wino_wgrad_kernel and the bias / ReLU epilogues of the linear layers issue the fp32
+ * instruction v_mfma_f32_32x32x2_f32 itself.
  * Replaces nn.Conv3d / nn.Conv2d / nn.Linear forward+backward:
  *   models/video.py:20, models/network_blocks.py:18,20,35,37,40,42,49, models/audio.py:22,
  *   models/av_wrapper.py:25 (Linear == 1x1x1 conv over a [B,1,1,1,C] tensor).
