@@ -292,8 +292,10 @@ def reference_loop(model, crit, video, audio, ids, dev, steps=30, warmup=6, drop
             dist.destroy_process_group()
     return {"clips_s": round(video.shape[0] * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
             "what": ("avid_hip.parallel.DistributedDataParallel (1 rank) + avid_hip.parallel.Adam + loss.item() per step: the "
-                     "reference's loop, its two factory lines swapped") if dropin else
-                    "torch DDP (1 rank) + torch.optim.Adam + loss.item() per step, same model / criterion kernels"}
+                     "reference's loop with the two objects an UNMODIFIED main-avid.py gets from utils.main_utils when "
+                     "avid-cma_amd is ahead of the reference on PYTHONPATH (avid-cma_amd/utils/main_utils.py)") if dropin else
+                    "torch DDP (1 rank) + torch.optim.Adam + loss.item() per step, same model / criterion kernels "
+                    "(what AVID_DROPIN=0 leaves the reference's factories with)"}
 
 
 def forward_roofline(model, video, lib, reps=3):

@@ -199,3 +199,51 @@ def test_dropin_wrapper_on_the_per_layer_path(gpu_device):
     assert losses[0] == l_eng[0]
     np.testing.assert_allclose(losses, l_eng, rtol=1e-4)
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(opt.flat.params, opt.flat.grad_views))
+
+
+def test_reference_factories_through_utils_main_utils_build_the_dropins(gpu_device, tmp_path, monkeypatch):
+    """`utils.main_utils` of this package = the reference's module body with `torch` bound to a proxy (avid-cma_amd/utils/main_utils.py):
+    the objects `distribute_model_to_cuda` (utils/main_utils.py:112) and `build_optimizer` (:250) hand to main-avid.py's loop are the
+    flat-buffer ones — without an edit to the reference.  The GPU box has no reference checkout, so a stand-in file with the two
+    call sites' shape (written here, in this test's own words) plays its part; the real file is checked on the build box
+    (tests/test_host_logic.py).  The loop's result is the step engine's bit for bit."""
+    import importlib
+    import sys
+    import types
+    from avid_hip import parallel
+    ref = tmp_path / "ref"
+    (ref / "utils").mkdir(parents=True)
+    (ref / "utils" / "main_utils.py").write_text(
+        "import torch\n\n"
+        "def distribute_model_to_cuda(models, args, batch_size, num_workers, ngpus_per_node):\n"
+        "    torch.cuda.set_device(args.gpu)\n"
+        "    models.cuda(args.gpu)\n"
+        "    return torch.nn.parallel.DistributedDataParallel(models, device_ids=[args.gpu]), args, batch_size // ngpus_per_node, num_workers\n\n"
+        "def build_optimizer(params, cfg, logger=None):\n"
+        "    o = torch.optim.Adam(params=params, lr=cfg['lr']['base_lr'], weight_decay=cfg['weight_decay'], betas=cfg['betas'])\n"
+        "    return o, torch.optim.lr_scheduler.MultiStepLR(o, milestones=cfg['lr']['milestones'], gamma=cfg['lr']['gamma'])\n")
+    import utils
+    monkeypatch.setattr(utils, "__path__", list(utils.__path__) + [str(ref / "utils")])
+    monkeypatch.delitem(sys.modules, "utils.main_utils", raising=False)
+    monkeypatch.delenv("AVID_DROPIN", raising=False)
+    mu = importlib.import_module("utils.main_utils")
+    try:
+        assert mu.REFERENCE_FILE == str(ref / "utils" / "main_utils.py")
+        dev, steps = gpu_device, 3
+        l_eng, g_eng, sd_eng, _ = _engine_steps(dev, True, steps, 4, 64)
+        m, crit = _model(dev), _crit(dev)
+        args = types.SimpleNamespace(gpu=dev.index, distributed=True)
+        net, _, bs, _ = mu.distribute_model_to_cuda(m, args, 4, 0, 1)
+        opt, sched = mu.build_optimizer(list(net.parameters()) + list(crit.parameters()),
+                                        {"lr": {"base_lr": 2e-4, "milestones": [100], "gamma": 1.0}, "weight_decay": 1e-5, "betas": [0.9, 0.999]})
+        assert type(net) is parallel.DistributedDataParallel and type(opt) is parallel.Adam and bs == 4
+        assert opt.flat is net._engine.flat
+        video, audio, ids = _data(dev, bs=4, steps=steps, hw=64)
+        losses = _loop(net, crit, opt, video, audio, ids, steps, sched=sched)
+        assert losses == l_eng
+        sd = m.state_dict()
+        for k in sd_eng:
+            assert torch.equal(sd[k], sd_eng[k]), k
+        assert torch.equal(net._engine.flat.grad, g_eng)
+    finally:
+        sys.modules.pop("utils.main_utils", None)

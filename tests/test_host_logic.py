@@ -98,8 +98,8 @@ def test_reference_factories_resolve_build_classes():
     try:
         for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
             del sys.modules[k]
-        main_utils = importlib.import_module("utils.main_utils")          # the reference's file
-        assert main_utils.__file__.startswith(ref)
+        main_utils = importlib.import_module("utils.main_utils")          # the reference's file, executed by this package's hook
+        assert main_utils.REFERENCE_FILE.startswith(ref) and main_utils.build_model.__code__.co_filename.startswith(ref)
         cfg = yaml.safe_load(open(os.path.join(ref, "configs/main/avid/kinetics/Cross-N1024.yaml")))
         model = main_utils.build_model(cfg["model"])
         import models
@@ -171,3 +171,47 @@ def test_bench_launcher_argument_handling():
     assert "shows 1 GPU" in str(e.value) and "--gpus 2" in str(e.value)
     with pytest.raises(SystemExit):
         bench.launcher_command(8, [], 0, {})
+
+
+def test_utils_main_utils_is_the_references_module_with_the_two_factories_swapped(tmp_path):
+    """avid-cma_amd/utils/main_utils.py executes the reference's own utils/main_utils.py (found behind it on the path) in its
+    namespace and binds `torch` there to a proxy whose nn.parallel.DistributedDataParallel / optim.Adam are this build's: what
+    main-avid.py:95-108 builds through utils/main_utils.py:112,250 are then the flat-buffer objects, with nothing of the reference
+    edited.  Checked here on the real file when the checkout is present (build container), on a stand-in otherwise."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = "/root/reference"
+    if not os.path.isfile(os.path.join(ref, "utils", "main_utils.py")):
+        ref = str(tmp_path)
+        os.makedirs(os.path.join(ref, "utils"))
+        open(os.path.join(ref, "utils", "__init__.py"), "w").close()
+        with open(os.path.join(ref, "utils", "main_utils.py"), "w") as f:     # a stand-in with the two call sites' shape
+            f.write("import torch\n\ndef build_model(cfg, logger=None):\n    return None\n\n"
+                    "def distribute_model_to_cuda(models, args, batch_size, num_workers, ngpus_per_node):\n"
+                    "    return torch.nn.parallel.DistributedDataParallel(models, device_ids=[args.gpu]), args, batch_size, num_workers\n\n"
+                    "def build_optimizer(params, cfg, logger=None):\n"
+                    "    o = torch.optim.Adam(params=params, lr=cfg['lr']['base_lr'], weight_decay=cfg['weight_decay'], betas=cfg['betas'])\n"
+                    "    return o, torch.optim.lr_scheduler.MultiStepLR(o, milestones=cfg['lr']['milestones'], gamma=cfg['lr']['gamma'])\n")
+    code = r'''
+import sys, torch
+import utils.main_utils as mu
+from avid_hip import parallel
+assert mu.REFERENCE_FILE.startswith(sys.argv[1]), mu.REFERENCE_FILE
+for name in ("build_model", "distribute_model_to_cuda", "build_optimizer"):
+    f = getattr(mu, name)
+    assert f.__code__.co_filename == mu.REFERENCE_FILE and f.__globals__ is vars(mu), name      # the reference's code, this namespace
+on = sys.argv[2] == "1"
+assert (mu.torch.optim.Adam is parallel.Adam) == on and (mu.torch.nn.parallel.DistributedDataParallel is parallel.DistributedDataParallel) == on
+assert mu.torch.optim.SGD is torch.optim.SGD and mu.torch.nn.DataParallel is torch.nn.DataParallel and mu.torch.save is torch.save
+p = [torch.nn.Parameter(torch.zeros(8, 4)), torch.nn.Parameter(torch.zeros(4))]
+opt, sched = mu.build_optimizer(p, {"name": "adam", "lr": {"base_lr": 2e-4, "milestones": [10], "gamma": 1.0}, "weight_decay": 1e-5, "betas": [0.9, 0.999]})
+assert isinstance(opt, parallel.Adam if on else torch.optim.Adam) and isinstance(opt, torch.optim.Optimizer)
+assert isinstance(sched, torch.optim.lr_scheduler.MultiStepLR) and opt.param_groups[0]["lr"] == 2e-4
+print("OK")
+'''
+    for on in ("1", "0"):
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(repo, "avid-cma_amd"), ref]), AVID_DROPIN=on)
+        out = subprocess.run([sys.executable, "-c", code, ref, on], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+        assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-1500:]
