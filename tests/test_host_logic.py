@@ -215,3 +215,60 @@ print("OK")
         env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(repo, "avid-cma_amd"), ref]), AVID_DROPIN=on)
         out = subprocess.run([sys.executable, "-c", code, ref, on], capture_output=True, text=True, env=env, cwd=str(tmp_path))
         assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-1500:]
+
+
+def test_a_cu_budget_below_the_column_block_count_still_plans(tmp_path):
+    """with avid_set_cu_budget(8) and a layer of 16 column blocks, plan_pk_tile's `cus / ntn * ntn` was 0 and the next
+    line divided by it (SIGFPE).  The planner now deals at least one M-tile's worth of column blocks.  Host code only: no GPU."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, ctypes as C
+sys.path.insert(0, sys.argv[1])
+from avid_hip import lib, ops
+assert lib.raw("avid_set_cu_budget")(8) == 8
+buf = C.create_string_buffer(256)
+for cin, cout in ((64, 1024), (128, 1024), (512, 512)):
+    d = ops._desc((4, 1, 32, 32), cin, cout, (1, 1, 1), (1, 1, 1), (0, 0, 0), False)
+    for which in (0, 1):
+        assert lib.raw("avid_conv_kernel_name")(C.byref(d), which, buf, 256) == 0 and buf.value.startswith(b"igemm_pk_kernel")
+    assert lib.raw("avid_conv_fwd_workspace_bytes")(C.byref(d)) >= 0 and lib.raw("avid_conv_fwd_stats_rows")(C.byref(d)) >= 0
+print("OK")
+'''
+    out = subprocess.run([sys.executable, "-c", code, os.path.join(repo, "avid-cma_amd")], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0 and "OK" in out.stdout, (out.returncode, out.stderr[-800:])
+
+
+def test_dropin_adam_refuses_a_parameter_list_that_is_not_its_flat_buffers():
+    """ADVICE r5: Adam over a list that shares parameters with a live flat buffer without being exactly its set used to re-seat them
+    into a second buffer (the launch programs then wrote one buffer and the optimizer read the other: no learning, silently)."""
+    import pytest
+    from avid_hip import parallel
+    lin = torch.nn.Linear(8, 8)
+    extra = torch.nn.Parameter(torch.zeros(3))
+    flat = parallel.FlatParams(lin)
+    opt = parallel.Adam(lin.parameters(), lr=1e-3)
+    assert opt.flat is flat                                           # exactly the set: adopted
+    with pytest.raises(ValueError, match="not exactly that buffer's parameter set"):
+        parallel.Adam(list(lin.parameters()) + [extra], lr=1e-3)      # superset
+    with pytest.raises(ValueError, match="not exactly that buffer's parameter set"):
+        parallel.Adam([lin.weight], lr=1e-3)                          # subset
+    other = torch.nn.Linear(4, 4)
+    assert parallel.Adam(other.parameters(), lr=1e-3).flat is not flat    # untouched parameters: flattened here
+
+
+def test_grad_buckets_reset_drops_what_a_failed_backward_left_behind():
+    """ADVICE r5: per-step state of the bucketed all-reduce is restored at the start of a training forward of the wrapper
+    (GradBuckets.reset): counts a raised backward pass left behind must not keep the next step's buckets from launching."""
+    from avid_hip import parallel
+    lin = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+    flat = parallel.FlatParams(lin)
+    b = parallel.GradBuckets(flat, bucket_bytes=64)
+    counts = list(b.counts)
+    b.pending[0] -= 1                       # as if one gradient of bucket 0 had been reported when the pass died
+    b.launched[-1] = True
+    b.reported[0] = True
+    b.reset()
+    assert b.pending == counts and not any(b.launched) and not any(b.reported) and b.works == [] and b.step_set is None
