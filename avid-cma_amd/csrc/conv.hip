@@ -3001,6 +3001,18 @@ struct PkPlan {
   long long tail_row0;   // rows [tail_row0, M) are produced by splitk_reduce_kernel from f slabs
   size_t ws_floats;
 };
+// AVID_PK_OVERLAP (development): the cost of two co-resident tail units relative to running them one after the other
+static double pk_overlap() {
+  static std::atomic<int> v{-1};
+  int m = v.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("AVID_PK_OVERLAP");
+    m = e ? (int)(atof(e) * 1000.0) : 1000;
+    if (m < 500 || m > 1000) m = 1000;
+    v.store(m, std::memory_order_relaxed);
+  }
+  return m / 1000.0;
+}
 static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_out, int mode) {
   PkPlan k{};
   const int cus = device_cus();
@@ -3034,7 +3046,8 @@ static PkPlan plan_pk_tile(long long M, int Cd, int nk, int tile, double* cost_o
       const long long units = tail * f;
       if (units > G) break;
       const int maxu = units == 0 ? 0 : (int)((units + C - 1) / C);       // units on the busiest CU
-      const double cost = (double)m * (nk + ovh) + maxu * (kps + ovh) + (f > 1 ? red : 0.0);
+      // (two units on one CU run side by side, each hiding the other's load -> LDS -> barrier chains: pk_overlap() of their sum)
+      const double cost = (double)m * (nk + ovh) + (maxu == 2 ? 2.0 * pk_overlap() : (double)maxu) * (kps + ovh) + (f > 1 ? red : 0.0);
       if (cost < best - 1e-9) {
         best = cost;
         k.full = (int)full; k.tail_units = (int)units; k.f = f; k.kps = kps;
