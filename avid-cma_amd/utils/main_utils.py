@@ -9,7 +9,9 @@ for that loop (same constructors, same behaviour towards ``main-avid.py:155-180`
 asked the user to swap the two factory lines.  This module does it without touching the reference: it finds the NEXT
 ``main_utils.py`` along ``utils.__path__`` (the reference checkout's), executes that file's code in this module's namespace, and
 then binds the module-level name ``torch`` — through which the reference's functions reach both factories at call time — to a
-proxy that forwards everything to torch except ``nn.parallel.DistributedDataParallel`` and ``optim.Adam``.
+proxy that forwards everything to torch except ``nn.parallel.DistributedDataParallel`` and ``optim.Adam`` — the latter only for a
+parameter list that IS the wrapped model's flat-buffer set (main-avid.py's case); any other list (the evaluation scripts' bare models
+and parameter subsets) gets torch's own Adam.
 
 Nothing of the reference is copied or edited; without a reference checkout on the path the import fails as it would have.
 ``AVID_DROPIN=0`` leaves ``torch`` alone (the reference's module as it is)."""
@@ -48,12 +50,50 @@ class _Forward:
         return dir(object.__getattribute__(self, "_target"))
 
 
+def _adam_factory():
+    """`torch.optim.Adam` as `build_optimizer` sees it: the flat-buffer Adam exactly where it is the step engine's — the parameters
+    are the set a live `avid_hip.parallel.DistributedDataParallel` wrapper (or TrainStep) holds in its flat buffers, which is what
+    main-avid.py:93-108 produces — and torch's own Adam for everything else the reference builds optimizers for (the evaluation
+    scripts: bare models, a classifier's parameter subset, several groups), whose semantics towards parameters without a gradient
+    the one-launch step does not share."""
+    import torch
+    from avid_hip import parallel
+
+    def Adam(params, *args, **kwargs):
+        ps = list(params)
+        plain = all(isinstance(p, torch.Tensor) for p in ps)
+        if plain and ps and parallel.flat_of([p for p in ps if p.requires_grad]) is not None:
+            try:
+                return parallel.Adam(ps, *args, **kwargs)
+            except (NotImplementedError, ValueError):
+                pass
+        return torch.optim.Adam(ps, *args, **kwargs)
+    Adam.__doc__ = parallel.Adam.__doc__
+    return Adam
+
+
+def _ddp_factory():
+    """`torch.nn.parallel.DistributedDataParallel` as `distribute_model_to_cuda` sees it: this build's wrapper for this build's two-tower
+    model (`models.av_wrapper`'s class), torch's own for any other module or for arguments the wrapper does not reproduce."""
+    import torch
+    from avid_hip import parallel
+
+    class DistributedDataParallel(parallel.DistributedDataParallel):
+        def __new__(cls, module, *args, **kwargs):
+            from models.av_wrapper import AV_Wrapper
+            if not isinstance(module, AV_Wrapper):
+                return torch.nn.parallel.DistributedDataParallel(module, *args, **kwargs)
+            return super().__new__(cls)
+    DistributedDataParallel.__name__ = DistributedDataParallel.__qualname__ = "DistributedDataParallel"
+    return DistributedDataParallel
+
+
 def _torch_with_dropins():
     import torch
     from avid_hip import parallel
-    nn_parallel = _Forward(torch.nn.parallel, {"DistributedDataParallel": parallel.DistributedDataParallel})
+    nn_parallel = _Forward(torch.nn.parallel, {"DistributedDataParallel": _ddp_factory()})
     nn = _Forward(torch.nn, {"parallel": nn_parallel})
-    optim = _Forward(torch.optim, {"Adam": parallel.Adam})
+    optim = _Forward(torch.optim, {"Adam": _adam_factory()})
     return _Forward(torch, {"nn": nn, "optim": optim})
 
 

@@ -236,7 +236,11 @@ def test_reference_factories_through_utils_main_utils_build_the_dropins(gpu_devi
         net, _, bs, _ = mu.distribute_model_to_cuda(m, args, 4, 0, 1)
         opt, sched = mu.build_optimizer(list(net.parameters()) + list(crit.parameters()),
                                         {"lr": {"base_lr": 2e-4, "milestones": [100], "gamma": 1.0}, "weight_decay": 1e-5, "betas": [0.9, 0.999]})
-        assert type(net) is parallel.DistributedDataParallel and type(opt) is parallel.Adam and bs == 4
+        assert isinstance(net, parallel.DistributedDataParallel) and type(opt) is parallel.Adam and bs == 4
+        # anything but this build's two-tower model, and any parameter list but the wrapper's, gets torch's own objects
+        lin = torch.nn.Linear(4, 4).to(dev)
+        assert type(mu.build_optimizer(lin.parameters(), {"lr": {"base_lr": 1e-3, "milestones": [1], "gamma": 1.0}, "weight_decay": 0.0,
+                                                          "betas": [0.9, 0.999]})[0]) is torch.optim.Adam
         assert opt.flat is net._engine.flat
         video, audio, ids = _data(dev, bs=4, steps=steps, hw=64)
         losses = _loop(net, crit, opt, video, audio, ids, steps, sched=sched)

@@ -203,12 +203,21 @@ for name in ("build_model", "distribute_model_to_cuda", "build_optimizer"):
     f = getattr(mu, name)
     assert f.__code__.co_filename == mu.REFERENCE_FILE and f.__globals__ is vars(mu), name      # the reference's code, this namespace
 on = sys.argv[2] == "1"
-assert (mu.torch.optim.Adam is parallel.Adam) == on and (mu.torch.nn.parallel.DistributedDataParallel is parallel.DistributedDataParallel) == on
+assert (mu.torch.optim.Adam is not torch.optim.Adam) == on and (mu.torch.nn.parallel.DistributedDataParallel is not torch.nn.parallel.DistributedDataParallel and issubclass(mu.torch.nn.parallel.DistributedDataParallel, parallel.DistributedDataParallel)) == on
 assert mu.torch.optim.SGD is torch.optim.SGD and mu.torch.nn.DataParallel is torch.nn.DataParallel and mu.torch.save is torch.save
-p = [torch.nn.Parameter(torch.zeros(8, 4)), torch.nn.Parameter(torch.zeros(4))]
-opt, sched = mu.build_optimizer(p, {"name": "adam", "lr": {"base_lr": 2e-4, "milestones": [10], "gamma": 1.0}, "weight_decay": 1e-5, "betas": [0.9, 0.999]})
-assert isinstance(opt, parallel.Adam if on else torch.optim.Adam) and isinstance(opt, torch.optim.Optimizer)
-assert isinstance(sched, torch.optim.lr_scheduler.MultiStepLR) and opt.param_groups[0]["lr"] == 2e-4
+cfg = {"name": "adam", "lr": {"base_lr": 2e-4, "milestones": [10], "gamma": 1.0}, "weight_decay": 1e-5, "betas": [0.9, 0.999]}
+# a bare model's parameters (the evaluation scripts' case, eval-action-recg.py:58,76): torch's own Adam either way
+lin = torch.nn.Linear(8, 4)
+opt, sched = mu.build_optimizer(lin.parameters(), cfg)
+assert type(opt) is torch.optim.Adam and isinstance(sched, torch.optim.lr_scheduler.MultiStepLR) and opt.param_groups[0]["lr"] == 2e-4
+assert type(mu.build_optimizer([lin.weight], cfg)[0]) is torch.optim.Adam
+# the parameters of a model whose flat buffers a wrapper / engine holds (main-avid.py:93-108): the flat-buffer Adam
+net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+flat = parallel.FlatParams(net)
+opt, _ = mu.build_optimizer(list(net.parameters()), cfg)
+assert (type(opt) is parallel.Adam and opt.flat is flat) if on else type(opt) is torch.optim.Adam
+assert type(mu.build_optimizer([net[0].weight], cfg)[0]) is torch.optim.Adam          # a subset of it: torch's, nothing re-seated
+assert all(p.data_ptr() == flat.flat.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
 print("OK")
 '''
     for on in ("1", "0"):
