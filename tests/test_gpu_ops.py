@@ -1044,3 +1044,33 @@ def test_wino2_presplit_is_bit_identical(shape, cin, cout, gpu_device, kernel_lo
         ops.wino2_configure(-1)
     for a, b in zip(res[1], res[0]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,C", [(64 * 8 * 28 * 28, 64), (1024, 512), (777, 128)], ids=["conv2x", "conv5x", "ragged"])
+def test_batchnorm_statistics_only(M, C, gpu_device, kernel_log):
+    """avid_bn_fwd_train(y = NULL): the saved vectors, running statistics and the batch counter of the full call, and no apply pass —
+    what the launch programs emit in front of a convolution that applies the map itself (avid_conv_fwd_in).  Large layers: the
+    same finalize launch, bit-identical vectors; small layers (whose full call folds inside its apply launch) agree to rounding."""
+    from avid_hip import lib, ops
+    x = (T(detgen.det_normalish(f"bnso:{M}:{C}:x", (M, C))) * 1.3 - 0.2).to(gpu_device)
+    g = T(detgen.det_param(f"bnso:{M}:{C}:bn.weight", (C,))).to(gpu_device)
+    b = T(detgen.det_param(f"bnso:{M}:{C}:bn.bias", (C,))).to(gpu_device)
+    outs = []
+    for full in (True, False):
+        rm, rv = torch.zeros(C, device=gpu_device), torch.ones(C, device=gpu_device)
+        nbt = torch.zeros((), dtype=torch.int64, device=gpu_device)
+        s4 = torch.empty(4, C, device=gpu_device)
+        y = torch.empty_like(x) if full else None
+        ws = ops.workspace(gpu_device, ops._bn_ws_bytes(M, C))
+        with kernel_log() as log:
+            lib.call("avid_bn_fwd_train", M, C, ops._p(x), ops._p(g), ops._p(b), ops._p(rm), ops._p(rv), 0.1, 1e-5, 1, ops._p(y),
+                     ops._p(s4[0]), ops._p(s4[1]), ops._p(s4[2]), ops._p(s4[3]), ops._p(nbt), None, 0, ops._p(ws), ws.numel(), ops._stream())
+        if not full:
+            assert log.launches("bn_apply_kernel") == 0 and log.launches("bn_fin_apply_kernel") == 0, sorted(log.report)
+        outs.append((s4, rm, rv, int(nbt)))
+    (s4a, rma, rva, na), (s4b, rmb, rvb, nb) = outs
+    assert na == nb == 1
+    if M * C > (1 << 23):              # the full call ran the same finalize launch
+        assert torch.equal(s4a, s4b) and torch.equal(rma, rmb) and torch.equal(rva, rvb)
+    else:
+        assert relerr(s4b, s4a) < 1e-6 and relerr(rmb, rma) < 1e-6 and relerr(rvb, rva) < 1e-6
